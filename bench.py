@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: input Gbases/s of the MI355X match-finding path (BASELINE.json `metric`).
+
+Workload (BASELINE.json configs[1]): 128 synthetic 5 Mbp genomes at 99 % identity matched by the
+SlidingWindowSparseEMMatcher path against the growing reference (G0 + reverse complement preloaded,
+1.28e9-byte circular buffer, 2^27-entry table: the sizes `mbgc c` derives for 128 files,
+MGMP.cpp:130-168). A *step* is one round: every GPU matches `--round` targets (default 16) against its
+frozen replica, then every replica loads the round's extensions in target order (hash insertion
+included). With N > 1 the targets are sharded file-per-GPU and the extension bytes are all-gathered
+over RCCL; per-GPU work is fixed, so scaling is weak. Inputs are resident in HBM before the timed
+region. One JSON line is printed by rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GENOME_LEN = 5_000_000
+MAX_REF_LEN = 1_280_000_000          # 128 files -> referenceFactor 128 -> 128 * 5e6 * 2 (MGMP.cpp:130-158)
+ALG_BYTES_PER_BASE = 5.5             # whole path, per input base
+# share of the probe kernel in that figure: query scan 1 B + 0.29 sequential table probes x 4 B
+ALG_BYTES_PROBE = 1.0 + 4 * 0.29
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
+
+
+def cpu_baseline(sample_targets, length):
+    """Time the CPU path on a bounded sample of the same workload (rank 0, N = 1): G0(+RC) preloaded,
+    then `sample_targets` targets matched and appended one after another on one core. Uses the
+    reference's own code (oracle/_ref, prebuilt) when it is loadable, else the C restatement."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mbgc_amd import synth
+    kind = "port"
+    try:
+        import _refh
+        if not _refh.available():
+            raise OSError
+        _refh.lib()
+        cls, kind = _refh.RefMatcher, "reference"
+    except Exception:
+        import _orc
+        cls = _orc.OracleMatcher
+    base = synth.base_codes(length)
+    m = cls(MAX_REF_LEN)
+    m.disable_sliding_window()
+    m.load_ref(synth.genome(base, 0), load_rc=True)
+    t = 0.0
+    for i in range(1, sample_targets + 1):
+        g = synth.genome(base, i)
+        t0 = time.perf_counter()
+        m.match(g)
+        m.load_ref(g)
+        t += time.perf_counter() - t0
+    m.close()
+    return dict(value=sample_targets * length / t / 1e9, unit="Gbases/s", cores=1, kind=kind,
+                sample="G0+RC preloaded, first %d of the 128 targets (%.0f Mbases), matchTexts + loadRef, 1 thread"
+                       % (sample_targets, sample_targets * length / 1e6))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=7)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--round", type=int, default=16, help="targets per GPU per step")
+    ap.add_argument("--length", type=int, default=GENOME_LEN)
+    ap.add_argument("--cpu-sample", type=int, default=24, help="targets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--check", action="store_true", help="compare the first step's matches with the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mbgc_amd import binding, synth
+    from mbgc_amd.rounds import RoundRunner, round_schedule
+
+    R, steps, warm = args.round, args.steps, args.warmup
+    n_targets = (steps + warm) * R * world
+    base = synth.base_codes(args.length)
+    m = binding.SlidingWindowSparseEMMatcher(MAX_REF_LEN, device=local_rank)
+    stream = torch.cuda.current_stream()
+    m.set_stream(stream.cuda_stream)
+    m.set_sliding_window_size(16)
+    g0 = torch.from_numpy(synth.genome(base, 0)).to(dev)
+    torch.cuda.synchronize()
+    m.load_ref_dev(g0.data_ptr(), g0.numel(), True, True, 0)
+
+    # this rank's targets of every round, resident in HBM before the clock starts
+    sched = round_schedule(n_targets, R, world)
+    bufs = []
+    for rnd in sched:
+        mine = rnd[rank]
+        arr = np.concatenate([synth.genome(base, 1 + t) for t in mine])
+        offs = np.arange(len(mine) + 1, dtype=np.uint64) * args.length
+        bufs.append((torch.from_numpy(arr).to(dev), offs))
+    torch.cuda.synchronize()
+
+    runner = RoundRunner(m, rank, world, None, dev)
+    tot_matches = 0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(warm):
+        c = runner.run_round(*bufs[s])
+        if args.check and s == 0 and rank == 0:
+            check_against_oracle(m, base, sched[0][0], c, args.length)
+    m.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(warm, warm + steps):
+        tot_matches += int(runner.run_round(*bufs[s]).sum())
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = m.profile_get()
+    m.profile_enable(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    bases_step = R * world * args.length
+    value = bases_step * steps / dt / 1e9
+    if rank == 0:
+        dom = max(("probe", "extend", "resolve", "insert", "load"), key=lambda k: prof[k][0])
+        per_launch_ms = {k: (prof[k][0] / prof[k][1] if prof[k][1] else 0.0) for k in prof}
+        probe_ms = per_launch_ms["probe"]
+        ach = ALG_BYTES_PROBE * R * args.length / (probe_ms * 1e-3) / 1e9 if probe_ms else 0.0
+        out = {
+            "metric": "input Gbases/s (compress path, SlidingWindowSparseEMMatcher only)",
+            "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: 128 synthetic 5 Mbp genomes @99%% identity, matcher only "
+                                   "(probe+verify, extend, resolve, loadRef+insert), round = %d targets/GPU" % R,
+                       "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": MAX_REF_LEN,
+                       "hash_entries": m.hash_size(), "sharding": "file-per-GPU, all-gather of extensions"},
+            "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "alg_bytes_per_base": ALG_BYTES_PROBE, "avg_launch_ms": round(probe_ms, 4),
+                         "whole_step_frac": round(ALG_BYTES_PER_BASE * value / HBM_PEAK_GBS, 5)},
+            "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items()},
+            "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof}, "dominant_kernel": dom,
+            "matches_per_step": tot_matches // steps,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def check_against_oracle(m, base, targets, counts, length):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _orc
+    from mbgc_amd import synth
+    o = _orc.OracleMatcher(MAX_REF_LEN)
+    o.set_sliding_window_size(16)
+    o.load_ref(synth.genome(base, 0), load_rc=True)
+    locks = [o.acquire_lock() for _ in targets]
+    for i, t in enumerate(targets):
+        exp = o.match(synth.genome(base, 1 + t), 32, locks[i])
+        got = m.batch_matches(i, counts[i])
+        assert np.array_equal(exp, got), "target %d differs from the oracle" % t
+    print("check: first round identical to the oracle (%d targets)" % len(targets), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

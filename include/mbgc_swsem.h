@@ -1,0 +1,142 @@
+/* mbgc_swsem.h — C ABI of the MI355X-native MBGC match-finding hot path (libmbgc_hip.so).
+ *
+ * Drop-in boundary: the reference has no FFI; its seam is the C++ class SlidingWindowSparseEMMatcher
+ * (constructed at matching/MultipleGenomeMatchingProcessor.cpp:170-176) plus
+ * MBGC_Encoder::processMatches (mbgccoder/MBGC_Encoder.cpp:143-308). Every entry point below names
+ * the reference member it replaces (file:line under the reference tree). The C++ facade in
+ * mbgc_amd/host/ keeps the reference's class and method names and forwards here; INTEGRATION.md
+ * shows the binding a maintainer adds to the reference.
+ *
+ * Conventions: plain pointers and sizes, no exceptions, no torch types. Every function that can fail
+ * returns 0 on success and a negative SWSEM_E* code otherwise; swsem_last_error() gives the message
+ * the reference would have printed before exit(EXIT_FAILURE) — the facade performs the exit.
+ * Pointers named *_dev are HIP device pointers on the handle's device; all others are host pointers.
+ * All calls on one handle must be serialised by the caller (the reference guards the same state with
+ * `omp critical`, SlidingWindowSparseEMMatcher.cpp:365,383); different handles are independent.
+ */
+#ifndef MBGC_SWSEM_H
+#define MBGC_SWSEM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWSEM_NO_LOCK   UINT64_MAX   /* SW_END_ERASED_FLAG, SlidingWindowSparseEMMatcher.h:46 */
+#define SWSEM_SKIPPED   UINT64_MAX   /* PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY, MGMP.h:97 */
+
+#define SWSEM_OK         0
+#define SWSEM_EINVAL    -1   /* bad argument (reference: message + exit) */
+#define SWSEM_ENOMEM    -2   /* device allocation failed */
+#define SWSEM_EHIP      -3   /* HIP runtime error */
+#define SWSEM_ELOCK     -4   /* invalid worker lock value, SlidingWindowSparseEMMatcher.cpp:388-391 */
+#define SWSEM_ENODEV    -5   /* no usable gfx950 device: the product never falls back to a CPU path */
+
+typedef struct swsem swsem_t;
+
+/* TextMatch, matching/TextMatchers.h:9-16 (nextSrcRegionLoadingPos is emission scratch, kept device-side) */
+typedef struct {
+    uint64_t posSrcText, length, posDestText;
+} swsem_match_t;
+
+const char *swsem_last_error(void);
+int swsem_device_count(void);
+
+/* SlidingWindowExpSparseEMMatcher::SlidingWindowExpSparseEMMatcher, SlidingWindowSparseEMMatcher.cpp:494-519
+ * (+ base ctor :325-359, initParams :74-104). maxRefLength is explicit: the 60 %-of-RAM cap of
+ * utils/helper.h:324-339 is host policy. k1 must be even, k2 must be 1 (the only values MBGC uses). */
+int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, int skipMargin, int device);
+void swsem_destroy(swsem_t *h);                                   /* ~SlidingWindowSparseEMMatcher, .cpp:460-467 */
+/* Run every launch of this handle on an existing HIP stream (hipStream_t), e.g. the caller's. */
+int swsem_set_stream(swsem_t *h, void *hip_stream);
+int swsem_synchronize(swsem_t *h);
+
+void swsem_disable_sliding_window(swsem_t *h);                    /* .h:93 */
+void swsem_set_sliding_window_size(swsem_t *h, int factor);       /* .h:97 */
+void swsem_disable_circular_buffer(swsem_t *h);                   /* .h:95 */
+uint64_t swsem_get_ref_length(const swsem_t *h);                  /* getRefLength, .h:106 */
+uint64_t swsem_get_loading_position(const swsem_t *h);            /* getLoadingPosition, .h:107 */
+uint64_t swsem_get_loaded_ref_length(const swsem_t *h);           /* getLoadedRefLength, .h:108 */
+uint64_t swsem_get_max_ref_length(const swsem_t *h);              /* getMaxRefLength, .h:105 */
+void swsem_set_position(swsem_t *h, uint64_t refPos, int reachedRefLengthCount);  /* setPosition, .h:110-113 */
+uint64_t swsem_acquire_lock(swsem_t *h);                          /* acquireWorkerMatchingLockPos, .cpp:361-378 */
+int swsem_release_lock(swsem_t *h, uint64_t lockValue);           /* releaseWorkerMatchingLockPos, .cpp:380-400 */
+int swsem_get_K(const swsem_t *h);
+uint32_t swsem_get_hash_size(const swsem_t *h);
+
+/* loadRef(refText, refLength, loadRCRef, addRegionSeparators, regionSeparator), .cpp:453-458 (-> :402-437,
+ * :146-171, utils/helper.cpp:405-410). Must be applied identically, in call order, on every replica. */
+int swsem_load_ref(swsem_t *h, const uint8_t *text, uint64_t len, int loadRC, int addSep, int sep);
+int swsem_load_ref_dev(swsem_t *h, const uint8_t *text_dev, uint64_t len, int loadRC, int addSep, int sep);
+int swsem_load_separator(swsem_t *h, int sep);                    /* loadSeparator, .cpp:439-451 */
+
+/* matchTexts(resMatches, destText, destLen, false, false, minMatchLength, matchingLockPos), .cpp:478-492.
+ * *matches points into a handle-owned buffer that stays valid until the next match call on the
+ * handle (the reference fills a caller-owned vector it clears on entry, .cpp:484). */
+int swsem_match(swsem_t *h, const uint8_t *query, uint64_t len, uint32_t minMatchLength, uint64_t lockPos,
+                const swsem_match_t **matches, uint64_t *nmatches);
+
+/* A round: n contigs matched against the frozen reference in one pass (what the reference's worker
+ * threads do concurrently, MGMP.cpp:340-403). queries_dev holds the contigs back to back, contig c at
+ * [offsets[c], offsets[c+1]); offsets/lockPos are host arrays. Results stay in HBM (for swsem_emit_batch)
+ * and can be fetched per contig. */
+int swsem_match_batch_dev(swsem_t *h, const uint8_t *queries_dev, const uint64_t *offsets, int n,
+                          uint32_t minMatchLength, const uint64_t *lockPos);
+int swsem_batch_counts(swsem_t *h, uint64_t *nmatches /* [n] */);
+int swsem_batch_matches(swsem_t *h, int contig, swsem_match_t *out, uint64_t cap);
+/* order-sensitive fingerprint of all match rows of the batch, computed on the device copy */
+int swsem_batch_fingerprint(swsem_t *h, uint64_t *fp, uint64_t *total_matches, uint64_t *total_length);
+
+/* ---- emission: MBGC_Encoder::processMatches (+extendMatchLeft/Right, mismatch2code), MBGC_Encoder.cpp:143-427 */
+typedef struct {
+    int enableExtensionsWithMismatches;   /* MBGC_Params.h:76 */
+    int mismatchesWithExclusion;          /* :77 */
+    int lazyDecompressionSupport;         /* :38 */
+    int enable40bitReference;             /* MGMP_Params.h:208 / MGMP.cpp:159-166 */
+    int frugal64bitLenEncoding;           /* MBGC_Params.h:73 */
+    int gapDepthOffsetEncoding;           /* :79 */
+    int gapDepthMismatchesEncoding;       /* :80 */
+    uint64_t gapBreakingMatchMinLength;   /* :81 */
+    int mmsMatchBonus, mmsMismatchPenalty, mmsMismatchesScoreThreshold, mmsMismatchesInitialScore; /* :92-97 */
+    int allowedTargetsOutrunForDissimilarContigs;           /* MGMP_Params.h:78 */
+    uint64_t minimalLengthForDissimilarContigs;             /* :79 */
+    int unmatchedFractionFactorTweakForDissimilarContigs;   /* :80 */
+} swsem_emit_params_t;
+void swsem_emit_params_default(swsem_emit_params_t *p, int mode /* -m 0..3, MBGC_Params.h:886-922 */);
+
+enum { SWSEM_LIT = 0, SWSEM_OFF = 1, SWSEM_OFF5 = 2, SWSEM_LEN = 3, SWSEM_GAP = 4, SWSEM_FLAGS = 5, SWSEM_NSTREAMS = 6 };
+
+typedef struct {
+    const uint8_t *data[SWSEM_NSTREAMS];  /* host pointers into a handle-owned buffer (valid until the next emit call) */
+    uint64_t size[SWSEM_NSTREAMS];
+    uint64_t unmatchedChars;              /* return value of processMatches, or SWSEM_SKIPPED */
+    /* the counters processMatches adds to atomically, MBGC_Encoder.cpp:293-306 */
+    uint64_t extensionsMatchedChars, extensionsMismatches, totalMatched, removedGapBreakingMatches;
+    uint64_t nmatches;                    /* matches left after the gap-breaking pass */
+} swsem_streams_t;
+
+/* processMatches for contig `contig` of the last swsem_match_batch_dev (or contig 0 of the last swsem_match).
+ * refExtLoadedPos/nLoaded = the encoder's refExtLoadedPosArr (lazy mode). processedTargetsCount/targetIdx/
+ * unmatchedFractionFactor feed the dissimilarity early-out (:202-205). */
+int swsem_emit(swsem_t *h, const swsem_emit_params_t *p, int contig, uint64_t lockPos,
+               int unmatchedFractionFactor, int64_t processedTargetsCount, int64_t targetIdx,
+               const uint64_t *refExtLoadedPos, uint64_t nLoaded, swsem_streams_t *out);
+
+/* ---- test / measurement hooks (not part of the reference surface) */
+int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out);      /* getRef() bytes, .h:104 */
+int swsem_debug_copy_ht(swsem_t *h, uint32_t *out /* [hash_size] 32-bit image as on the CPU */);
+enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2, SWSEM_K_EXTEND = 3, SWSEM_K_RESOLVE = 4,
+       SWSEM_K_STITCH = 5, SWSEM_K_EMIT = 6, SWSEM_K_COUNT = 7 };
+/* When enabled every kernel launch is bracketed by HIP events on the handle's stream; the accumulated
+ * device time (ms) and launch count per kernel family are read back with swsem_profile_get. */
+int swsem_profile_enable(swsem_t *h, int on);
+int swsem_profile_get(swsem_t *h, double ms[SWSEM_K_COUNT], uint64_t launches[SWSEM_K_COUNT]);
+/* algorithmic counters of the last batch: [0] query bases, [1] hash-table probes, [2] verified hits,
+ * [3] matches, [4] sum of match lengths */
+int swsem_batch_stats(swsem_t *h, uint64_t stats[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

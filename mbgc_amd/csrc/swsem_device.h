@@ -1,0 +1,91 @@
+// Shared device-side definitions of the MI355X match-finding path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace swk {
+
+constexpr int WAVE = 64;
+constexpr int TILE = 4096;            // query positions per probe tile (= one resolve block)
+constexpr int PROBE_THREADS = 256;
+constexpr int POS_PER_THREAD = TILE / PROBE_THREADS;
+constexpr uint32_t EXT_CAP = 2048;    // bytes compared per side by the per-hit extension kernel
+constexpr int OVERLAP_MATCH_MAX_LENGTH = 1 << 13;   // SlidingWindowSparseEMMatcher.h:18
+
+// Hash-table entry: (epoch << 32) | (pos >> k1ord). The reference's table is "last writer wins" in
+// sample order (SlidingWindowSparseEMMatcher.cpp:146-171); every insertion phase gets a fresh,
+// larger epoch and positions ascend inside a phase, so a 64-bit atomicMax reproduces exactly the
+// image a single CPU thread leaves behind. The low word alone is the reference's 32-bit entry.
+typedef unsigned long long ht_entry;
+
+// one verified k-mer hit of a query position (32 B)
+struct __attribute__((aligned(16))) Hit {
+    uint64_t c;        // reference position of the sample (htDecodePos)
+    uint32_t i;        // query position
+    uint32_t ell;      // equal bytes to the left of (c,i), limited to min(i, c - lo) and EXT_CAP
+    uint32_t rext;     // equal bytes to the right of (c+K, i+K), limited by hi / N and EXT_CAP
+    uint32_t loDist;   // c - tmpStart1, saturated
+    uint32_t flags;    // bit0: ell hit the cap, bit1: rext hit the cap
+    uint32_t pad;
+};
+constexpr uint32_t HIT_CAPL = 1u, HIT_CAPR = 2u;
+
+struct Match {         // == swsem_match_t
+    uint64_t posSrc, len, posDest;
+};
+
+// per-contig description of a round
+struct Contig {
+    uint64_t qoff;     // byte offset of the contig in the query buffer
+    uint64_t n;        // contig length
+    uint64_t lock;     // matchingLockPos or UINT64_MAX
+    uint64_t matchBase;// first row of this contig in the batch match array
+    uint32_t tile0;    // first tile of this contig
+    uint32_t ntiles;
+    uint32_t matchCap; // rows reserved
+    uint32_t pad;
+};
+
+// frozen matcher state seen by the kernels of one round
+struct RefView {
+    const uint8_t *ref;
+    const ht_entry *ht;
+    uint64_t pos1, refLength, maxRefLength;
+    uint32_t mask;
+    int K, k1ord, skipMargin;
+    uint32_t minLen;
+};
+
+// little-endian u32 at an arbitrary byte address, built from two aligned dwords. An aligned dword
+// that holds at least one valid byte never crosses a page, so this is safe at buffer ends as long as
+// the caller only asks for addresses whose 4 bytes are valid.
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
+    const uintptr_t a = (uintptr_t) p;
+    const uint32_t *b = (const uint32_t *) (a & ~(uintptr_t) 3);
+    const uint32_t sh = (uint32_t) (a & 3);
+    const uint32_t lo = b[0];
+    if (sh == 0) return lo;
+    return __builtin_amdgcn_alignbyte(b[1], lo, sh);
+}
+
+// maRushPrime1HashSimplified<K>, utils/Hashes.h:28-40, one step (pure u32 arithmetic is exact)
+__device__ __forceinline__ uint32_t hash_step(uint32_t h, uint32_t k, uint32_t j) {
+    return (h ^ (k + j)) * 171717u;
+}
+
+// window test of SlidingWindowSparseEMMatcher.cpp:212-222. Returns false when the entry is rejected.
+__device__ __forceinline__ bool window_ok(const RefView &v, uint64_t lock, uint64_t c, uint64_t &lo, uint64_t &hi) {
+    const uint64_t swStart = v.pos1;
+    const uint64_t swStop = lock != UINT64_MAX ? lock : v.pos1;
+    const bool endsBefore = c + (uint64_t) v.K < swStart;
+    const bool startsBefore = c < swStop;
+    if (swStart <= swStop) {
+        if (!endsBefore && startsBefore) return false;
+    } else if (!endsBefore || startsBefore)
+        return false;
+    hi = endsBefore ? swStart : v.refLength;
+    lo = startsBefore ? 0 : swStop;
+    return true;
+}
+
+}  // namespace swk

@@ -1,0 +1,439 @@
+// Hand-written CDNA4 (gfx950) kernels of the MBGC match-finding hot path: reference loading
+// (copy / reverse complement / sparse k-mer insertion), hash-table probing with k-mer verification,
+// per-hit exact extension and the greedy match resolution. Integer/byte work, HBM-bound: no MFMA.
+#include "swsem_device.h"
+
+namespace swk {
+
+// ------------------------------------------------------------------------------------------------
+// reference loading: SlidingWindowSparseEMMatcher::loadRef (private), .cpp:402-437
+// ------------------------------------------------------------------------------------------------
+
+// PgHelpers::upperReverseComplement, utils/helper.cpp:405-410: dst[n-1-i] = LUT[src[i]].
+// Each thread produces 4 consecutive destination bytes (one dword store when aligned).
+__global__ void __launch_bounds__(256) k_load_rc(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                 uint64_t n, const uint8_t *__restrict__ lut) {
+    __shared__ uint8_t slut[256];
+    slut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x * 4;
+    for (uint64_t d = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4; d < n; d += stride) {
+        const uint64_t m = n - d < 4 ? n - d : 4;
+#pragma unroll
+        for (uint64_t k = 0; k < 4; k++)
+            if (k < m) dst[d + k] = slut[src[n - 1 - d - k]];
+    }
+}
+
+__global__ void k_set_byte(uint8_t *p, uint8_t v) { *p = v; }
+
+// processIgnoreCollisionsRef, .cpp:146-171. Thread t < nMain inserts the main-loop sample at
+// S + t*k1 with epoch `epoch`; thread nMain + u inserts the tail sample T + u*k1 with epoch + 1
+// (the tail runs after the main loop on the CPU, so it wins collisions against it).
+__global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
+                                                uint64_t S, uint64_t nMain, uint64_t T, uint64_t nTail, int k1,
+                                                int k1ord, int K, uint32_t mask, uint32_t epoch) {
+    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nMain + nTail) return;
+    const bool tail = t >= nMain;
+    const uint64_t p = tail ? T + (t - nMain) * (uint64_t) k1 : S + t * (uint64_t) k1;
+    const uint8_t *s = ref + p;
+    uint32_t h = (uint32_t) K;
+    const int nw = K / 4;
+    for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
+    const ht_entry key = ((ht_entry) (epoch + (tail ? 1u : 0u)) << 32) | (ht_entry) (uint32_t) (p >> k1ord);
+    atomicMax(&ht[h & mask], key);
+}
+
+__global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict__ ht, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t) ht[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// probe + verify: the query scan of processExactMatchQueryIgnoreCollisionsTight, .cpp:200-226,:298
+// One workgroup = one tile of TILE consecutive query positions of one contig. The tile's bytes are
+// staged once into LDS with coalesced dword loads; every position's K-mer hash is built from LDS,
+// the hash table is gathered (one 8-byte entry per position, all gathers of a thread in flight
+// together), entries passing the sliding-window test are verified against the reference K-mer, and
+// the verified hits are compacted in position order into the tile's slot range.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_t *__restrict__ qbuf,
+                                                         const Contig *__restrict__ contigs,
+                                                         const uint32_t *__restrict__ tileContig,
+                                                         Hit *__restrict__ hits, uint32_t *__restrict__ tileCount,
+                                                         unsigned long long *__restrict__ stats) {
+    __shared__ uint32_t qs[TILE / 4 + 24];
+    __shared__ uint32_t waveCnt[POS_PER_THREAD][PROBE_THREADS / WAVE];
+    const uint32_t tile = blockIdx.x;
+    const Contig cg = contigs[tileContig[tile]];
+    const uint64_t ts = (uint64_t) (tile - cg.tile0) * TILE;        // first position of the tile
+    const int K = v.K;
+    const uint64_t npos_all = cg.n + 1 >= (uint64_t) K + 1 ? cg.n - K + 1 : 0;   // positions i with i + K <= N
+    const uint32_t npos = npos_all > ts ? (uint32_t) (npos_all - ts < TILE ? npos_all - ts : TILE) : 0;
+    const uint8_t *q = qbuf + cg.qoff;
+    // stage bytes [ts, ts + npos + K - 1) from the enclosing aligned dwords
+    const uintptr_t A = (uintptr_t) (q + ts);
+    const uint32_t sh = (uint32_t) (A & 3);
+    const uint32_t *A0 = (const uint32_t *) (A & ~(uintptr_t) 3);
+    const uint32_t nbytes = npos ? npos + K - 1 : 0;
+    const uint32_t ndw = (sh + nbytes + 3) / 4;
+    for (uint32_t w = threadIdx.x; w < ndw; w += PROBE_THREADS) qs[w] = A0[w];
+    __syncthreads();
+
+    const int nw = K / 4;
+    uint32_t hsh[POS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < POS_PER_THREAD; k++) {
+        const uint32_t j = k * PROBE_THREADS + threadIdx.x;
+        uint32_t h = (uint32_t) K;
+        if (j < npos) {
+            const uint32_t o = sh + j;
+            const uint32_t *w = qs + (o >> 2);
+            const uint32_t s = o & 3;
+            uint32_t lo = w[0];
+            for (int x = 0; x < nw; x++) {
+                const uint32_t hi = w[x + 1];
+                h = hash_step(h, __builtin_amdgcn_alignbyte(hi, lo, s), (uint32_t) x);
+                lo = hi;
+            }
+        }
+        hsh[k] = h & v.mask;
+    }
+    // all gathers of this thread are issued before the first one is consumed
+    uint32_t ent[POS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < POS_PER_THREAD; k++) {
+        const uint32_t j = k * PROBE_THREADS + threadIdx.x;
+        ent[k] = j < npos ? (uint32_t) v.ht[hsh[k]] : 0u;
+    }
+    uint64_t cpos[POS_PER_THREAD];
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    uint32_t nver = 0;
+#pragma unroll
+    for (int k = 0; k < POS_PER_THREAD; k++) {
+        const uint32_t j = k * PROBE_THREADS + threadIdx.x;
+        uint64_t c = 0;
+        if (ent[k] != 0) {                                            // .cpp:208
+            c = (uint64_t) ent[k] << v.k1ord;                         // htDecodePos, .h:133
+            uint64_t lo, hi;
+            if (!window_ok(v, cg.lock, c, lo, hi)) c = 0;
+        }
+        if (c) {                                                      // memcmp(curr1, curr2, K) == 0, .cpp:298
+            const uint32_t o = sh + j;
+            const uint32_t *w = qs + (o >> 2);
+            const uint32_t s = o & 3;
+            const uint8_t *r = v.ref + c;
+            uint32_t lo = w[0];
+            bool same = true;
+            for (int x = 0; x < nw; x++) {
+                const uint32_t hi = w[x + 1];
+                same &= __builtin_amdgcn_alignbyte(hi, lo, s) == ld_u32(r + 4 * x);
+                lo = hi;
+            }
+            if (!same) c = 0;
+        }
+        cpos[k] = c;
+        const unsigned long long b = __ballot(c != 0);
+        if (lane == 0) waveCnt[k][wv] = (uint32_t) __popcll(b);
+        nver += c != 0;
+    }
+    __syncthreads();
+    // position order inside the tile = (k, wave, lane) lexicographic
+    uint32_t base = 0, total = 0;
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < POS_PER_THREAD; k++)
+#pragma unroll
+            for (int w = 0; w < PROBE_THREADS / WAVE; w++) run += waveCnt[k][w];
+        total = run;
+    }
+    Hit *out = hits + (uint64_t) tile * TILE;
+#pragma unroll
+    for (int k = 0; k < POS_PER_THREAD; k++) {
+        uint32_t off = base;
+        for (uint32_t w = 0; w < wv; w++) off += waveCnt[k][w];
+        const unsigned long long b = __ballot(cpos[k] != 0);
+        if (cpos[k]) {
+            const uint32_t slot = off + (uint32_t) __popcll(b & ((1ull << lane) - 1));
+            Hit hrec;
+            hrec.c = cpos[k];
+            hrec.i = (uint32_t) (ts + k * PROBE_THREADS + threadIdx.x);
+            hrec.ell = 0; hrec.rext = 0; hrec.loDist = 0; hrec.flags = 0; hrec.pad = 0;
+            out[slot] = hrec;
+        }
+#pragma unroll
+        for (int w = 0; w < PROBE_THREADS / WAVE; w++) base += waveCnt[k][w];
+    }
+    if (threadIdx.x == 0) {
+        tileCount[tile] = total;
+        atomicAdd(&stats[1], (unsigned long long) npos);
+        atomicAdd(&stats[2], (unsigned long long) total);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-hit exact extension (.cpp:227-246 to the right, the equality run used by :257-259,:264-266,
+// :278-280 to the left). One thread per verified hit; runs are capped at EXT_CAP bytes and flagged,
+// the resolve kernel continues a capped run on demand.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *a, const uint8_t *b, uint32_t maxlen) {
+    uint32_t n = 0;
+    while (n + 4 <= maxlen) {
+        const uint32_t x = ld_u32(a + n) ^ ld_u32(b + n);
+        if (x) return n + (uint32_t) (__builtin_ctz(x) >> 3);
+        n += 4;
+    }
+    while (n < maxlen && a[n] == b[n]) n++;
+    return n;
+}
+// equal bytes at a[-1], a[-2], ... vs b[-1], b[-2], ...
+__device__ __forceinline__ uint32_t lcp_bwd(const uint8_t *a, const uint8_t *b, uint32_t maxlen) {
+    uint32_t n = 0;
+    while (n + 4 <= maxlen) {
+        const uint32_t x = ld_u32(a - n - 4) ^ ld_u32(b - n - 4);
+        if (x) return n + (uint32_t) (__builtin_clz(x) >> 3);
+        n += 4;
+    }
+    while (n < maxlen && a[-(int64_t) n - 1] == b[-(int64_t) n - 1]) n++;
+    return n;
+}
+
+__global__ void __launch_bounds__(256) k_extend(RefView v, const uint8_t *__restrict__ qbuf,
+                                                const Contig *__restrict__ contigs,
+                                                const uint32_t *__restrict__ tileContig, Hit *__restrict__ hits,
+                                                const uint32_t *__restrict__ tileCount) {
+    const uint32_t tile = blockIdx.x / (TILE / 256);
+    const uint32_t slot = (blockIdx.x % (TILE / 256)) * 256 + threadIdx.x;
+    if (slot >= tileCount[tile]) return;
+    const Contig cg = contigs[tileContig[tile]];
+    Hit *hp = hits + (uint64_t) tile * TILE + slot;
+    const uint64_t c = hp->c;
+    const uint32_t i = hp->i;
+    uint64_t lo, hi;
+    window_ok(v, cg.lock, c, lo, hi);
+    const uint8_t *q = qbuf + cg.qoff;
+    const uint64_t maxR64 = (hi - (c + v.K)) < (cg.n - ((uint64_t) i + v.K)) ? (hi - (c + v.K)) : (cg.n - ((uint64_t) i + v.K));
+    const uint32_t maxR = maxR64 > EXT_CAP ? EXT_CAP : (uint32_t) maxR64;
+    const uint32_t rext = lcp_fwd(v.ref + c + v.K, q + i + v.K, maxR);
+    const uint64_t loDist = c - lo;
+    const uint64_t jmax64 = (uint64_t) i < loDist ? (uint64_t) i : loDist;
+    const uint32_t jmax = jmax64 > EXT_CAP ? EXT_CAP : (uint32_t) jmax64;
+    const uint32_t ell = lcp_bwd(v.ref + c, q + i, jmax);
+    uint32_t flags = 0;
+    if (rext == EXT_CAP && maxR64 > EXT_CAP) flags |= HIT_CAPR;
+    if (ell == EXT_CAP && jmax64 > EXT_CAP) flags |= HIT_CAPL;
+    hp->ell = ell;
+    hp->rext = rext;
+    hp->loDist = loDist > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) loDist;
+    hp->flags = flags;
+}
+
+// ------------------------------------------------------------------------------------------------
+// greedy resolution: the match list semantics of .cpp:250-315, replayed on the precomputed hits.
+// One wave per chain; every lane runs the same (wave-uniform) automaton, 64 hits are fetched per
+// step and skipped hits are jumped over with a ballot. No reference or query byte is touched
+// unless a capped run has to be continued.
+// ------------------------------------------------------------------------------------------------
+struct Chain {
+    int64_t scan;          // next query position the sequential loop would visit
+    int32_t sp;            // match-stack size
+    int32_t ringLow;       // lowest stack index whose copy in the LDS ring is valid
+    int32_t minTouched;    // lowest stack index examined so far (-1: walked off the bottom)
+};
+
+constexpr int RING = 64;
+
+__device__ __forceinline__ void stack_get(const Match *st, const uint2 *ring, const Chain &ch, int idx,
+                                          int64_t &posDest, int64_t &len) {
+    if (idx >= ch.ringLow) {
+        const uint2 e = ring[idx & (RING - 1)];
+        posDest = e.x; len = e.y;
+    } else {
+        posDest = (int64_t) st[idx].posDest; len = (int64_t) st[idx].len;
+    }
+}
+
+// continue a capped left run (wave-cooperative, 256 bytes per step)
+__device__ uint32_t wave_more_left(const uint8_t *a, const uint8_t *b, uint32_t have, uint64_t limit) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    uint64_t n = have;
+    while (n + 4 * WAVE <= limit) {
+        const uint32_t x = ld_u32(a - n - 4 * lane - 4) ^ ld_u32(b - n - 4 * lane - 4);
+        const unsigned long long bad = __ballot(x != 0);
+        if (bad) {
+            const int l = __builtin_ctzll(bad);
+            const uint32_t xl = __shfl(x, l);
+            return (uint32_t) (n + 4 * l + (__builtin_clz(xl) >> 3));
+        }
+        n += 4 * WAVE;
+    }
+    while (n < limit && a[-(int64_t) n - 1] == b[-(int64_t) n - 1]) n++;
+    return (uint32_t) n;
+}
+__device__ uint32_t wave_more_right(const uint8_t *a, const uint8_t *b, uint32_t have, uint64_t limit) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    uint64_t n = have;
+    while (n + 4 * WAVE <= limit) {
+        const uint32_t x = ld_u32(a + n + 4 * lane) ^ ld_u32(b + n + 4 * lane);
+        const unsigned long long bad = __ballot(x != 0);
+        if (bad) {
+            const int l = __builtin_ctzll(bad);
+            const uint32_t xl = __shfl(x, l);
+            return (uint32_t) (n + 4 * l + (__builtin_ctz(xl) >> 3));
+        }
+        n += 4 * WAVE;
+    }
+    while (n < limit && a[n] == b[n]) n++;
+    return (uint32_t) n;
+}
+
+// Processes one visited hit. All arguments are wave-uniform. Returns true when a match was emitted.
+__device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q, Match *st, uint2 *ring,
+                            Chain &ch, uint64_t c, int64_t i, int64_t ell, int64_t rext, int64_t loDist,
+                            uint32_t flags) {
+    const int64_t K = v.K;
+    uint64_t lo = 0, hi = 0;
+    if (flags) window_ok(v, cg.lock, c, lo, hi);
+    // true left run on demand: the automaton below only ever asks "is ell >= x", so a capped run is
+    // continued the first time it could matter
+    auto need_ell = [&](int64_t x) {
+        if ((flags & HIT_CAPL) && x > ell) {
+            const uint64_t d = c - lo;
+            const uint64_t jmax = (uint64_t) i < d ? (uint64_t) i : d;
+            ell = wave_more_left(v.ref + c, q + i, (uint32_t) ell, jmax);
+            flags &= ~HIT_CAPL;
+        }
+    };
+    int64_t s = 0;                                   // (p1, p2) = (c - s, i - s)
+    int keep = ch.sp;                                // resSizeWithoutOverlapped
+    bool brokeOut = false;
+    while (keep-- > 0) {                             // .cpp:253
+        int64_t mPos, mLen;
+        stack_get(st, ring, ch, keep, mPos, mLen);
+        const int64_t mEnd = mPos + mLen;
+        if (mEnd < i - s) {                          // .cpp:255
+            const int64_t g = mEnd;
+            need_ell((loDist < i - g + 1 ? loDist : i - g + 1) - 1);
+            int64_t t = loDist < i - g + 1 ? loDist : i - g + 1;
+            if (ell + 1 < t) t = ell + 1;
+            if (t > s) s = t;                        // .cpp:257-259
+            if (i - s > g - 1) { brokeOut = true; break; }   // .cpp:260-261
+            s -= 1;                                  // .cpp:262
+        }
+        const int64_t d = (i - s) - mPos;            // lastDelta, .cpp:264
+        bool fail = (loDist - s < d) || (mLen > OVERLAP_MATCH_MAX_LENGTH);
+        if (!fail) {
+            need_ell(s + d);
+            fail = ell < s + d;                      // strcmplcp(...) != 0, .cpp:266
+        }
+        if (fail) { s += 1; brokeOut = true; break; }        // .cpp:267-268
+        s += d;                                      // .cpp:270
+    }
+    if (!brokeOut) keep = -1;
+    if (keep < ch.minTouched) ch.minTouched = keep;
+    if (keep < 0) {                                  // .cpp:277-280
+        need_ell((loDist < i + 1 ? loDist : i + 1) - 1);
+        int64_t t = loDist < i + 1 ? loDist : i + 1;
+        if (ell + 1 < t) t = ell + 1;
+        if (t > s) s = t;
+    } else {                                         // .cpp:285-289
+        int64_t mPos, mLen;
+        stack_get(st, ring, ch, keep, mPos, mLen);
+        const int64_t overlap = (mPos + mLen) - (i - s + 1);
+        if (overlap > 0) s -= overlap;
+    }
+    ++keep;
+    // right1 - p1 > minMatchLength, .cpp:298 (the K-mer itself was verified by the probe kernel)
+    if (K + rext + s > (int64_t) v.minLen || (flags & HIT_CAPR)) {
+        if (flags & HIT_CAPR) {
+            const uint64_t a = hi - (c + K), b = cg.n - ((uint64_t) i + K);
+            rext = wave_more_right(v.ref + c + K, q + i + K, (uint32_t) rext, a < b ? a : b);
+            flags &= ~HIT_CAPR;
+        }
+        if (K + rext + s > (int64_t) v.minLen) {
+            Match m;
+            m.posSrc = (uint64_t) ((int64_t) c - s + 1);
+            m.len = (uint64_t) (K + rext + s - 1);
+            m.posDest = (uint64_t) (i - s + 1);
+            ch.sp = keep;                            // resMatches.resize(...), .cpp:299
+            if ((threadIdx.x & (WAVE - 1)) == 0) st[ch.sp] = m;
+            ring[ch.sp & (RING - 1)] = make_uint2((uint32_t) m.posDest, (uint32_t) m.len);
+            if (ch.sp - (RING - 1) > ch.ringLow) ch.ringLow = ch.sp - (RING - 1);
+            if (ch.ringLow > ch.sp) ch.ringLow = ch.sp;
+            ch.sp++;
+            int64_t skip = K + rext;                 // (matchEnd - i2), k2 == 1, .cpp:308
+            skip -= skip > v.skipMargin ? v.skipMargin : skip;
+            ch.scan = skip ? i + skip : i + 1;       // .cpp:310-313 then the loop's i2 += k2
+            return true;
+        }
+    }
+    ch.scan = i + 1;
+    return false;
+}
+
+// Runs the chain over the hits of tiles [t0, t1) of one contig.
+__device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const Hit *__restrict__ hits,
+                          const uint32_t *__restrict__ tileCount, uint32_t t0, uint32_t t1, Match *st,
+                          uint2 *ring, Chain &ch) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    for (uint32_t t = t0; t < t1; t++) {
+        const uint32_t cnt = tileCount[t];
+        const Hit *th = hits + (uint64_t) t * TILE;
+        if ((int64_t) (t - cg.tile0 + 1) * TILE <= ch.scan) continue;   // the whole tile was jumped over
+        for (uint32_t b = 0; b < cnt; b += WAVE) {
+            Hit h;
+            bool valid = b + lane < cnt;
+            if (valid) h = th[b + lane];
+            else { h.c = 0; h.i = 0; h.ell = 0; h.rext = 0; h.loDist = 0; h.flags = 0; h.pad = 0; }
+            while (true) {
+                const unsigned long long m = __ballot(valid && (int64_t) h.i >= ch.scan);
+                if (!m) break;
+                const int l = __builtin_ctzll(m);
+                const uint64_t c = ((uint64_t) (uint32_t) __shfl((int) (h.c >> 32), l) << 32) |
+                                   (uint32_t) __shfl((int) (uint32_t) h.c, l);
+                const int64_t i = (uint32_t) __shfl((int) h.i, l);
+                const int64_t ell = (uint32_t) __shfl((int) h.ell, l);
+                const int64_t rext = (uint32_t) __shfl((int) h.rext, l);
+                const int64_t loDist = (uint32_t) __shfl((int) h.loDist, l);
+                const uint32_t flags = (uint32_t) __shfl((int) h.flags, l);
+                process_hit(v, cg, q, st, ring, ch, c, i, ell, rext, loDist, flags);
+                valid = valid && lane > (uint32_t) l;
+            }
+        }
+    }
+}
+
+// v1 resolution: one wave replays a whole contig.
+__global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *__restrict__ qbuf,
+                                                      const Contig *__restrict__ contigs,
+                                                      const Hit *__restrict__ hits,
+                                                      const uint32_t *__restrict__ tileCount,
+                                                      Match *__restrict__ matches, uint32_t *__restrict__ matchCount) {
+    __shared__ uint2 ring[RING];
+    const Contig cg = contigs[blockIdx.x];
+    Chain ch;
+    ch.scan = 0; ch.sp = 0; ch.ringLow = 0; ch.minTouched = 0;
+    run_chain(v, cg, qbuf + cg.qoff, hits, tileCount, cg.tile0, cg.tile0 + cg.ntiles, matches + cg.matchBase,
+              ring, ch);
+    if (threadIdx.x == 0) matchCount[blockIdx.x] = (uint32_t) ch.sp;
+}
+
+// order-sensitive fingerprint of the whole batch, single thread: test hook only
+__global__ void k_fingerprint(const Contig *__restrict__ contigs, int n, const Match *__restrict__ matches,
+                              const uint32_t *__restrict__ matchCount, unsigned long long *out) {
+    unsigned long long fp = 0xcbf29ce484222325ull, tot = 0, len = 0;
+    for (int c = 0; c < n; c++) {
+        const Match *m = matches + contigs[c].matchBase;
+        for (uint32_t k = 0; k < matchCount[c]; k++) {
+            fp ^= m[k].posSrc; fp *= 0x100000001b3ull;
+            fp ^= m[k].len; fp *= 0x100000001b3ull;
+            fp ^= m[k].posDest; fp *= 0x100000001b3ull;
+            tot++; len += m[k].len;
+        }
+    }
+    out[0] = fp; out[1] = tot; out[2] = len;
+}
+
+}  // namespace swk

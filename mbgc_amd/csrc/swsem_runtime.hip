@@ -1,0 +1,569 @@
+// Host runtime + C ABI (include/mbgc_swsem.h) of the MI355X match-finding path.
+// The host keeps exactly the scalar state the reference keeps in SlidingWindowSparseEMMatcher
+// (pos1, reachedRefLengthCount, samplingPos, swEnd, the worker-lock deque); the reference bytes,
+// the hash table and every per-round intermediate live in HBM.
+#include "../../include/mbgc_swsem.h"
+#include "swsem_kernels.hip"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+using namespace swk;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SWSEM_EHIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+constexpr uint64_t REF_SHIFT = 1;          // SlidingWindowSparseEMMatcher.h:14
+constexpr int SW_WIDTH_FACTOR = 16;        // .h:47
+constexpr uint64_t REF_SLACK = 256;
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return SWSEM_OK;
+        if (p) (void) hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        if (hipMalloc((void **) &p, want * sizeof(T)) != hipSuccess) {
+            p = nullptr;
+            return fail(SWSEM_ENOMEM, "device allocation of %zu bytes failed", want * sizeof(T));
+        }
+        cap = want;
+        return SWSEM_OK;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ProfEvent { hipEvent_t a, b; int fam; };
+
+}  // namespace
+
+struct swsem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    // --- reference state (names follow SlidingWindowSparseEMMatcher.h:29-49,78)
+    uint8_t *ref = nullptr;                // start1
+    ht_entry *ht = nullptr;
+    uint8_t *lut = nullptr;                // upper-complement LUT, utils/helper.cpp:312-338
+    int64_t pos1 = REF_SHIFT;
+    uint64_t maxRefLength = 0;
+    int laps = 0;                          // reachedRefLengthCount
+    int L = 0, K = 0, k1 = 0, k2 = 1, skipMargin = 0, k1ord = 0;
+    uint32_t hash_size = 0, mask = 0;
+    uint64_t samplingPos = 0, swSize = 0, swEnd = 0;
+    bool circular = true;
+    std::deque<uint64_t> locks;            // workersSwEndPositions
+    uint32_t epoch = 1;
+    // --- per-round scratch
+    DevBuf<uint8_t> stage;                 // host text / host query staging
+    DevBuf<Contig> dContigs;
+    DevBuf<uint32_t> dTileContig, dTileCount, dMatchCount;
+    DevBuf<Hit> dHits;
+    DevBuf<Match> dMatches;
+    DevBuf<unsigned long long> dStats;
+    std::vector<Contig> contigs;
+    std::vector<uint32_t> matchCount;
+    std::vector<swsem_match_t> hostMatches;
+    const uint8_t *qdev = nullptr;         // query buffer of the last batch
+    uint32_t ntiles = 0;
+    uint32_t minLen = 0;
+    bool batchValid = false;
+    uint64_t stats[5] = {0, 0, 0, 0, 0};
+    // --- profiling
+    bool prof = false;
+    std::vector<ProfEvent> events;
+    double profMs[SWSEM_K_COUNT] = {0};
+    uint64_t profN[SWSEM_K_COUNT] = {0};
+
+    uint64_t refLength() const { return laps ? maxRefLength : (uint64_t) pos1; }
+    RefView view() const {
+        RefView v;
+        v.ref = ref; v.ht = ht; v.pos1 = (uint64_t) pos1; v.refLength = refLength(); v.maxRefLength = maxRefLength;
+        v.mask = mask; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
+        return v;
+    }
+    void mark(int fam, bool begin) {
+        if (!prof) return;
+        if (begin) {
+            ProfEvent e; e.fam = fam;
+            (void) hipEventCreate(&e.a); (void) hipEventCreate(&e.b);
+            (void) hipEventRecord(e.a, stream);
+            events.push_back(e);
+        } else
+            (void) hipEventRecord(events.back().b, stream);
+    }
+    void drain_events() {
+        for (auto &e : events) {
+            (void) hipEventSynchronize(e.b);
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, e.a, e.b);
+            profMs[e.fam] += ms; profN[e.fam]++;
+            (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b);
+        }
+        events.clear();
+    }
+};
+
+namespace {
+
+// initParams, SlidingWindowSparseEMMatcher.cpp:74-104
+void init_params(swsem *h) {
+    const int L = h->L;
+    if (L > 110) h->K = 56;
+    else if (L > 62) h->K = 44;
+    else if (L > 53) h->K = 40;
+    else if (L > 46) h->K = 36;
+    else if (L > 42) h->K = 32;
+    else if (L > 32) h->K = 28;
+    else h->K = (L / 4 - 1) * 4;
+    const int KmmL = (L / 4 - 1) * 4;
+    if (KmmL < h->K) h->K = KmmL;
+    uint8_t i = 24;
+    do {
+        h->hash_size = ((uint32_t) 1) << (i++);
+    } while (i <= 31 && h->hash_size < h->maxRefLength / (uint64_t) h->k1);
+    h->mask = h->hash_size - 1;
+}
+
+void build_lut(uint8_t *lut) {
+    for (int i = 0; i < 256; i++) lut[i] = (uint8_t) i;
+    lut[127] = 0;   // the reference's table constructor stops at i < CHAR_MAX, utils/helper.cpp:321-322
+    const char *from = "AaCcGgTtNnUuYyRrKkMmBbDdHhVvWwSs";
+    const char *to = "TTGGCCAANNAARRYYMMKKVVHHDDBBSSWW";
+    for (int i = 0; from[i]; i++) lut[(uint8_t) from[i]] = (uint8_t) to[i];
+}
+
+// processIgnoreCollisionsRef (.cpp:146-171): derive the two sample sets and launch one insertion.
+int insert_samples(swsem *h) {
+    const int64_t STEP = (int64_t) h->k1 * 128;
+    const int64_t E = h->pos1 - h->K;
+    const int64_t S = (int64_t) h->samplingPos;
+    uint64_t nMain = 0;
+    if (S < E - STEP) {
+        const int64_t blocks = ((E - STEP) - S + STEP - 1) / STEP;
+        nMain = (uint64_t) blocks * 128;
+    }
+    const int64_t T = h->k1 + ((E - 1) / STEP) * STEP;
+    uint64_t nTail = 0;
+    if (T < E + 1) nTail = (uint64_t) ((E - T) / h->k1 + 1);
+    const uint64_t total = nMain + nTail;
+    if (total) {
+        h->mark(SWSEM_K_INSERT, true);
+        k_insert<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, h->stream>>>(
+            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch);
+        h->mark(SWSEM_K_INSERT, false);
+        HIPCHK(hipGetLastError());
+    }
+    h->epoch += 2;
+    h->samplingPos = (uint64_t) (T + (int64_t) nTail * h->k1);
+    return SWSEM_OK;
+}
+
+// private loadRef, .cpp:402-437, on a device-resident text
+int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSep, int sep) {
+    while (len != 0) {
+        if ((uint64_t) h->pos1 == h->maxRefLength && h->swEnd != h->maxRefLength) {
+            h->laps++;
+            h->pos1 = REF_SHIFT;
+            h->samplingPos = REF_SHIFT;
+        }
+        const uint64_t tmpEnd = h->swEnd;
+        uint64_t tmpLength = len;
+        const uint64_t tmpMax = tmpEnd < (uint64_t) h->pos1 ? h->maxRefLength : tmpEnd;
+        if ((uint64_t) h->pos1 + tmpLength > tmpMax) tmpLength = tmpMax - (uint64_t) h->pos1;
+        if (tmpLength) {
+            h->mark(SWSEM_K_LOAD, true);
+            if (rc) {
+                const uint64_t thr = (tmpLength + 3) / 4;
+                const unsigned blocks = (unsigned) std::min<uint64_t>((thr + 255) / 256, 8192);
+                k_load_rc<<<dim3(blocks), dim3(256), 0, h->stream>>>(text + len - tmpLength, h->ref + h->pos1, tmpLength, h->lut);
+            } else
+                HIPCHK(hipMemcpyAsync(h->ref + h->pos1, text, tmpLength, hipMemcpyDeviceToDevice, h->stream));
+            h->mark(SWSEM_K_LOAD, false);
+        }
+        if (addSep && (uint64_t) h->pos1 + tmpLength == h->swEnd)
+            k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->swEnd - 1, (uint8_t) sep);
+        h->pos1 += (int64_t) tmpLength;
+        int r = insert_samples(h);
+        if (r) return r;
+        text += rc ? 0 : tmpLength;
+        len = (uint64_t) h->pos1 == tmpEnd ? 0 : len - tmpLength;
+    }
+    HIPCHK(hipGetLastError());
+    return SWSEM_OK;
+}
+
+int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {
+    if (n <= 0) return fail(SWSEM_EINVAL, "empty batch");
+    if (minLen < (uint32_t) h->K)   // SlidingWindowSparseEMMatcher.cpp:480-483
+        return fail(SWSEM_EINVAL, "Minimal matching length cannot be smaller than K (%u < %d)", minLen, h->K);
+    h->batchValid = false;
+    h->matchCount.clear();
+    h->minLen = minLen;
+    h->contigs.assign(n, Contig());
+    std::vector<uint32_t> tileContig;
+    uint64_t matchRows = 0, bases = 0;
+    uint32_t tiles = 0;
+    for (int c = 0; c < n; c++) {
+        Contig &cg = h->contigs[c];
+        cg.qoff = offsets[c];
+        cg.n = offsets[c + 1] - offsets[c];
+        if (cg.n >= (1ull << 32)) return fail(SWSEM_EINVAL, "contig %d longer than 4 GiB", c);
+        cg.lock = lockPos ? lockPos[c] : UINT64_MAX;
+        const uint64_t npos = cg.n >= (uint64_t) h->K ? cg.n - h->K + 1 : 0;
+        cg.tile0 = tiles;
+        cg.ntiles = (uint32_t) ((npos + TILE - 1) / TILE);
+        cg.matchBase = matchRows;
+        cg.matchCap = (uint32_t) (cg.n / minLen + 2);
+        matchRows += cg.matchCap;
+        for (uint32_t t = 0; t < cg.ntiles; t++) tileContig.push_back((uint32_t) c);
+        tiles += cg.ntiles;
+        bases += cg.n;
+    }
+    h->ntiles = tiles;
+    int r;
+    if ((r = h->dContigs.reserve(n))) return r;
+    if ((r = h->dMatchCount.reserve(n))) return r;
+    if ((r = h->dStats.reserve(8))) return r;
+    if ((r = h->dTileContig.reserve(std::max<uint32_t>(tiles, 1)))) return r;
+    if ((r = h->dTileCount.reserve(std::max<uint32_t>(tiles, 1)))) return r;
+    if ((r = h->dHits.reserve((size_t) std::max<uint32_t>(tiles, 1) * TILE))) return r;
+    if ((r = h->dMatches.reserve(matchRows))) return r;
+    HIPCHK(hipMemcpyAsync(h->dContigs.p, h->contigs.data(), n * sizeof(Contig), hipMemcpyHostToDevice, h->stream));
+    if (tiles)
+        HIPCHK(hipMemcpyAsync(h->dTileContig.p, tileContig.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->dStats.p, 0, 8 * sizeof(unsigned long long), h->stream));
+    // the host vectors above must outlive the async copies
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const RefView v = h->view();
+    if (tiles) {
+        h->mark(SWSEM_K_PROBE, true);
+        k_probe<<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dHits.p,
+                                                                  h->dTileCount.p, h->dStats.p);
+        h->mark(SWSEM_K_PROBE, false);
+        h->mark(SWSEM_K_EXTEND, true);
+        k_extend<<<dim3(tiles * (TILE / 256)), dim3(256), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dHits.p,
+                                                                        h->dTileCount.p);
+        h->mark(SWSEM_K_EXTEND, false);
+    }
+    h->mark(SWSEM_K_RESOLVE, true);
+    k_resolve_seq<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dHits.p, h->dTileCount.p, h->dMatches.p,
+                                                        h->dMatchCount.p);
+    h->mark(SWSEM_K_RESOLVE, false);
+    HIPCHK(hipGetLastError());
+    h->qdev = qdev;
+    h->stats[0] = bases;
+    h->batchValid = true;
+    return SWSEM_OK;
+}
+
+int fetch_counts(swsem *h) {
+    const int n = (int) h->contigs.size();
+    h->matchCount.resize(n);
+    HIPCHK(hipMemcpyAsync(h->matchCount.data(), h->dMatchCount.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    unsigned long long st[8];
+    HIPCHK(hipMemcpyAsync(st, h->dStats.p, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stats[1] = st[1]; h->stats[2] = st[2];
+    uint64_t tot = 0;
+    for (int c = 0; c < n; c++) tot += h->matchCount[c];
+    h->stats[3] = tot;
+    return SWSEM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *swsem_last_error(void) { return g_err.c_str(); }
+
+int swsem_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, int skipMargin, int device) {
+    *out = nullptr;
+    if (k1 <= 0 || (k1 % 2)) return fail(SWSEM_EINVAL, "Error initializing ExpSparseMEM: incorrect k1 (%d)", k1);
+    if (k2 != 1) return fail(SWSEM_EINVAL, "k2 = %d unsupported (MBGC always uses k2 = 1, MGMP_Params.h:202)", k2);
+    if (L < 16) return fail(SWSEM_EINVAL, "Error: Minimal matching length too short!");
+    if (maxRefLength < 64 || (maxRefLength >> __builtin_ctz((unsigned) k1)) >= (1ull << 32))
+        return fail(SWSEM_EINVAL, "reference length limit %llu out of range", (unsigned long long) maxRefLength);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev)
+        return fail(SWSEM_ENODEV, "no HIP device %d (the HIP path has no CPU fallback)", device);
+    HIPCHK(hipSetDevice(device));
+    swsem *h = new swsem();
+    h->device = device;
+    h->maxRefLength = maxRefLength;
+    h->L = L; h->k1 = k1; h->k2 = k2; h->skipMargin = skipMargin;
+    h->k1ord = __builtin_ctz((unsigned) k1);
+    h->swEnd = maxRefLength;
+    h->swSize = maxRefLength / SW_WIDTH_FACTOR;
+    init_params(h);
+    h->samplingPos = (uint64_t) k1;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
+    h->ownStream = true;
+    if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
+        hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
+        hipMalloc((void **) &h->lut, 256) != hipSuccess) {
+        swsem_destroy(h);
+        return fail(SWSEM_ENOMEM, "cannot allocate %llu B reference + %llu B hash table in HBM",
+                    (unsigned long long) maxRefLength, (unsigned long long) h->hash_size * 8ull);
+    }
+    uint8_t lut[256];
+    build_lut(lut);
+    HIPCHK(hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(h->ht, 0, (size_t) h->hash_size * sizeof(ht_entry), h->stream));
+    // start1[0] = 0 (.cpp:335); the rest of the buffer is written before it is ever read, the slack
+    // past the end is zeroed because the reference's own reads run a few bytes over (:224, ENC:337)
+    HIPCHK(hipMemsetAsync(h->ref, 0, 64, h->stream));
+    HIPCHK(hipMemsetAsync(h->ref + maxRefLength, 0, REF_SLACK, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = h;
+    return SWSEM_OK;
+}
+
+void swsem_destroy(swsem_t *h) {
+    if (!h) return;
+    (void) hipSetDevice(h->device);
+    if (h->stream) (void) hipStreamSynchronize(h->stream);
+    h->drain_events();
+    if (h->ref) (void) hipFree(h->ref);
+    if (h->ht) (void) hipFree(h->ht);
+    if (h->lut) (void) hipFree(h->lut);
+    h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dTileCount.release();
+    h->dMatchCount.release(); h->dHits.release(); h->dMatches.release(); h->dStats.release();
+    if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int swsem_set_stream(swsem_t *h, void *s) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->ownStream) (void) hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t) s;
+    h->ownStream = false;
+    return SWSEM_OK;
+}
+int swsem_synchronize(swsem_t *h) { HIPCHK(hipStreamSynchronize(h->stream)); return SWSEM_OK; }
+
+void swsem_disable_sliding_window(swsem_t *h) { h->swSize = 0; h->swEnd = h->circular ? 0 : h->maxRefLength; }
+void swsem_set_sliding_window_size(swsem_t *h, int f) { h->swSize = h->maxRefLength / (uint64_t) (uint8_t) f; }
+void swsem_disable_circular_buffer(swsem_t *h) { h->circular = false; h->swEnd = h->maxRefLength; }
+uint64_t swsem_get_ref_length(const swsem_t *h) { return h->refLength(); }
+uint64_t swsem_get_loading_position(const swsem_t *h) { return (uint64_t) h->pos1; }
+uint64_t swsem_get_loaded_ref_length(const swsem_t *h) {
+    return (uint64_t) h->laps * (h->maxRefLength - REF_SHIFT) + ((uint64_t) h->pos1 - REF_SHIFT);
+}
+uint64_t swsem_get_max_ref_length(const swsem_t *h) { return h->maxRefLength; }
+void swsem_set_position(swsem_t *h, uint64_t p, int laps) { h->pos1 = (int64_t) p; h->laps = laps; }
+int swsem_get_K(const swsem_t *h) { return h->K; }
+uint32_t swsem_get_hash_size(const swsem_t *h) { return h->hash_size; }
+
+// acquireWorkerMatchingLockPos, .cpp:361-378
+uint64_t swsem_acquire_lock(swsem_t *h) {
+    if (h->swSize == 0 || !h->circular) return h->swEnd;
+    uint64_t w = (uint64_t) h->pos1 + h->swSize;
+    if (h->laps || w > h->maxRefLength) {
+        if (w > h->maxRefLength) w -= h->maxRefLength - REF_SHIFT;
+    } else
+        w = h->maxRefLength;
+    if (h->locks.empty()) h->swEnd = w;
+    h->locks.push_back(w);
+    return w;
+}
+
+// releaseWorkerMatchingLockPos, .cpp:380-400
+int swsem_release_lock(swsem_t *h, uint64_t v) {
+    if (h->swSize == 0 || !h->circular) return SWSEM_OK;
+    size_t i = 0;
+    while (i < h->locks.size() && h->locks[i] != v) i++;
+    if (i == h->locks.size()) return fail(SWSEM_ELOCK, "ERROR: Invalid worker lock value (%llu)", (unsigned long long) v);
+    if (i == 0) {
+        do {
+            h->locks.pop_front();
+        } while (!h->locks.empty() && h->locks.front() == UINT64_MAX);
+        if (!h->locks.empty()) h->swEnd = h->locks.front();
+    } else
+        h->locks[i] = UINT64_MAX;
+    return SWSEM_OK;
+}
+
+int swsem_load_ref_dev(swsem_t *h, const uint8_t *t, uint64_t len, int loadRC, int addSep, int sep) {
+    HIPCHK(hipSetDevice(h->device));
+    int r = load_pieces(h, t, len, false, addSep != 0, sep);
+    if (r) return r;
+    if (loadRC) r = load_pieces(h, t, len, true, addSep != 0, sep);
+    return r;
+}
+
+int swsem_load_ref(swsem_t *h, const uint8_t *t, uint64_t len, int loadRC, int addSep, int sep) {
+    HIPCHK(hipSetDevice(h->device));
+    if (len == 0) return SWSEM_OK;
+    int r = h->stage.reserve(len + 64);
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(h->stage.p, t, len, hipMemcpyHostToDevice, h->stream));
+    r = swsem_load_ref_dev(h, h->stage.p, len, loadRC, addSep, sep);
+    if (r) return r;
+    HIPCHK(hipStreamSynchronize(h->stream));   // the staging buffer is reused by the next call
+    return SWSEM_OK;
+}
+
+// loadSeparator, .cpp:439-451
+int swsem_load_separator(swsem_t *h, int sep) {
+    HIPCHK(hipSetDevice(h->device));
+    if ((uint64_t) h->pos1 == h->maxRefLength && h->swEnd != h->maxRefLength) {
+        h->laps++;
+        h->pos1 = REF_SHIFT;
+        h->samplingPos = REF_SHIFT;
+    }
+    if ((uint64_t) h->pos1 == h->maxRefLength) return SWSEM_OK;
+    if ((uint64_t) h->pos1 == h->swEnd)
+        k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1 - 1, (uint8_t) sep);
+    else
+        k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1++, (uint8_t) sep);
+    HIPCHK(hipGetLastError());
+    return SWSEM_OK;
+}
+
+int swsem_match_batch_dev(swsem_t *h, const uint8_t *q, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {
+    HIPCHK(hipSetDevice(h->device));
+    return run_batch(h, q, offsets, n, minLen, lockPos);
+}
+
+int swsem_batch_counts(swsem_t *h, uint64_t *nm) {
+    if (!h->batchValid) return fail(SWSEM_EINVAL, "no batch results");
+    int r = fetch_counts(h);
+    if (r) return r;
+    for (size_t c = 0; c < h->contigs.size(); c++) nm[c] = h->matchCount[c];
+    return SWSEM_OK;
+}
+
+int swsem_batch_matches(swsem_t *h, int c, swsem_match_t *out, uint64_t cap) {
+    if (!h->batchValid || c < 0 || c >= (int) h->contigs.size()) return fail(SWSEM_EINVAL, "no such contig in the batch");
+    if (h->matchCount.size() != h->contigs.size()) { int r = fetch_counts(h); if (r) return r; }
+    const uint64_t n = std::min<uint64_t>(cap, h->matchCount[c]);
+    if (n) HIPCHK(hipMemcpy(out, h->dMatches.p + h->contigs[c].matchBase, n * sizeof(Match), hipMemcpyDeviceToHost));
+    return SWSEM_OK;
+}
+
+int swsem_batch_fingerprint(swsem_t *h, uint64_t *fp, uint64_t *tot, uint64_t *len) {
+    if (!h->batchValid) return fail(SWSEM_EINVAL, "no batch results");
+    k_fingerprint<<<1, 1, 0, h->stream>>>(h->dContigs.p, (int) h->contigs.size(), h->dMatches.p, h->dMatchCount.p, h->dStats.p + 4);
+    unsigned long long o[3];
+    HIPCHK(hipMemcpyAsync(o, h->dStats.p + 4, sizeof o, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *fp = o[0]; *tot = o[1]; *len = o[2];
+    h->stats[3] = o[1]; h->stats[4] = o[2];
+    return SWSEM_OK;
+}
+
+int swsem_match(swsem_t *h, const uint8_t *query, uint64_t len, uint32_t minLen, uint64_t lockPos,
+                const swsem_match_t **matches, uint64_t *nmatches) {
+    HIPCHK(hipSetDevice(h->device));
+    *matches = nullptr; *nmatches = 0;
+    int r = h->stage.reserve(len + 64);
+    if (r) return r;
+    if (len) HIPCHK(hipMemcpyAsync(h->stage.p, query, len, hipMemcpyHostToDevice, h->stream));
+    const uint64_t offs[2] = {0, len};
+    if ((r = run_batch(h, h->stage.p, offs, 1, minLen, &lockPos))) return r;
+    if ((r = fetch_counts(h))) return r;
+    h->hostMatches.resize(h->matchCount[0]);
+    if (h->matchCount[0])
+        HIPCHK(hipMemcpy(h->hostMatches.data(), h->dMatches.p, h->matchCount[0] * sizeof(Match), hipMemcpyDeviceToHost));
+    *matches = h->hostMatches.data();
+    *nmatches = h->matchCount[0];
+    return SWSEM_OK;
+}
+
+int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->ref + from, n, hipMemcpyDeviceToHost));
+    return SWSEM_OK;
+}
+
+int swsem_debug_copy_ht(swsem_t *h, uint32_t *out) {
+    DevBuf<uint32_t> tmp;
+    int r = tmp.reserve(h->hash_size);
+    if (r) return r;
+    k_ht_low_words<<<dim3((h->hash_size + 255) / 256), dim3(256), 0, h->stream>>>(h->ht, tmp.p, h->hash_size);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, tmp.p, (size_t) h->hash_size * 4, hipMemcpyDeviceToHost));
+    tmp.release();
+    return SWSEM_OK;
+}
+
+int swsem_profile_enable(swsem_t *h, int on) {
+    h->drain_events();
+    h->prof = on != 0;
+    memset(h->profMs, 0, sizeof h->profMs);
+    memset(h->profN, 0, sizeof h->profN);
+    return SWSEM_OK;
+}
+
+int swsem_profile_get(swsem_t *h, double ms[SWSEM_K_COUNT], uint64_t n[SWSEM_K_COUNT]) {
+    h->drain_events();
+    for (int i = 0; i < SWSEM_K_COUNT; i++) { ms[i] = h->profMs[i]; n[i] = h->profN[i]; }
+    return SWSEM_OK;
+}
+
+int swsem_batch_stats(swsem_t *h, uint64_t s[5]) {
+    if (!h->batchValid) return fail(SWSEM_EINVAL, "no batch results");
+    for (int i = 0; i < 5; i++) s[i] = h->stats[i];
+    return SWSEM_OK;
+}
+
+void swsem_emit_params_default(swsem_emit_params_t *p, int mode) {
+    memset(p, 0, sizeof(*p));
+    p->enableExtensionsWithMismatches = 1;
+    p->mismatchesWithExclusion = 1;
+    p->lazyDecompressionSupport = 1;
+    p->enable40bitReference = 0;
+    p->frugal64bitLenEncoding = 1;
+    p->gapDepthOffsetEncoding = 64;                     // MBGC_Params.h:51
+    p->gapDepthMismatchesEncoding = 2;                  // :52
+    p->gapBreakingMatchMinLength = 256;                 // :53
+    p->mmsMatchBonus = 50;                              // initMismatchesMatchingScoreParams, :92-97
+    p->mmsMismatchPenalty = 50;
+    p->mmsMismatchesScoreThreshold = 500;
+    p->mmsMismatchesInitialScore = 125;
+    p->allowedTargetsOutrunForDissimilarContigs = 1;    // MGMP_Params.h:60
+    p->minimalLengthForDissimilarContigs = 1024;        // :64
+    p->unmatchedFractionFactorTweakForDissimilarContigs = 16;   // :61
+    if (mode == 0) {                                    // MBGC_Params.h:893-902
+        p->allowedTargetsOutrunForDissimilarContigs = 4;
+        p->unmatchedFractionFactorTweakForDissimilarContigs = 32;
+        p->frugal64bitLenEncoding = 0;
+    }
+    if (mode == 2) {                                    // :903-906
+        p->allowedTargetsOutrunForDissimilarContigs = 0;
+        p->unmatchedFractionFactorTweakForDissimilarContigs = 2;
+    }
+}
+
+int swsem_emit(swsem_t *, const swsem_emit_params_t *, int, uint64_t, int, int64_t, int64_t, const uint64_t *, uint64_t,
+               swsem_streams_t *) {
+    return fail(SWSEM_EINVAL, "swsem_emit: not built yet");
+}
+
+}  // extern "C"
