@@ -132,9 +132,10 @@ enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2, SWSEM_K_EXTEND =
  * device time (ms) and launch count per kernel family are read back with swsem_profile_get. */
 int swsem_profile_enable(swsem_t *h, int on);
 int swsem_profile_get(swsem_t *h, double ms[SWSEM_K_COUNT], uint64_t launches[SWSEM_K_COUNT]);
-/* algorithmic counters of the last batch: [0] query bases, [1] hash-table probes, [2] verified hits,
- * [3] matches, [4] sum of match lengths */
-int swsem_batch_stats(swsem_t *h, uint64_t stats[5]);
+/* counters of the last batch (after swsem_batch_counts): [0] query bases, [1] hash-table probes,
+ * [2] verified hits, [3] matches, [4] sum of match lengths (after swsem_batch_fingerprint),
+ * [5] resolve blocks whose speculation was rejected and that were replayed from the true state */
+int swsem_batch_stats(swsem_t *h, uint64_t stats[6]);
 
 #ifdef __cplusplus
 }

@@ -201,9 +201,9 @@ class SlidingWindowSparseEMMatcher:
         return fp.value, tot.value, ln.value
 
     def batch_stats(self):
-        s = (C.c_uint64 * 5)()
+        s = (C.c_uint64 * 6)()
         _chk(lib().swsem_batch_stats(self.h, s))
-        return dict(zip(("bases", "probes", "hits", "matches", "matched_len"), s))
+        return dict(zip(("bases", "probes", "hits", "matches", "matched_len", "replayed_blocks"), s))
 
     # --- emission (MBGC_Encoder::processMatches)
     def emit(self, params, contig=0, lock=NO_LOCK, factor=128, processed=0, target_idx=0, loaded=None):

@@ -238,22 +238,97 @@ __global__ void __launch_bounds__(256) k_extend(RefView v, const uint8_t *__rest
 // ------------------------------------------------------------------------------------------------
 struct Chain {
     int64_t scan;          // next query position the sequential loop would visit
-    int32_t sp;            // match-stack size
-    int32_t ringLow;       // lowest stack index whose copy in the LDS ring is valid
-    int32_t minTouched;    // lowest stack index examined so far (-1: walked off the bottom)
+    int32_t minTouched;    // lowest stack index examined since the last reset (-1: walked off the bottom)
+    int32_t minKeep;       // lowest keepCount of an emission since the last reset
+    int32_t visited;       // hits visited since the last reset
 };
 
 constexpr int RING = 64;
+constexpr int OVERLAP = 1024;          // warm-up positions of a speculative block chain (<= TILE)
+constexpr int SNAP = 4;                // stack elements snapshotted at a block boundary / end
 
-__device__ __forceinline__ void stack_get(const Match *st, const uint2 *ring, const Chain &ch, int idx,
-                                          int64_t &posDest, int64_t &len) {
-    if (idx >= ch.ringLow) {
-        const uint2 e = ring[idx & (RING - 1)];
-        posDest = e.x; len = e.y;
-    } else {
-        posDest = (int64_t) st[idx].posDest; len = (int64_t) st[idx].len;
+// A chain's match stack held in one array (global memory) with the top RING entries mirrored in LDS.
+struct ArrayStack {
+    Match *st;
+    uint2 *ring;
+    int32_t sp, ringLow;
+    __device__ __forceinline__ int size() const { return sp; }
+    __device__ __forceinline__ void get(int idx, int64_t &posDest, int64_t &len) {
+        if (idx >= ringLow) {
+            const uint2 e = ring[idx & (RING - 1)];
+            posDest = e.x; len = e.y;
+        } else {
+            posDest = (int64_t) st[idx].posDest; len = (int64_t) st[idx].len;
+        }
     }
-}
+    // resMatches.resize(keep); resMatches.push_back(m)   (.cpp:299-300)
+    __device__ __forceinline__ void truncate_push(int keep, const Match &m) {
+        sp = keep;
+        if ((threadIdx.x & (WAVE - 1)) == 0) st[sp] = m;
+        ring[sp & (RING - 1)] = make_uint2((uint32_t) m.posDest, (uint32_t) m.len);
+        if (sp - (RING - 1) > ringLow) ringLow = sp - (RING - 1);
+        if (ringLow > sp) ringLow = sp;
+        sp++;
+    }
+};
+
+// The true match list of a contig while the stitch kernel assembles it: a chain of per-block
+// segments (block b contributes region_b[segStart[b] .. +keepN[b])), newest segment on top, plus the
+// pushes of the block being replayed ("own"). Elements are only ever consulted from the top down.
+struct VirtStack {
+    Match *region;            // block regions of this contig
+    uint32_t cap;             // rows per block region
+    uint32_t *segStart, *keepN;
+    int32_t *prev;
+    int32_t segTop;           // newest non-empty segment, -1 if none
+    int32_t size_;            // rows in the whole list
+    Match *own; int32_t ownN; // pushes of the block being replayed
+    int32_t curSeg, curLocal, curR;   // cursor: element curLocal of segment curSeg is curR rows below the top of the segments
+    __device__ __forceinline__ int size() const { return size_; }
+    __device__ const Match *at(int idx) {
+        const int below = size_ - ownN;              // rows held by the segments
+        if (idx >= below) return own + (idx - below);
+        const int r = below - 1 - idx;
+        if (curSeg < 0 || curR > r) { curSeg = segTop; curLocal = (int32_t) keepN[segTop] - 1; curR = 0; }
+        while (curR < r) {
+            const int step = r - curR < curLocal ? r - curR : curLocal;
+            if (step > 0) { curLocal -= step; curR += step; }
+            else { curSeg = prev[curSeg]; curLocal = (int32_t) keepN[curSeg] - 1; curR++; }
+        }
+        return region + (uint64_t) curSeg * cap + segStart[curSeg] + curLocal;
+    }
+    __device__ __forceinline__ void get(int idx, int64_t &posDest, int64_t &len) {
+        const Match *m = at(idx);
+        posDest = (int64_t) m->posDest; len = (int64_t) m->len;
+    }
+    __device__ void pop_segments(int p) {
+        const bool l0 = (threadIdx.x & (WAVE - 1)) == 0;
+        while (p > 0) {
+            const int k = (int) keepN[segTop];
+            const int take = k < p ? k : p;
+            if (l0) keepN[segTop] = (uint32_t) (k - take);
+            p -= take;
+            if (take == k) segTop = prev[segTop];
+        }
+        curSeg = -1;
+    }
+    __device__ void truncate_push(int keep, const Match &m) {
+        int p = size_ - keep;
+        const int t = p < ownN ? p : ownN;
+        ownN -= t; p -= t;
+        if (p > 0) pop_segments(p);
+        if ((threadIdx.x & (WAVE - 1)) == 0) own[ownN] = m;
+        ownN++;
+        size_ = keep + 1;
+    }
+    __device__ void push_segment(int b, uint32_t start, uint32_t n) {
+        if (n == 0) return;
+        if ((threadIdx.x & (WAVE - 1)) == 0) { segStart[b] = start; keepN[b] = n; prev[b] = segTop; }
+        segTop = b;
+        size_ += (int32_t) n;
+        curSeg = -1;
+    }
+};
 
 // continue a capped left run (wave-cooperative, 256 bytes per step)
 __device__ uint32_t wave_more_left(const uint8_t *a, const uint8_t *b, uint32_t have, uint64_t limit) {
@@ -290,9 +365,9 @@ __device__ uint32_t wave_more_right(const uint8_t *a, const uint8_t *b, uint32_t
 }
 
 // Processes one visited hit. All arguments are wave-uniform. Returns true when a match was emitted.
-__device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q, Match *st, uint2 *ring,
-                            Chain &ch, uint64_t c, int64_t i, int64_t ell, int64_t rext, int64_t loDist,
-                            uint32_t flags) {
+template <class Stack>
+__device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q, Stack &stk, Chain &ch,
+                            uint64_t c, int64_t i, int64_t ell, int64_t rext, int64_t loDist, uint32_t flags) {
     const int64_t K = v.K;
     uint64_t lo = 0, hi = 0;
     if (flags) window_ok(v, cg.lock, c, lo, hi);
@@ -307,11 +382,11 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
         }
     };
     int64_t s = 0;                                   // (p1, p2) = (c - s, i - s)
-    int keep = ch.sp;                                // resSizeWithoutOverlapped
+    int keep = stk.size();                           // resSizeWithoutOverlapped
     bool brokeOut = false;
     while (keep-- > 0) {                             // .cpp:253
         int64_t mPos, mLen;
-        stack_get(st, ring, ch, keep, mPos, mLen);
+        stk.get(keep, mPos, mLen);
         const int64_t mEnd = mPos + mLen;
         if (mEnd < i - s) {                          // .cpp:255
             const int64_t g = mEnd;
@@ -333,6 +408,7 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
     }
     if (!brokeOut) keep = -1;
     if (keep < ch.minTouched) ch.minTouched = keep;
+    ch.visited++;
     if (keep < 0) {                                  // .cpp:277-280
         need_ell((loDist < i + 1 ? loDist : i + 1) - 1);
         int64_t t = loDist < i + 1 ? loDist : i + 1;
@@ -340,7 +416,7 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
         if (t > s) s = t;
     } else {                                         // .cpp:285-289
         int64_t mPos, mLen;
-        stack_get(st, ring, ch, keep, mPos, mLen);
+        stk.get(keep, mPos, mLen);
         const int64_t overlap = (mPos + mLen) - (i - s + 1);
         if (overlap > 0) s -= overlap;
     }
@@ -357,12 +433,8 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
             m.posSrc = (uint64_t) ((int64_t) c - s + 1);
             m.len = (uint64_t) (K + rext + s - 1);
             m.posDest = (uint64_t) (i - s + 1);
-            ch.sp = keep;                            // resMatches.resize(...), .cpp:299
-            if ((threadIdx.x & (WAVE - 1)) == 0) st[ch.sp] = m;
-            ring[ch.sp & (RING - 1)] = make_uint2((uint32_t) m.posDest, (uint32_t) m.len);
-            if (ch.sp - (RING - 1) > ch.ringLow) ch.ringLow = ch.sp - (RING - 1);
-            if (ch.ringLow > ch.sp) ch.ringLow = ch.sp;
-            ch.sp++;
+            stk.truncate_push(keep, m);
+            if (keep < ch.minKeep) ch.minKeep = keep;
             int64_t skip = K + rext;                 // (matchEnd - i2), k2 == 1, .cpp:308
             skip -= skip > v.skipMargin ? v.skipMargin : skip;
             ch.scan = skip ? i + skip : i + 1;       // .cpp:310-313 then the loop's i2 += k2
@@ -374,9 +446,9 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
 }
 
 // Runs the chain over the hits of tiles [t0, t1) of one contig.
+template <class Stack>
 __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const Hit *__restrict__ hits,
-                          const uint32_t *__restrict__ tileCount, uint32_t t0, uint32_t t1, Match *st,
-                          uint2 *ring, Chain &ch) {
+                          const uint32_t *__restrict__ tileCount, uint32_t t0, uint32_t t1, Stack &stk, Chain &ch) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     for (uint32_t t = t0; t < t1; t++) {
         const uint32_t cnt = tileCount[t];
@@ -398,14 +470,15 @@ __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, 
                 const int64_t rext = (uint32_t) __shfl((int) h.rext, l);
                 const int64_t loDist = (uint32_t) __shfl((int) h.loDist, l);
                 const uint32_t flags = (uint32_t) __shfl((int) h.flags, l);
-                process_hit(v, cg, q, st, ring, ch, c, i, ell, rext, loDist, flags);
+                process_hit(v, cg, q, stk, ch, c, i, ell, rext, loDist, flags);
                 valid = valid && lane > (uint32_t) l;
             }
         }
     }
 }
 
-// v1 resolution: one wave replays a whole contig.
+// Sequential resolution (one wave replays a whole contig): the simple form, kept as the cross-check
+// of the block-parallel path (SWSEM_RESOLVE=seq).
 __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *__restrict__ qbuf,
                                                       const Contig *__restrict__ contigs,
                                                       const Hit *__restrict__ hits,
@@ -414,10 +487,192 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
     __shared__ uint2 ring[RING];
     const Contig cg = contigs[blockIdx.x];
     Chain ch;
-    ch.scan = 0; ch.sp = 0; ch.ringLow = 0; ch.minTouched = 0;
-    run_chain(v, cg, qbuf + cg.qoff, hits, tileCount, cg.tile0, cg.tile0 + cg.ntiles, matches + cg.matchBase,
-              ring, ch);
-    if (threadIdx.x == 0) matchCount[blockIdx.x] = (uint32_t) ch.sp;
+    ch.scan = 0; ch.minTouched = 0; ch.minKeep = 0; ch.visited = 0;
+    ArrayStack stk;
+    stk.st = matches + cg.matchBase; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
+    run_chain(v, cg, qbuf + cg.qoff, hits, tileCount, cg.tile0, cg.tile0 + cg.ntiles, stk, ch);
+    if (threadIdx.x == 0) matchCount[blockIdx.x] = (uint32_t) stk.sp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-parallel resolution. The greedy chain is sequential, but its state at a query position is
+// tiny (scan position + the few newest matches), and chains started from different states fall into
+// step after a few emissions. So every tile gets its own wave: it warms up on the last OVERLAP
+// positions of the previous tile from an empty stack (speculation), snapshots its state at the tile
+// boundary, then replays its own tile. The stitch kernel walks the tiles of a contig in order with
+// the TRUE state, accepts a block when its boundary snapshot equals the true state as deep as the
+// block ever looked (then everything it did is exactly what the sequential loop does), and replays
+// the block from the true state otherwise. Results are therefore identical to the sequential loop by
+// construction; speculation only decides how much of the work ran in parallel.
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) BlockRec {
+    int64_t scanB;         // scan position at the tile boundary (clamped to >= tile start)
+    int64_t scanF;         // scan position after the tile
+    int32_t spB, spF;      // stack size at the boundary / at the end
+    int32_t minTouched;    // lowest index examined while replaying the own tile (INT_MAX: nothing visited)
+    int32_t minKeep;       // rows of the boundary stack that survived the own tile (<= spB)
+    Match bTop[SNAP];      // newest rows at the boundary, newest first
+    Match fTop[SNAP];      // newest rows at the end, newest first
+};
+
+__device__ __forceinline__ void snapshot_top(const Match *st, int sp, Match *out) {
+    for (int j = 0; j < SNAP; j++) {
+        if (j < sp) out[j] = st[sp - 1 - j];
+        else { out[j].posSrc = 0; out[j].len = 0; out[j].posDest = 0; }
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
+                                                         const Contig *__restrict__ contigs,
+                                                         const uint32_t *__restrict__ tileContig,
+                                                         const Hit *__restrict__ hits,
+                                                         const uint32_t *__restrict__ tileCount,
+                                                         Match *__restrict__ regions, uint32_t cap,
+                                                         BlockRec *__restrict__ recs) {
+    __shared__ uint2 ring[RING];
+    const uint32_t tile = blockIdx.x;
+    const Contig cg = contigs[tileContig[tile]];
+    const uint32_t b = tile - cg.tile0;
+    const int64_t w0 = (int64_t) b * TILE;
+    Chain ch;
+    ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0;
+    ArrayStack stk;
+    stk.st = regions + (uint64_t) tile * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
+    const uint8_t *q = qbuf + cg.qoff;
+    if (b) run_chain(v, cg, q, hits, tileCount, tile - 1, tile, stk, ch);   // warm-up on the previous tile's tail
+    BlockRec r;
+    r.scanB = ch.scan > w0 ? ch.scan : w0;
+    r.spB = stk.sp;
+    __builtin_amdgcn_s_waitcnt(0);            // the wave's own stack rows are read back below
+    snapshot_top(stk.st, stk.sp, r.bTop);
+    ch.minTouched = 0x7fffffff; ch.minKeep = stk.sp; ch.visited = 0;
+    run_chain(v, cg, q, hits, tileCount, tile, tile + 1, stk, ch);
+    r.scanF = ch.scan;
+    r.spF = stk.sp;
+    r.minTouched = ch.visited ? ch.minTouched : 0x7fffffff;
+    r.minKeep = ch.minKeep < r.spB ? ch.minKeep : r.spB;
+    snapshot_top(stk.st, stk.sp, r.fTop);
+    if (threadIdx.x == 0) recs[tile] = r;
+}
+
+__device__ __forceinline__ bool same_match(const Match &a, const Match &b) {
+    return a.posSrc == b.posSrc && a.len == b.len && a.posDest == b.posDest;
+}
+
+// One wave per contig: walk the blocks with the true state (see above). Outputs per block the
+// segment (segStart, keepN) of its region that belongs to the final list, the row offsets and the
+// contig's match count.
+__global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__restrict__ qbuf,
+                                                 const Contig *__restrict__ contigs, const Hit *__restrict__ hits,
+                                                 const uint32_t *__restrict__ tileCount, Match *__restrict__ regions,
+                                                 uint32_t cap, const BlockRec *__restrict__ recs,
+                                                 uint32_t *__restrict__ segStart, uint32_t *__restrict__ keepN,
+                                                 int32_t *__restrict__ prev, uint32_t *__restrict__ dstOff,
+                                                 uint32_t *__restrict__ matchCount,
+                                                 unsigned long long *__restrict__ stats) {
+    const Contig cg = contigs[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const uint8_t *q = qbuf + cg.qoff;
+    VirtStack vs;
+    vs.region = regions + (uint64_t) cg.tile0 * cap; vs.cap = cap;
+    vs.segStart = segStart + cg.tile0; vs.keepN = keepN + cg.tile0; vs.prev = prev + cg.tile0;
+    vs.segTop = -1; vs.size_ = 0; vs.own = nullptr; vs.ownN = 0; vs.curSeg = -1; vs.curLocal = 0; vs.curR = 0;
+    for (uint32_t b = lane; b < cg.ntiles; b += WAVE) { vs.keepN[b] = 0; vs.segStart[b] = 0; }
+    __builtin_amdgcn_s_waitcnt(0);
+    int64_t scanT = 0;                 // true scan position
+    Match topT[SNAP];                  // newest true rows, newest first
+    int known = 0;                     // how many entries of topT are valid
+    uint32_t replayed = 0;
+    const BlockRec *rc = recs + cg.tile0;
+    for (uint32_t b = 0; b < cg.ntiles; b++) {
+        const int64_t w0 = (int64_t) b * TILE;
+        if (scanT >= w0 + TILE) continue;                       // the sequential loop jumped over this tile
+        const BlockRec r = rc[b];
+        bool ok;
+        if (b == 0) ok = true;                                  // block 0 started from the true (empty) state
+        else {
+            ok = (scanT > w0 ? scanT : w0) == r.scanB;
+            if (ok && r.minTouched != 0x7fffffff) {
+                const int D = r.minTouched < 0 ? r.spB + 1 : r.spB - r.minTouched;
+                if (r.minTouched < 0) ok = vs.size_ == r.spB && r.spB <= SNAP;
+                else ok = D <= SNAP && D <= vs.size_;
+                const int cmp = r.minTouched < 0 ? r.spB : D;
+                if (ok && cmp > known) {                        // refresh the true top rows from the list
+                    __builtin_amdgcn_s_waitcnt(0);
+                    for (int j = 0; j < SNAP && j < vs.size_; j++) topT[j] = *vs.at(vs.size_ - 1 - j);
+                    known = vs.size_ < SNAP ? vs.size_ : SNAP;
+                }
+                for (int j = 0; ok && j < cmp; j++) ok = same_match(topT[j], r.bTop[j]);
+            }
+        }
+        if (ok) {
+            if (r.minTouched != 0x7fffffff || b == 0) {
+                const int popB = r.spB - r.minKeep;
+                const int npush = r.spF - r.minKeep;
+                if (popB > 0) vs.pop_segments(popB);
+                vs.size_ -= popB;
+                vs.push_segment((int) b, (uint32_t) r.minKeep, (uint32_t) npush);
+                // newest rows after the block: its pushes first, then what is left of the old top
+                Match nt[SNAP];
+                int nk = 0;
+                for (int j = 0; j < SNAP; j++) {
+                    if (j < npush) { nt[j] = r.fTop[j]; nk = j + 1; }
+                    else {
+                        const int o = popB + (j - npush);
+                        if (o < known) { nt[j] = topT[o]; nk = j + 1; }
+                    }
+                }
+                for (int j = 0; j < SNAP; j++) topT[j] = nt[j];
+                known = nk;
+                scanT = r.scanF;
+            }
+        } else {
+            // replay the tile from the true state; its rows replace the speculative ones in the region
+            Chain ch;
+            ch.scan = scanT; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0;
+            vs.own = vs.region + (uint64_t) b * cap; vs.ownN = 0;
+            run_chain(v, cg, q, hits, tileCount, cg.tile0 + b, cg.tile0 + b + 1, vs, ch);
+            const int n = vs.ownN;
+            vs.size_ -= n; vs.ownN = 0; vs.own = nullptr;
+            __builtin_amdgcn_s_waitcnt(0);
+            vs.push_segment((int) b, 0, (uint32_t) n);
+            scanT = ch.scan;
+            known = 0;
+            replayed++;
+        }
+    }
+    // row offsets of the surviving segments (ascending block order = list order)
+    __builtin_amdgcn_s_waitcnt(0);
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < cg.ntiles; b0 += WAVE) {
+        const uint32_t b = b0 + lane;
+        const uint32_t k = b < cg.ntiles ? vs.keepN[b] : 0;
+        uint32_t x = k;                                          // inclusive wave scan
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t y = (uint32_t) __shfl_up((int) x, d);
+            if ((int) lane >= d) x += y;
+        }
+        if (b < cg.ntiles) dstOff[cg.tile0 + b] = run + x - k;
+        run += (uint32_t) __shfl((int) x, WAVE - 1);
+    }
+    if (lane == 0) {
+        matchCount[blockIdx.x] = run;
+        atomicAdd(&stats[3], (unsigned long long) replayed);
+    }
+}
+
+// copy every block's surviving rows to their place in the contig's match array
+__global__ void __launch_bounds__(WAVE) k_gather(const Contig *__restrict__ contigs, const uint32_t *__restrict__ tileContig,
+                                                 const Match *__restrict__ regions, uint32_t cap,
+                                                 const uint32_t *__restrict__ segStart, const uint32_t *__restrict__ keepN,
+                                                 const uint32_t *__restrict__ dstOff, Match *__restrict__ matches) {
+    const uint32_t tile = blockIdx.x;
+    const uint32_t n = keepN[tile];
+    if (n == 0) return;
+    const Contig cg = contigs[tileContig[tile]];
+    const Match *src = regions + (uint64_t) tile * cap + segStart[tile];
+    Match *dst = matches + cg.matchBase + dstOff[tile];
+    for (uint32_t k = threadIdx.x; k < n; k += WAVE) dst[k] = src[k];
 }
 
 // order-sensitive fingerprint of the whole batch, single thread: test hook only

@@ -78,8 +78,12 @@ struct swsem {
     DevBuf<Contig> dContigs;
     DevBuf<uint32_t> dTileContig, dTileCount, dMatchCount;
     DevBuf<Hit> dHits;
-    DevBuf<Match> dMatches;
+    DevBuf<Match> dMatches, dRegions;
+    DevBuf<BlockRec> dRecs;
+    DevBuf<uint32_t> dSegStart, dKeepN, dDstOff;
+    DevBuf<int32_t> dPrev;
     DevBuf<unsigned long long> dStats;
+    bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     std::vector<Contig> contigs;
     std::vector<uint32_t> matchCount;
     std::vector<swsem_match_t> hostMatches;
@@ -87,7 +91,7 @@ struct swsem {
     uint32_t ntiles = 0;
     uint32_t minLen = 0;
     bool batchValid = false;
-    uint64_t stats[5] = {0, 0, 0, 0, 0};
+    uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
     // --- profiling
     bool prof = false;
     std::vector<ProfEvent> events;
@@ -265,10 +269,32 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
                                                                         h->dTileCount.p);
         h->mark(SWSEM_K_EXTEND, false);
     }
-    h->mark(SWSEM_K_RESOLVE, true);
-    k_resolve_seq<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dHits.p, h->dTileCount.p, h->dMatches.p,
-                                                        h->dMatchCount.p);
-    h->mark(SWSEM_K_RESOLVE, false);
+    if (h->seqResolve || tiles == 0) {
+        h->mark(SWSEM_K_RESOLVE, true);
+        k_resolve_seq<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dHits.p, h->dTileCount.p,
+                                                            h->dMatches.p, h->dMatchCount.p);
+        h->mark(SWSEM_K_RESOLVE, false);
+    } else {
+        // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
+        const uint32_t cap = (uint32_t) ((TILE + OVERLAP + h->K) / h->K + 8);
+        if ((r = h->dRegions.reserve((size_t) tiles * cap))) return r;
+        if ((r = h->dRecs.reserve(tiles))) return r;
+        if ((r = h->dSegStart.reserve(tiles))) return r;
+        if ((r = h->dKeepN.reserve(tiles))) return r;
+        if ((r = h->dDstOff.reserve(tiles))) return r;
+        if ((r = h->dPrev.reserve(tiles))) return r;
+        h->mark(SWSEM_K_RESOLVE, true);
+        k_resolve_blocks<<<dim3(tiles), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dHits.p,
+                                                                   h->dTileCount.p, h->dRegions.p, cap, h->dRecs.p);
+        h->mark(SWSEM_K_RESOLVE, false);
+        h->mark(SWSEM_K_STITCH, true);
+        k_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dHits.p, h->dTileCount.p, h->dRegions.p, cap,
+                                                       h->dRecs.p, h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
+                                                       h->dMatchCount.p, h->dStats.p);
+        k_gather<<<dim3(tiles), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dTileContig.p, h->dRegions.p, cap, h->dSegStart.p,
+                                                          h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
+        h->mark(SWSEM_K_STITCH, false);
+    }
     HIPCHK(hipGetLastError());
     h->qdev = qdev;
     h->stats[0] = bases;
@@ -283,7 +309,7 @@ int fetch_counts(swsem *h) {
     unsigned long long st[8];
     HIPCHK(hipMemcpyAsync(st, h->dStats.p, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->stats[1] = st[1]; h->stats[2] = st[2];
+    h->stats[1] = st[1]; h->stats[2] = st[2]; h->stats[5] = st[3];
     uint64_t tot = 0;
     for (int c = 0; c < n; c++) tot += h->matchCount[c];
     h->stats[3] = tot;
@@ -324,6 +350,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     h->samplingPos = (uint64_t) k1;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     h->ownStream = true;
+    if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
         hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
         hipMalloc((void **) &h->lut, 256) != hipSuccess) {
@@ -354,6 +381,8 @@ void swsem_destroy(swsem_t *h) {
     if (h->lut) (void) hipFree(h->lut);
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dTileCount.release();
     h->dMatchCount.release(); h->dHits.release(); h->dMatches.release(); h->dStats.release();
+    h->dRegions.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
+    h->dPrev.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -527,9 +556,9 @@ int swsem_profile_get(swsem_t *h, double ms[SWSEM_K_COUNT], uint64_t n[SWSEM_K_C
     return SWSEM_OK;
 }
 
-int swsem_batch_stats(swsem_t *h, uint64_t s[5]) {
+int swsem_batch_stats(swsem_t *h, uint64_t s[6]) {
     if (!h->batchValid) return fail(SWSEM_EINVAL, "no batch results");
-    for (int i = 0; i < 5; i++) s[i] = h->stats[i];
+    for (int i = 0; i < 6; i++) s[i] = h->stats[i];
     return SWSEM_OK;
 }
 
