@@ -25,8 +25,8 @@ struct __attribute__((aligned(16))) Hit {
     uint32_t ell;      // equal bytes to the left of (c,i), limited to min(i, c - lo) and EXT_CAP
     uint32_t rext;     // equal bytes to the right of (c+K, i+K), limited by hi / N and EXT_CAP
     uint32_t loDist;   // c - tmpStart1, saturated
-    uint32_t flags;    // bit0: ell hit the cap, bit1: rext hit the cap
-    uint32_t pad;
+    uint32_t flagL;    // HIT_CAPL when ell hit the cap (written by the left-extension thread)
+    uint32_t flagR;    // HIT_CAPR when rext hit the cap (written by the right-extension thread)
 };
 constexpr uint32_t HIT_CAPL = 1u, HIT_CAPR = 2u;
 
@@ -42,8 +42,8 @@ struct Contig {
     uint64_t matchBase;// first row of this contig in the batch match array
     uint32_t tile0;    // first tile of this contig
     uint32_t ntiles;
-    uint32_t matchCap; // rows reserved
-    uint32_t pad;
+    uint32_t rb0;      // first resolve block of this contig
+    uint32_t nrb;      // resolve blocks (= ceil(ntiles / tiles per resolve block))
 };
 
 // frozen matcher state seen by the kernels of one round
@@ -56,16 +56,18 @@ struct RefView {
     uint32_t minLen;
 };
 
-// little-endian u32 at an arbitrary byte address, built from two aligned dwords. An aligned dword
-// that holds at least one valid byte never crosses a page, so this is safe at buffer ends as long as
-// the caller only asks for addresses whose 4 bytes are valid.
+// little-endian loads at arbitrary byte addresses. gfx950 under HSA runs global memory in unaligned
+// access mode, so hipcc lowers these to single global_load_dword / _dwordx4; callers only ask for
+// ranges whose bytes are all valid.
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
-    const uintptr_t a = (uintptr_t) p;
-    const uint32_t *b = (const uint32_t *) (a & ~(uintptr_t) 3);
-    const uint32_t sh = (uint32_t) (a & 3);
-    const uint32_t lo = b[0];
-    if (sh == 0) return lo;
-    return __builtin_amdgcn_alignbyte(b[1], lo, sh);
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint4 ld_u128(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
 }
 
 // maRushPrime1HashSimplified<K>, utils/Hashes.h:28-40, one step (pure u32 arithmetic is exact)

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_
             Hit hrec;
             hrec.c = cpos[k];
             hrec.i = (uint32_t) (ts + k * PROBE_THREADS + threadIdx.x);
-            hrec.ell = 0; hrec.rext = 0; hrec.loDist = 0; hrec.flags = 0; hrec.pad = 0;
+            hrec.ell = 0; hrec.rext = 0; hrec.loDist = 0; hrec.flagL = 0; hrec.flagR = 0;
             out[slot] = hrec;
         }
 #pragma unroll
@@ -180,6 +180,17 @@ __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *a, const uint8_t *b, uint32_t maxlen) {
     uint32_t n = 0;
+    while (n + 16 <= maxlen) {
+        const uint4 x = ld_u128(a + n), y = ld_u128(b + n);
+        const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+        if (d0 | d1 | d2 | d3) {
+            if (d0) return n + (uint32_t) (__builtin_ctz(d0) >> 3);
+            if (d1) return n + 4 + (uint32_t) (__builtin_ctz(d1) >> 3);
+            if (d2) return n + 8 + (uint32_t) (__builtin_ctz(d2) >> 3);
+            return n + 12 + (uint32_t) (__builtin_ctz(d3) >> 3);
+        }
+        n += 16;
+    }
     while (n + 4 <= maxlen) {
         const uint32_t x = ld_u32(a + n) ^ ld_u32(b + n);
         if (x) return n + (uint32_t) (__builtin_ctz(x) >> 3);
@@ -191,6 +202,17 @@ __device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *a, const uint8_t *b, 
 // equal bytes at a[-1], a[-2], ... vs b[-1], b[-2], ...
 __device__ __forceinline__ uint32_t lcp_bwd(const uint8_t *a, const uint8_t *b, uint32_t maxlen) {
     uint32_t n = 0;
+    while (n + 16 <= maxlen) {
+        const uint4 x = ld_u128(a - n - 16), y = ld_u128(b - n - 16);
+        const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+        if (d0 | d1 | d2 | d3) {
+            if (d3) return n + (uint32_t) (__builtin_clz(d3) >> 3);
+            if (d2) return n + 4 + (uint32_t) (__builtin_clz(d2) >> 3);
+            if (d1) return n + 8 + (uint32_t) (__builtin_clz(d1) >> 3);
+            return n + 12 + (uint32_t) (__builtin_clz(d0) >> 3);
+        }
+        n += 16;
+    }
     while (n + 4 <= maxlen) {
         const uint32_t x = ld_u32(a - n - 4) ^ ld_u32(b - n - 4);
         if (x) return n + (uint32_t) (__builtin_clz(x) >> 3);
@@ -200,34 +222,39 @@ __device__ __forceinline__ uint32_t lcp_bwd(const uint8_t *a, const uint8_t *b, 
     return n;
 }
 
+// One workgroup per probe tile, two threads per hit: even thread = left run, odd thread = right run.
 __global__ void __launch_bounds__(256) k_extend(RefView v, const uint8_t *__restrict__ qbuf,
                                                 const Contig *__restrict__ contigs,
                                                 const uint32_t *__restrict__ tileContig, Hit *__restrict__ hits,
                                                 const uint32_t *__restrict__ tileCount) {
-    const uint32_t tile = blockIdx.x / (TILE / 256);
-    const uint32_t slot = (blockIdx.x % (TILE / 256)) * 256 + threadIdx.x;
-    if (slot >= tileCount[tile]) return;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t cnt = tileCount[tile];
+    if (cnt == 0) return;
     const Contig cg = contigs[tileContig[tile]];
-    Hit *hp = hits + (uint64_t) tile * TILE + slot;
-    const uint64_t c = hp->c;
-    const uint32_t i = hp->i;
-    uint64_t lo, hi;
-    window_ok(v, cg.lock, c, lo, hi);
     const uint8_t *q = qbuf + cg.qoff;
-    const uint64_t maxR64 = (hi - (c + v.K)) < (cg.n - ((uint64_t) i + v.K)) ? (hi - (c + v.K)) : (cg.n - ((uint64_t) i + v.K));
-    const uint32_t maxR = maxR64 > EXT_CAP ? EXT_CAP : (uint32_t) maxR64;
-    const uint32_t rext = lcp_fwd(v.ref + c + v.K, q + i + v.K, maxR);
-    const uint64_t loDist = c - lo;
-    const uint64_t jmax64 = (uint64_t) i < loDist ? (uint64_t) i : loDist;
-    const uint32_t jmax = jmax64 > EXT_CAP ? EXT_CAP : (uint32_t) jmax64;
-    const uint32_t ell = lcp_bwd(v.ref + c, q + i, jmax);
-    uint32_t flags = 0;
-    if (rext == EXT_CAP && maxR64 > EXT_CAP) flags |= HIT_CAPR;
-    if (ell == EXT_CAP && jmax64 > EXT_CAP) flags |= HIT_CAPL;
-    hp->ell = ell;
-    hp->rext = rext;
-    hp->loDist = loDist > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) loDist;
-    hp->flags = flags;
+    for (uint32_t slot = threadIdx.x >> 1; slot < cnt; slot += 128) {
+        Hit *hp = hits + (uint64_t) tile * TILE + slot;
+        const uint64_t c = hp->c;
+        const uint32_t i = hp->i;
+        uint64_t lo, hi;
+        window_ok(v, cg.lock, c, lo, hi);
+        if (threadIdx.x & 1) {
+            const uint64_t ra = hi - (c + v.K), rb = cg.n - ((uint64_t) i + v.K);
+            const uint64_t maxR64 = ra < rb ? ra : rb;
+            const uint32_t maxR = maxR64 > EXT_CAP ? EXT_CAP : (uint32_t) maxR64;
+            const uint32_t rext = lcp_fwd(v.ref + c + v.K, q + i + v.K, maxR);
+            hp->rext = rext;
+            hp->flagR = (rext == EXT_CAP && maxR64 > EXT_CAP) ? HIT_CAPR : 0;
+        } else {
+            const uint64_t loDist = c - lo;
+            const uint64_t jmax64 = (uint64_t) i < loDist ? (uint64_t) i : loDist;
+            const uint32_t jmax = jmax64 > EXT_CAP ? EXT_CAP : (uint32_t) jmax64;
+            const uint32_t ell = lcp_bwd(v.ref + c, q + i, jmax);
+            hp->ell = ell;
+            hp->loDist = loDist > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) loDist;
+            hp->flagL = (ell == EXT_CAP && jmax64 > EXT_CAP) ? HIT_CAPL : 0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,7 +485,7 @@ __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, 
             Hit h;
             bool valid = b + lane < cnt;
             if (valid) h = th[b + lane];
-            else { h.c = 0; h.i = 0; h.ell = 0; h.rext = 0; h.loDist = 0; h.flags = 0; h.pad = 0; }
+            else { h.c = 0; h.i = 0; h.ell = 0; h.rext = 0; h.loDist = 0; h.flagL = 0; h.flagR = 0; }
             while (true) {
                 const unsigned long long m = __ballot(valid && (int64_t) h.i >= ch.scan);
                 if (!m) break;
@@ -469,7 +496,7 @@ __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, 
                 const int64_t ell = (uint32_t) __shfl((int) h.ell, l);
                 const int64_t rext = (uint32_t) __shfl((int) h.rext, l);
                 const int64_t loDist = (uint32_t) __shfl((int) h.loDist, l);
-                const uint32_t flags = (uint32_t) __shfl((int) h.flags, l);
+                const uint32_t flags = (uint32_t) __shfl((int) (h.flagL | h.flagR), l);
                 process_hit(v, cg, q, stk, ch, c, i, ell, rext, loDist, flags);
                 valid = valid && lane > (uint32_t) l;
             }
@@ -506,66 +533,90 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
 // construction; speculation only decides how much of the work ran in parallel.
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) BlockRec {
-    int64_t scanB;         // scan position at the tile boundary (clamped to >= tile start)
-    int64_t scanF;         // scan position after the tile
+    int64_t scanB;         // scan position at the block boundary (clamped to >= block start)
+    int64_t scanF;         // scan position after the block
     int32_t spB, spF;      // stack size at the boundary / at the end
-    int32_t minTouched;    // lowest index examined while replaying the own tile (INT_MAX: nothing visited)
-    int32_t minKeep;       // rows of the boundary stack that survived the own tile (<= spB)
+    int32_t minTouched;    // lowest index examined while replaying the own tiles (INT_MAX: nothing visited)
+    int32_t minKeep;       // rows of the boundary stack that survived the own tiles (<= spB)
     Match bTop[SNAP];      // newest rows at the boundary, newest first
     Match fTop[SNAP];      // newest rows at the end, newest first
 };
 
 __device__ __forceinline__ void snapshot_top(const Match *st, int sp, Match *out) {
+#pragma unroll
     for (int j = 0; j < SNAP; j++) {
         if (j < sp) out[j] = st[sp - 1 - j];
         else { out[j].posSrc = 0; out[j].len = 0; out[j].posDest = 0; }
     }
 }
 
+// resolve block rbIdx of a contig = tiles [rbIdx*rb, (rbIdx+1)*rb) of it
 __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
-                                                         const uint32_t *__restrict__ tileContig,
+                                                         const uint32_t *__restrict__ rbContig,
                                                          const Hit *__restrict__ hits,
                                                          const uint32_t *__restrict__ tileCount,
-                                                         Match *__restrict__ regions, uint32_t cap,
+                                                         Match *__restrict__ regions, uint32_t cap, uint32_t rb,
                                                          BlockRec *__restrict__ recs) {
     __shared__ uint2 ring[RING];
-    const uint32_t tile = blockIdx.x;
-    const Contig cg = contigs[tileContig[tile]];
-    const uint32_t b = tile - cg.tile0;
-    const int64_t w0 = (int64_t) b * TILE;
+    const uint32_t g = blockIdx.x;
+    const Contig cg = contigs[rbContig[g]];
+    const uint32_t b = g - cg.rb0;
+    const uint32_t t0 = cg.tile0 + b * rb;
+    const uint32_t t1 = t0 + rb < cg.tile0 + cg.ntiles ? t0 + rb : cg.tile0 + cg.ntiles;
+    const int64_t w0 = (int64_t) b * rb * TILE;
     Chain ch;
     ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0;
     ArrayStack stk;
-    stk.st = regions + (uint64_t) tile * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
+    stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
-    if (b) run_chain(v, cg, q, hits, tileCount, tile - 1, tile, stk, ch);   // warm-up on the previous tile's tail
+    if (b) run_chain(v, cg, q, hits, tileCount, t0 - 1, t0, stk, ch);   // warm-up on the previous tile's tail
     BlockRec r;
     r.scanB = ch.scan > w0 ? ch.scan : w0;
     r.spB = stk.sp;
     __builtin_amdgcn_s_waitcnt(0);            // the wave's own stack rows are read back below
     snapshot_top(stk.st, stk.sp, r.bTop);
     ch.minTouched = 0x7fffffff; ch.minKeep = stk.sp; ch.visited = 0;
-    run_chain(v, cg, q, hits, tileCount, tile, tile + 1, stk, ch);
+    run_chain(v, cg, q, hits, tileCount, t0, t1, stk, ch);
     r.scanF = ch.scan;
     r.spF = stk.sp;
     r.minTouched = ch.visited ? ch.minTouched : 0x7fffffff;
     r.minKeep = ch.minKeep < r.spB ? ch.minKeep : r.spB;
+    __builtin_amdgcn_s_waitcnt(0);
     snapshot_top(stk.st, stk.sp, r.fTop);
-    if (threadIdx.x == 0) recs[tile] = r;
+    if (threadIdx.x == 0) recs[g] = r;
 }
 
 __device__ __forceinline__ bool same_match(const Match &a, const Match &b) {
     return a.posSrc == b.posSrc && a.len == b.len && a.posDest == b.posDest;
 }
 
-// One wave per contig: walk the blocks with the true state (see above). Outputs per block the
+// newest-first window over the true list, kept in registers (static indices only)
+struct TopWin {
+    Match e[SNAP];
+    int known;
+    __device__ __forceinline__ void drop(int p) {
+        for (int k = 0; k < p && k < SNAP; k++) {
+#pragma unroll
+            for (int j = 0; j + 1 < SNAP; j++) e[j] = e[j + 1];
+        }
+        known = known > p ? known - p : 0;
+    }
+    __device__ __forceinline__ void prepend(const Match &m) {
+#pragma unroll
+        for (int j = SNAP - 1; j > 0; j--) e[j] = e[j - 1];
+        e[0] = m;
+        known = known < SNAP ? known + 1 : SNAP;
+    }
+};
+
+// One wave per contig: walk the resolve blocks with the true state (see above). Outputs per block the
 // segment (segStart, keepN) of its region that belongs to the final list, the row offsets and the
 // contig's match count.
 __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__restrict__ qbuf,
                                                  const Contig *__restrict__ contigs, const Hit *__restrict__ hits,
                                                  const uint32_t *__restrict__ tileCount, Match *__restrict__ regions,
-                                                 uint32_t cap, const BlockRec *__restrict__ recs,
+                                                 uint32_t cap, uint32_t rb, const BlockRec *__restrict__ recs,
                                                  uint32_t *__restrict__ segStart, uint32_t *__restrict__ keepN,
                                                  int32_t *__restrict__ prev, uint32_t *__restrict__ dstOff,
                                                  uint32_t *__restrict__ matchCount,
@@ -574,85 +625,88 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     const uint32_t lane = threadIdx.x;
     const uint8_t *q = qbuf + cg.qoff;
     VirtStack vs;
-    vs.region = regions + (uint64_t) cg.tile0 * cap; vs.cap = cap;
-    vs.segStart = segStart + cg.tile0; vs.keepN = keepN + cg.tile0; vs.prev = prev + cg.tile0;
+    vs.region = regions + (uint64_t) cg.rb0 * cap; vs.cap = cap;
+    vs.segStart = segStart + cg.rb0; vs.keepN = keepN + cg.rb0; vs.prev = prev + cg.rb0;
     vs.segTop = -1; vs.size_ = 0; vs.own = nullptr; vs.ownN = 0; vs.curSeg = -1; vs.curLocal = 0; vs.curR = 0;
-    for (uint32_t b = lane; b < cg.ntiles; b += WAVE) { vs.keepN[b] = 0; vs.segStart[b] = 0; }
+    for (uint32_t b = lane; b < cg.nrb; b += WAVE) { vs.keepN[b] = 0; vs.segStart[b] = 0; }
     __builtin_amdgcn_s_waitcnt(0);
     int64_t scanT = 0;                 // true scan position
-    Match topT[SNAP];                  // newest true rows, newest first
-    int known = 0;                     // how many entries of topT are valid
+    TopWin top;                        // newest true rows
+    top.known = 0;
     uint32_t replayed = 0;
-    const BlockRec *rc = recs + cg.tile0;
-    for (uint32_t b = 0; b < cg.ntiles; b++) {
-        const int64_t w0 = (int64_t) b * TILE;
-        if (scanT >= w0 + TILE) continue;                       // the sequential loop jumped over this tile
+    const BlockRec *rc = recs + cg.rb0;
+    const int64_t span = (int64_t) rb * TILE;
+    for (uint32_t b = 0; b < cg.nrb; b++) {
+        const int64_t w0 = (int64_t) b * span;
+        if (scanT >= w0 + span) continue;                       // the sequential loop jumped over this block
         const BlockRec r = rc[b];
+        const bool visited = r.minTouched != 0x7fffffff;
         bool ok;
         if (b == 0) ok = true;                                  // block 0 started from the true (empty) state
         else {
             ok = (scanT > w0 ? scanT : w0) == r.scanB;
-            if (ok && r.minTouched != 0x7fffffff) {
-                const int D = r.minTouched < 0 ? r.spB + 1 : r.spB - r.minTouched;
+            if (ok && visited) {
+                // rows of the boundary stack the block looked at (all of them + "nothing below" when it
+                // walked off the bottom)
+                const int cmp = r.minTouched < 0 ? r.spB : r.spB - r.minTouched;
                 if (r.minTouched < 0) ok = vs.size_ == r.spB && r.spB <= SNAP;
-                else ok = D <= SNAP && D <= vs.size_;
-                const int cmp = r.minTouched < 0 ? r.spB : D;
-                if (ok && cmp > known) {                        // refresh the true top rows from the list
+                else ok = cmp <= SNAP && cmp <= vs.size_;
+                if (ok && cmp > top.known) {                    // refresh the true newest rows from the list
                     __builtin_amdgcn_s_waitcnt(0);
-                    for (int j = 0; j < SNAP && j < vs.size_; j++) topT[j] = *vs.at(vs.size_ - 1 - j);
-                    known = vs.size_ < SNAP ? vs.size_ : SNAP;
+                    const int n = vs.size_ < SNAP ? vs.size_ : SNAP;
+#pragma unroll
+                    for (int j = 0; j < SNAP; j++)
+                        if (j < n) top.e[j] = *vs.at(vs.size_ - 1 - j);
+                    top.known = n;
                 }
-                for (int j = 0; ok && j < cmp; j++) ok = same_match(topT[j], r.bTop[j]);
+#pragma unroll
+                for (int j = 0; j < SNAP; j++)
+                    if (ok && j < cmp) ok = same_match(top.e[j], r.bTop[j]);
             }
         }
         if (ok) {
-            if (r.minTouched != 0x7fffffff || b == 0) {
+            if (visited || b == 0) {
                 const int popB = r.spB - r.minKeep;
                 const int npush = r.spF - r.minKeep;
                 if (popB > 0) vs.pop_segments(popB);
                 vs.size_ -= popB;
                 vs.push_segment((int) b, (uint32_t) r.minKeep, (uint32_t) npush);
-                // newest rows after the block: its pushes first, then what is left of the old top
-                Match nt[SNAP];
-                int nk = 0;
-                for (int j = 0; j < SNAP; j++) {
-                    if (j < npush) { nt[j] = r.fTop[j]; nk = j + 1; }
-                    else {
-                        const int o = popB + (j - npush);
-                        if (o < known) { nt[j] = topT[o]; nk = j + 1; }
-                    }
-                }
-                for (int j = 0; j < SNAP; j++) topT[j] = nt[j];
-                known = nk;
+                top.drop(popB);
+                if (npush >= SNAP) top.known = 0;               // fully replaced by the block's own rows
+#pragma unroll
+                for (int j = SNAP - 1; j >= 0; j--)
+                    if (j < npush) top.prepend(r.fTop[j]);
                 scanT = r.scanF;
             }
         } else {
-            // replay the tile from the true state; its rows replace the speculative ones in the region
+            // replay the block from the true state; its rows replace the speculative ones in the region
             Chain ch;
             ch.scan = scanT; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0;
             vs.own = vs.region + (uint64_t) b * cap; vs.ownN = 0;
-            run_chain(v, cg, q, hits, tileCount, cg.tile0 + b, cg.tile0 + b + 1, vs, ch);
+            const uint32_t t0 = cg.tile0 + b * rb;
+            const uint32_t t1 = t0 + rb < cg.tile0 + cg.ntiles ? t0 + rb : cg.tile0 + cg.ntiles;
+            run_chain(v, cg, q, hits, tileCount, t0, t1, vs, ch);
             const int n = vs.ownN;
             vs.size_ -= n; vs.ownN = 0; vs.own = nullptr;
             __builtin_amdgcn_s_waitcnt(0);
             vs.push_segment((int) b, 0, (uint32_t) n);
             scanT = ch.scan;
-            known = 0;
+            top.known = 0;
             replayed++;
         }
     }
     // row offsets of the surviving segments (ascending block order = list order)
     __builtin_amdgcn_s_waitcnt(0);
     uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < cg.ntiles; b0 += WAVE) {
+    for (uint32_t b0 = 0; b0 < cg.nrb; b0 += WAVE) {
         const uint32_t b = b0 + lane;
-        const uint32_t k = b < cg.ntiles ? vs.keepN[b] : 0;
+        const uint32_t k = b < cg.nrb ? vs.keepN[b] : 0;
         uint32_t x = k;                                          // inclusive wave scan
         for (int d = 1; d < WAVE; d <<= 1) {
             const uint32_t y = (uint32_t) __shfl_up((int) x, d);
             if ((int) lane >= d) x += y;
         }
-        if (b < cg.ntiles) dstOff[cg.tile0 + b] = run + x - k;
+        if (b < cg.nrb) dstOff[cg.rb0 + b] = run + x - k;
         run += (uint32_t) __shfl((int) x, WAVE - 1);
     }
     if (lane == 0) {
@@ -662,16 +716,16 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
 }
 
 // copy every block's surviving rows to their place in the contig's match array
-__global__ void __launch_bounds__(WAVE) k_gather(const Contig *__restrict__ contigs, const uint32_t *__restrict__ tileContig,
+__global__ void __launch_bounds__(WAVE) k_gather(const Contig *__restrict__ contigs, const uint32_t *__restrict__ rbContig,
                                                  const Match *__restrict__ regions, uint32_t cap,
                                                  const uint32_t *__restrict__ segStart, const uint32_t *__restrict__ keepN,
                                                  const uint32_t *__restrict__ dstOff, Match *__restrict__ matches) {
-    const uint32_t tile = blockIdx.x;
-    const uint32_t n = keepN[tile];
+    const uint32_t g = blockIdx.x;
+    const uint32_t n = keepN[g];
     if (n == 0) return;
-    const Contig cg = contigs[tileContig[tile]];
-    const Match *src = regions + (uint64_t) tile * cap + segStart[tile];
-    Match *dst = matches + cg.matchBase + dstOff[tile];
+    const Contig cg = contigs[rbContig[g]];
+    const Match *src = regions + (uint64_t) g * cap + segStart[g];
+    Match *dst = matches + cg.matchBase + dstOff[g];
     for (uint32_t k = threadIdx.x; k < n; k += WAVE) dst[k] = src[k];
 }
 

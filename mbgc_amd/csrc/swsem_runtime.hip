@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -76,7 +77,7 @@ struct swsem {
     // --- per-round scratch
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
-    DevBuf<uint32_t> dTileContig, dTileCount, dMatchCount;
+    DevBuf<uint32_t> dTileContig, dTileCount, dMatchCount, dRbContig;
     DevBuf<Hit> dHits;
     DevBuf<Match> dMatches, dRegions;
     DevBuf<BlockRec> dRecs;
@@ -84,6 +85,7 @@ struct swsem {
     DevBuf<int32_t> dPrev;
     DevBuf<unsigned long long> dStats;
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
+    uint32_t rb = 4;                       // probe tiles per resolve block (SWSEM_RB)
     std::vector<Contig> contigs;
     std::vector<uint32_t> matchCount;
     std::vector<swsem_match_t> hostMatches;
@@ -224,9 +226,9 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     h->matchCount.clear();
     h->minLen = minLen;
     h->contigs.assign(n, Contig());
-    std::vector<uint32_t> tileContig;
+    std::vector<uint32_t> tileContig, rbContig;
     uint64_t matchRows = 0, bases = 0;
-    uint32_t tiles = 0;
+    uint32_t tiles = 0, rblocks = 0;
     for (int c = 0; c < n; c++) {
         Contig &cg = h->contigs[c];
         cg.qoff = offsets[c];
@@ -237,10 +239,13 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         cg.tile0 = tiles;
         cg.ntiles = (uint32_t) ((npos + TILE - 1) / TILE);
         cg.matchBase = matchRows;
-        cg.matchCap = (uint32_t) (cg.n / minLen + 2);
-        matchRows += cg.matchCap;
+        matchRows += cg.n / minLen + 2;
+        cg.rb0 = rblocks;
+        cg.nrb = (cg.ntiles + h->rb - 1) / h->rb;
         for (uint32_t t = 0; t < cg.ntiles; t++) tileContig.push_back((uint32_t) c);
+        for (uint32_t t = 0; t < cg.nrb; t++) rbContig.push_back((uint32_t) c);
         tiles += cg.ntiles;
+        rblocks += cg.nrb;
         bases += cg.n;
     }
     h->ntiles = tiles;
@@ -253,8 +258,11 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if ((r = h->dHits.reserve((size_t) std::max<uint32_t>(tiles, 1) * TILE))) return r;
     if ((r = h->dMatches.reserve(matchRows))) return r;
     HIPCHK(hipMemcpyAsync(h->dContigs.p, h->contigs.data(), n * sizeof(Contig), hipMemcpyHostToDevice, h->stream));
-    if (tiles)
+    if ((r = h->dRbContig.reserve(std::max<uint32_t>(rblocks, 1)))) return r;
+    if (tiles) {
         HIPCHK(hipMemcpyAsync(h->dTileContig.p, tileContig.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->dRbContig.p, rbContig.data(), rblocks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(hipMemsetAsync(h->dStats.p, 0, 8 * sizeof(unsigned long long), h->stream));
     // the host vectors above must outlive the async copies
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -265,7 +273,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
                                                                   h->dTileCount.p, h->dStats.p);
         h->mark(SWSEM_K_PROBE, false);
         h->mark(SWSEM_K_EXTEND, true);
-        k_extend<<<dim3(tiles * (TILE / 256)), dim3(256), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dHits.p,
+        k_extend<<<dim3(tiles), dim3(256), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dHits.p,
                                                                         h->dTileCount.p);
         h->mark(SWSEM_K_EXTEND, false);
     }
@@ -276,23 +284,23 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         h->mark(SWSEM_K_RESOLVE, false);
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
-        const uint32_t cap = (uint32_t) ((TILE + OVERLAP + h->K) / h->K + 8);
-        if ((r = h->dRegions.reserve((size_t) tiles * cap))) return r;
-        if ((r = h->dRecs.reserve(tiles))) return r;
-        if ((r = h->dSegStart.reserve(tiles))) return r;
-        if ((r = h->dKeepN.reserve(tiles))) return r;
-        if ((r = h->dDstOff.reserve(tiles))) return r;
-        if ((r = h->dPrev.reserve(tiles))) return r;
+        const uint32_t cap = (uint32_t) ((h->rb * TILE + OVERLAP + h->K) / h->K + 8);
+        if ((r = h->dRegions.reserve((size_t) rblocks * cap))) return r;
+        if ((r = h->dRecs.reserve(rblocks))) return r;
+        if ((r = h->dSegStart.reserve(rblocks))) return r;
+        if ((r = h->dKeepN.reserve(rblocks))) return r;
+        if ((r = h->dDstOff.reserve(rblocks))) return r;
+        if ((r = h->dPrev.reserve(rblocks))) return r;
         h->mark(SWSEM_K_RESOLVE, true);
-        k_resolve_blocks<<<dim3(tiles), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dHits.p,
-                                                                   h->dTileCount.p, h->dRegions.p, cap, h->dRecs.p);
+        k_resolve_blocks<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dHits.p,
+                                                                     h->dTileCount.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
         k_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dHits.p, h->dTileCount.p, h->dRegions.p, cap,
-                                                       h->dRecs.p, h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
-                                                       h->dMatchCount.p, h->dStats.p);
-        k_gather<<<dim3(tiles), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dTileContig.p, h->dRegions.p, cap, h->dSegStart.p,
-                                                          h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
+                                                       h->rb, h->dRecs.p, h->dSegStart.p, h->dKeepN.p, h->dPrev.p,
+                                                       h->dDstOff.p, h->dMatchCount.p, h->dStats.p);
+        k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
+                                                            h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
         h->mark(SWSEM_K_STITCH, false);
     }
     HIPCHK(hipGetLastError());
@@ -351,6 +359,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     h->ownStream = true;
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
+    if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rb = (uint32_t) x; }
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
         hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
         hipMalloc((void **) &h->lut, 256) != hipSuccess) {
@@ -382,7 +391,7 @@ void swsem_destroy(swsem_t *h) {
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dTileCount.release();
     h->dMatchCount.release(); h->dHits.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
-    h->dPrev.release();
+    h->dPrev.release(); h->dRbContig.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }

@@ -194,3 +194,35 @@ def test_batch_round_on_device(binding):
     fp, tot, ln = h.batch_fingerprint()
     allm = np.concatenate(exp)
     assert fp == _orc.fingerprint(allm) and tot == len(allm) and ln == int(allm[:, 1].sum())
+
+
+@pytest.mark.parametrize("env", [{"SWSEM_RESOLVE": "seq"}, {"SWSEM_RB": "1"}, {"SWSEM_RB": "2"}, {"SWSEM_RB": "16"}])
+def test_resolve_variants_agree_with_oracle(binding, env, monkeypatch):
+    """sequential replay, and block-parallel speculation at several block sizes: same rows"""
+    for k, val in env.items():
+        monkeypatch.setenv(k, val)
+    for div, seed in ((0.01, 41), (0.0005, 42), (0.1, 43)):
+        gs = small_collection(4, 120_000, div, seed=seed)
+        h, o = pair(binding, 8_000_000)
+        for m in (h, o):
+            m.load_ref(gs[0], load_rc=True)
+        for g in gs[1:]:
+            assert np.array_equal(h.match(g), o.match(g)), (env, div)
+            for m in (h, o):
+                m.load_ref(g)
+        h.close(); o.close()
+
+
+def test_speculation_mostly_accepted(binding):
+    """on the 99 %-identity regime nearly every resolve block is accepted as speculated"""
+    import torch
+    gs = small_collection(3, 1_000_000, 0.01, seed=77)
+    h = binding.SlidingWindowSparseEMMatcher(16_000_000)
+    h.load_ref(gs[0], load_rc=True)
+    buf = torch.from_numpy(np.concatenate(gs[1:])).to("cuda:0")
+    torch.cuda.synchronize()
+    h.match_batch_dev(buf.data_ptr(), np.array([0, 1_000_000, 2_000_000], dtype=np.uint64), 32, None)
+    h.batch_counts()
+    st = h.batch_stats()
+    nblocks = 2 * ((1_000_000 - 27 + 4095) // 4096 + 3) // 4
+    assert st["replayed_blocks"] <= nblocks // 10, st
