@@ -9,7 +9,6 @@ constexpr int WAVE = 64;
 constexpr int TILE = 4096;            // query positions per probe tile (= one resolve block)
 constexpr int PROBE_THREADS = 256;
 constexpr int POS_PER_THREAD = TILE / PROBE_THREADS;
-constexpr uint32_t EXT_CAP = 2048;    // bytes compared per side by the per-hit extension kernel
 constexpr int OVERLAP_MATCH_MAX_LENGTH = 1 << 13;   // SlidingWindowSparseEMMatcher.h:18
 
 // Hash-table entry: (epoch << 32) | (pos >> k1ord). The reference's table is "last writer wins" in
@@ -18,17 +17,7 @@ constexpr int OVERLAP_MATCH_MAX_LENGTH = 1 << 13;   // SlidingWindowSparseEMMatc
 // image a single CPU thread leaves behind. The low word alone is the reference's 32-bit entry.
 typedef unsigned long long ht_entry;
 
-// one verified k-mer hit of a query position (32 B)
-struct __attribute__((aligned(16))) Hit {
-    uint64_t c;        // reference position of the sample (htDecodePos)
-    uint32_t i;        // query position
-    uint32_t ell;      // equal bytes to the left of (c,i), limited to min(i, c - lo) and EXT_CAP
-    uint32_t rext;     // equal bytes to the right of (c+K, i+K), limited by hi / N and EXT_CAP
-    uint32_t loDist;   // c - tmpStart1, saturated
-    uint32_t flagL;    // HIT_CAPL when ell hit the cap (written by the left-extension thread)
-    uint32_t flagR;    // HIT_CAPR when rext hit the cap (written by the right-extension thread)
-};
-constexpr uint32_t HIT_CAPL = 1u, HIT_CAPR = 2u;
+constexpr uint32_t HIT_CAPL = 1u, HIT_CAPR = 2u;   // the left / right run is known only up to the value held
 
 struct Match {         // == swsem_match_t
     uint64_t posSrc, len, posDest;
@@ -40,6 +29,7 @@ struct Contig {
     uint64_t n;        // contig length
     uint64_t lock;     // matchingLockPos or UINT64_MAX
     uint64_t matchBase;// first row of this contig in the batch match array
+    uint64_t candBase; // first slot of this contig in the candidate array (ntiles * TILE slots)
     uint32_t tile0;    // first tile of this contig
     uint32_t ntiles;
     uint32_t rb0;      // first resolve block of this contig

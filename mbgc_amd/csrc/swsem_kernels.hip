@@ -1,6 +1,7 @@
 // Hand-written CDNA4 (gfx950) kernels of the MBGC match-finding hot path: reference loading
-// (copy / reverse complement / sparse k-mer insertion), hash-table probing with k-mer verification,
-// per-hit exact extension and the greedy match resolution. Integer/byte work, HBM-bound: no MFMA.
+// (copy / reverse complement / sparse k-mer insertion), hash-table probing of every query position,
+// and the greedy match resolution with wave-cooperative exact extension. Integer/byte work,
+// HBM-bound: no MFMA.
 #include "swsem_device.h"
 
 namespace swk {
@@ -51,25 +52,25 @@ __global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// probe + verify: the query scan of processExactMatchQueryIgnoreCollisionsTight, .cpp:200-226,:298
-// One workgroup = one tile of TILE consecutive query positions of one contig. The tile's bytes are
-// staged once into LDS with coalesced dword loads; every position's K-mer hash is built from LDS,
-// the hash table is gathered (one 8-byte entry per position, all gathers of a thread in flight
-// together), entries passing the sliding-window test are verified against the reference K-mer, and
-// the verified hits are compacted in position order into the tile's slot range.
+// probe: the table lookups of the query scan, processExactMatchQueryIgnoreCollisionsTight
+// .cpp:200-222, for EVERY query position at once (the sequential loop only visits a subset; which
+// subset is decided later by the resolve chains). One workgroup = one tile of TILE consecutive
+// positions of one contig. The tile's bytes are staged once into LDS with coalesced dword loads, every
+// position's K-mer hash is built from LDS, the hash table is gathered (one 8-byte entry per position,
+// all gathers of a thread in flight together) and the entry — zeroed when empty or rejected by the
+// sliding-window test — is stored per position with coalesced dword stores.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ tileContig,
-                                                         Hit *__restrict__ hits, uint32_t *__restrict__ tileCount,
+                                                         uint32_t *__restrict__ cand,
                                                          unsigned long long *__restrict__ stats) {
     __shared__ uint32_t qs[TILE / 4 + 24];
-    __shared__ uint32_t waveCnt[POS_PER_THREAD][PROBE_THREADS / WAVE];
     const uint32_t tile = blockIdx.x;
     const Contig cg = contigs[tileContig[tile]];
     const uint64_t ts = (uint64_t) (tile - cg.tile0) * TILE;        // first position of the tile
     const int K = v.K;
-    const uint64_t npos_all = cg.n + 1 >= (uint64_t) K + 1 ? cg.n - K + 1 : 0;   // positions i with i + K <= N
+    const uint64_t npos_all = cg.n >= (uint64_t) K ? cg.n - K + 1 : 0;           // positions i with i + K <= N
     const uint32_t npos = npos_all > ts ? (uint32_t) (npos_all - ts < TILE ? npos_all - ts : TILE) : 0;
     const uint8_t *q = qbuf + cg.qoff;
     // stage bytes [ts, ts + npos + K - 1) from the enclosing aligned dwords
@@ -107,160 +108,30 @@ __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_
         const uint32_t j = k * PROBE_THREADS + threadIdx.x;
         ent[k] = j < npos ? (uint32_t) v.ht[hsh[k]] : 0u;
     }
-    uint64_t cpos[POS_PER_THREAD];
-    const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    uint32_t nver = 0;
+    uint32_t *out = cand + cg.candBase + ts;
+    uint32_t nz = 0;
 #pragma unroll
     for (int k = 0; k < POS_PER_THREAD; k++) {
         const uint32_t j = k * PROBE_THREADS + threadIdx.x;
-        uint64_t c = 0;
-        if (ent[k] != 0) {                                            // .cpp:208
-            c = (uint64_t) ent[k] << v.k1ord;                         // htDecodePos, .h:133
+        uint32_t e = ent[k];
+        if (e != 0) {                                                 // .cpp:208
             uint64_t lo, hi;
-            if (!window_ok(v, cg.lock, c, lo, hi)) c = 0;
+            if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;   // .cpp:212-220
         }
-        if (c) {                                                      // memcmp(curr1, curr2, K) == 0, .cpp:298
-            const uint32_t o = sh + j;
-            const uint32_t *w = qs + (o >> 2);
-            const uint32_t s = o & 3;
-            const uint8_t *r = v.ref + c;
-            uint32_t lo = w[0];
-            bool same = true;
-            for (int x = 0; x < nw; x++) {
-                const uint32_t hi = w[x + 1];
-                same &= __builtin_amdgcn_alignbyte(hi, lo, s) == ld_u32(r + 4 * x);
-                lo = hi;
-            }
-            if (!same) c = 0;
-        }
-        cpos[k] = c;
-        const unsigned long long b = __ballot(c != 0);
-        if (lane == 0) waveCnt[k][wv] = (uint32_t) __popcll(b);
-        nver += c != 0;
+        out[j] = e;                                                   // the whole tile slot is written
+        nz += e != 0;
     }
-    __syncthreads();
-    // position order inside the tile = (k, wave, lane) lexicographic
-    uint32_t base = 0, total = 0;
-    {
-        uint32_t run = 0;
-#pragma unroll
-        for (int k = 0; k < POS_PER_THREAD; k++)
-#pragma unroll
-            for (int w = 0; w < PROBE_THREADS / WAVE; w++) run += waveCnt[k][w];
-        total = run;
-    }
-    Hit *out = hits + (uint64_t) tile * TILE;
-#pragma unroll
-    for (int k = 0; k < POS_PER_THREAD; k++) {
-        uint32_t off = base;
-        for (uint32_t w = 0; w < wv; w++) off += waveCnt[k][w];
-        const unsigned long long b = __ballot(cpos[k] != 0);
-        if (cpos[k]) {
-            const uint32_t slot = off + (uint32_t) __popcll(b & ((1ull << lane) - 1));
-            Hit hrec;
-            hrec.c = cpos[k];
-            hrec.i = (uint32_t) (ts + k * PROBE_THREADS + threadIdx.x);
-            hrec.ell = 0; hrec.rext = 0; hrec.loDist = 0; hrec.flagL = 0; hrec.flagR = 0;
-            out[slot] = hrec;
-        }
-#pragma unroll
-        for (int w = 0; w < PROBE_THREADS / WAVE; w++) base += waveCnt[k][w];
-    }
-    if (threadIdx.x == 0) {
-        tileCount[tile] = total;
-        atomicAdd(&stats[1], (unsigned long long) npos);
-        atomicAdd(&stats[2], (unsigned long long) total);
-    }
+    const unsigned long long b = __ballot(nz != 0);
+    (void) b;
+    for (int d = WAVE / 2; d > 0; d >>= 1) nz += (uint32_t) __shfl_down((int) nz, d);
+    if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&stats[2], (unsigned long long) nz);
+    if (threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long) npos);
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-hit exact extension (.cpp:227-246 to the right, the equality run used by :257-259,:264-266,
-// :278-280 to the left). One thread per verified hit; runs are capped at EXT_CAP bytes and flagged,
-// the resolve kernel continues a capped run on demand.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lcp_fwd(const uint8_t *a, const uint8_t *b, uint32_t maxlen) {
-    uint32_t n = 0;
-    while (n + 16 <= maxlen) {
-        const uint4 x = ld_u128(a + n), y = ld_u128(b + n);
-        const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
-        if (d0 | d1 | d2 | d3) {
-            if (d0) return n + (uint32_t) (__builtin_ctz(d0) >> 3);
-            if (d1) return n + 4 + (uint32_t) (__builtin_ctz(d1) >> 3);
-            if (d2) return n + 8 + (uint32_t) (__builtin_ctz(d2) >> 3);
-            return n + 12 + (uint32_t) (__builtin_ctz(d3) >> 3);
-        }
-        n += 16;
-    }
-    while (n + 4 <= maxlen) {
-        const uint32_t x = ld_u32(a + n) ^ ld_u32(b + n);
-        if (x) return n + (uint32_t) (__builtin_ctz(x) >> 3);
-        n += 4;
-    }
-    while (n < maxlen && a[n] == b[n]) n++;
-    return n;
-}
-// equal bytes at a[-1], a[-2], ... vs b[-1], b[-2], ...
-__device__ __forceinline__ uint32_t lcp_bwd(const uint8_t *a, const uint8_t *b, uint32_t maxlen) {
-    uint32_t n = 0;
-    while (n + 16 <= maxlen) {
-        const uint4 x = ld_u128(a - n - 16), y = ld_u128(b - n - 16);
-        const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
-        if (d0 | d1 | d2 | d3) {
-            if (d3) return n + (uint32_t) (__builtin_clz(d3) >> 3);
-            if (d2) return n + 4 + (uint32_t) (__builtin_clz(d2) >> 3);
-            if (d1) return n + 8 + (uint32_t) (__builtin_clz(d1) >> 3);
-            return n + 12 + (uint32_t) (__builtin_clz(d0) >> 3);
-        }
-        n += 16;
-    }
-    while (n + 4 <= maxlen) {
-        const uint32_t x = ld_u32(a - n - 4) ^ ld_u32(b - n - 4);
-        if (x) return n + (uint32_t) (__builtin_clz(x) >> 3);
-        n += 4;
-    }
-    while (n < maxlen && a[-(int64_t) n - 1] == b[-(int64_t) n - 1]) n++;
-    return n;
-}
-
-// One workgroup per probe tile, two threads per hit: even thread = left run, odd thread = right run.
-__global__ void __launch_bounds__(256) k_extend(RefView v, const uint8_t *__restrict__ qbuf,
-                                                const Contig *__restrict__ contigs,
-                                                const uint32_t *__restrict__ tileContig, Hit *__restrict__ hits,
-                                                const uint32_t *__restrict__ tileCount) {
-    const uint32_t tile = blockIdx.x;
-    const uint32_t cnt = tileCount[tile];
-    if (cnt == 0) return;
-    const Contig cg = contigs[tileContig[tile]];
-    const uint8_t *q = qbuf + cg.qoff;
-    for (uint32_t slot = threadIdx.x >> 1; slot < cnt; slot += 128) {
-        Hit *hp = hits + (uint64_t) tile * TILE + slot;
-        const uint64_t c = hp->c;
-        const uint32_t i = hp->i;
-        uint64_t lo, hi;
-        window_ok(v, cg.lock, c, lo, hi);
-        if (threadIdx.x & 1) {
-            const uint64_t ra = hi - (c + v.K), rb = cg.n - ((uint64_t) i + v.K);
-            const uint64_t maxR64 = ra < rb ? ra : rb;
-            const uint32_t maxR = maxR64 > EXT_CAP ? EXT_CAP : (uint32_t) maxR64;
-            const uint32_t rext = lcp_fwd(v.ref + c + v.K, q + i + v.K, maxR);
-            hp->rext = rext;
-            hp->flagR = (rext == EXT_CAP && maxR64 > EXT_CAP) ? HIT_CAPR : 0;
-        } else {
-            const uint64_t loDist = c - lo;
-            const uint64_t jmax64 = (uint64_t) i < loDist ? (uint64_t) i : loDist;
-            const uint32_t jmax = jmax64 > EXT_CAP ? EXT_CAP : (uint32_t) jmax64;
-            const uint32_t ell = lcp_bwd(v.ref + c, q + i, jmax);
-            hp->ell = ell;
-            hp->loDist = loDist > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) loDist;
-            hp->flagL = (ell == EXT_CAP && jmax64 > EXT_CAP) ? HIT_CAPL : 0;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// greedy resolution: the match list semantics of .cpp:250-315, replayed on the precomputed hits.
-// One wave per chain; every lane runs the same (wave-uniform) automaton, 64 hits are fetched per
-// step and skipped hits are jumped over with a ballot. No reference or query byte is touched
+// greedy resolution: the match list semantics of .cpp:250-315, replayed on the candidate array.
+// One wave per chain; every lane runs the same (wave-uniform) automaton, 64 positions are fetched per
+// step and skipped positions are jumped over with a ballot. Reference and query bytes are only touched
 // unless a capped run has to be continued.
 // ------------------------------------------------------------------------------------------------
 struct Chain {
@@ -357,38 +228,63 @@ struct VirtStack {
     }
 };
 
-// continue a capped left run (wave-cooperative, 256 bytes per step)
-__device__ uint32_t wave_more_left(const uint8_t *a, const uint8_t *b, uint32_t have, uint64_t limit) {
+// Wave-cooperative exact comparison, 256 bytes per step: equal bytes of a[n..limit) vs b[n..limit)
+// given that the first n are equal. steps > 0 bounds the number of wave steps; *more tells the caller
+// the run may continue past the value returned.
+__device__ uint64_t wave_lcp_fwd(const uint8_t *a, const uint8_t *b, uint64_t n, uint64_t limit, int steps, bool &more) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    uint64_t n = have;
-    while (n + 4 * WAVE <= limit) {
-        const uint32_t x = ld_u32(a - n - 4 * lane - 4) ^ ld_u32(b - n - 4 * lane - 4);
-        const unsigned long long bad = __ballot(x != 0);
-        if (bad) {
-            const int l = __builtin_ctzll(bad);
-            const uint32_t xl = __shfl(x, l);
-            return (uint32_t) (n + 4 * l + (__builtin_clz(xl) >> 3));
+    more = false;
+    while (n < limit) {
+        const uint64_t off = n + 4 * lane;
+        uint32_t eq = 4;
+        bool stop = false;
+        if (off + 4 <= limit) {
+            const uint32_t x = ld_u32(a + off) ^ ld_u32(b + off);
+            if (x) { eq = (uint32_t) (__builtin_ctz(x) >> 3); stop = true; }
+        } else {
+            eq = 0; stop = true;
+            if (off < limit) {
+                const uint32_t avail = (uint32_t) (limit - off);
+                while (eq < avail && a[off + eq] == b[off + eq]) eq++;
+            }
+        }
+        const unsigned long long bal = __ballot(stop);
+        if (bal) {
+            const int l = __builtin_ctzll(bal);
+            return n + 4 * (uint64_t) l + (uint32_t) __shfl((int) eq, l);
         }
         n += 4 * WAVE;
+        if (steps && --steps == 0 && n < limit) { more = true; return n; }
     }
-    while (n < limit && a[-(int64_t) n - 1] == b[-(int64_t) n - 1]) n++;
-    return (uint32_t) n;
+    return limit;
 }
-__device__ uint32_t wave_more_right(const uint8_t *a, const uint8_t *b, uint32_t have, uint64_t limit) {
+// the same to the left: equal bytes of a[-1-k] vs b[-1-k], k in [n, limit)
+__device__ uint64_t wave_lcp_bwd(const uint8_t *a, const uint8_t *b, uint64_t n, uint64_t limit, int steps, bool &more) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    uint64_t n = have;
-    while (n + 4 * WAVE <= limit) {
-        const uint32_t x = ld_u32(a + n + 4 * lane) ^ ld_u32(b + n + 4 * lane);
-        const unsigned long long bad = __ballot(x != 0);
-        if (bad) {
-            const int l = __builtin_ctzll(bad);
-            const uint32_t xl = __shfl(x, l);
-            return (uint32_t) (n + 4 * l + (__builtin_ctz(xl) >> 3));
+    more = false;
+    while (n < limit) {
+        const uint64_t off = n + 4 * lane;
+        uint32_t eq = 4;
+        bool stop = false;
+        if (off + 4 <= limit) {
+            const uint32_t x = ld_u32(a - off - 4) ^ ld_u32(b - off - 4);
+            if (x) { eq = (uint32_t) (__builtin_clz(x) >> 3); stop = true; }
+        } else {
+            eq = 0; stop = true;
+            if (off < limit) {
+                const uint32_t avail = (uint32_t) (limit - off);
+                while (eq < avail && a[-(int64_t) (off + eq) - 1] == b[-(int64_t) (off + eq) - 1]) eq++;
+            }
+        }
+        const unsigned long long bal = __ballot(stop);
+        if (bal) {
+            const int l = __builtin_ctzll(bal);
+            return n + 4 * (uint64_t) l + (uint32_t) __shfl((int) eq, l);
         }
         n += 4 * WAVE;
+        if (steps && --steps == 0 && n < limit) { more = true; return n; }
     }
-    while (n < limit && a[n] == b[n]) n++;
-    return (uint32_t) n;
+    return limit;
 }
 
 // Processes one visited hit. All arguments are wave-uniform. Returns true when a match was emitted.
@@ -404,7 +300,8 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
         if ((flags & HIT_CAPL) && x > ell) {
             const uint64_t d = c - lo;
             const uint64_t jmax = (uint64_t) i < d ? (uint64_t) i : d;
-            ell = wave_more_left(v.ref + c, q + i, (uint32_t) ell, jmax);
+            bool more;
+            ell = (int64_t) wave_lcp_bwd(v.ref + c, q + i, (uint64_t) ell, jmax, 0, more);
             flags &= ~HIT_CAPL;
         }
     };
@@ -452,7 +349,8 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
     if (K + rext + s > (int64_t) v.minLen || (flags & HIT_CAPR)) {
         if (flags & HIT_CAPR) {
             const uint64_t a = hi - (c + K), b = cg.n - ((uint64_t) i + K);
-            rext = wave_more_right(v.ref + c + K, q + i + K, (uint32_t) rext, a < b ? a : b);
+            bool more;
+            rext = (int64_t) wave_lcp_fwd(v.ref + c + K, q + i + K, (uint64_t) rext, a < b ? a : b, 0, more);
             flags &= ~HIT_CAPR;
         }
         if (K + rext + s > (int64_t) v.minLen) {
@@ -472,35 +370,51 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
     return false;
 }
 
-// Runs the chain over the hits of tiles [t0, t1) of one contig.
+// A visited candidate: verify the K-mer (memcmp(curr1, curr2, K), .cpp:298 — a failed candidate changes
+// no state in the reference either), take the first 256-byte step of the right run (.cpp:227-246) and
+// of the left run, all loads of the three comparisons in flight together, then run the automaton.
 template <class Stack>
-__device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const Hit *__restrict__ hits,
-                          const uint32_t *__restrict__ tileCount, uint32_t t0, uint32_t t1, Stack &stk, Chain &ch) {
+__device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stack &stk, Chain &ch, int64_t i, uint32_t val) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    for (uint32_t t = t0; t < t1; t++) {
-        const uint32_t cnt = tileCount[t];
-        const Hit *th = hits + (uint64_t) t * TILE;
-        if ((int64_t) (t - cg.tile0 + 1) * TILE <= ch.scan) continue;   // the whole tile was jumped over
-        for (uint32_t b = 0; b < cnt; b += WAVE) {
-            Hit h;
-            bool valid = b + lane < cnt;
-            if (valid) h = th[b + lane];
-            else { h.c = 0; h.i = 0; h.ell = 0; h.rext = 0; h.loDist = 0; h.flagL = 0; h.flagR = 0; }
-            while (true) {
-                const unsigned long long m = __ballot(valid && (int64_t) h.i >= ch.scan);
-                if (!m) break;
-                const int l = __builtin_ctzll(m);
-                const uint64_t c = ((uint64_t) (uint32_t) __shfl((int) (h.c >> 32), l) << 32) |
-                                   (uint32_t) __shfl((int) (uint32_t) h.c, l);
-                const int64_t i = (uint32_t) __shfl((int) h.i, l);
-                const int64_t ell = (uint32_t) __shfl((int) h.ell, l);
-                const int64_t rext = (uint32_t) __shfl((int) h.rext, l);
-                const int64_t loDist = (uint32_t) __shfl((int) h.loDist, l);
-                const uint32_t flags = (uint32_t) __shfl((int) (h.flagL | h.flagR), l);
-                process_hit(v, cg, q, stk, ch, c, i, ell, rext, loDist, flags);
-                valid = valid && lane > (uint32_t) l;
-            }
+    const uint64_t c = (uint64_t) val << v.k1ord;                     // htDecodePos, .h:133
+    uint64_t lo, hi;
+    window_ok(v, cg.lock, c, lo, hi);
+    const int64_t K = v.K;
+    const uint8_t *r0 = v.ref + c, *q0 = q + i;
+    const uint64_t ra = hi - (c + K), rb = cg.n - ((uint64_t) i + K);
+    const uint64_t limR = ra < rb ? ra : rb;
+    const uint64_t d = c - lo;
+    const uint64_t limL = (uint64_t) i < d ? (uint64_t) i : d;
+    uint32_t xk = 0;
+    if ((int) lane < (int) (K / 4)) xk = ld_u32(r0 + 4 * lane) ^ ld_u32(q0 + 4 * lane);
+    bool moreR, moreL;
+    const uint64_t rext = wave_lcp_fwd(r0 + K, q0 + K, 0, limR, 1, moreR);
+    const uint64_t ell = wave_lcp_bwd(r0, q0, 0, limL, 1, moreL);
+    if (__ballot(xk != 0)) { ch.scan = i + 1; return; }
+    process_hit(v, cg, q, stk, ch, c, i, (int64_t) ell, (int64_t) rext, (int64_t) (d > 0xFFFFFFFFull ? 0xFFFFFFFFull : d),
+                (moreL ? HIT_CAPL : 0u) | (moreR ? HIT_CAPR : 0u));
+}
+
+// Runs the chain over the candidates at query positions [p0, p1) of one contig (p1 <= positions).
+template <class Stack>
+__device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
+                          int64_t p0, int64_t p1, Stack &stk, Chain &ch) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    while (true) {
+        const int64_t s = ch.scan > p0 ? ch.scan : p0;
+        if (s >= p1) break;
+        const int64_t base = s & ~(int64_t) (WAVE - 1);
+        const int64_t pos = base + lane;
+        const uint32_t val = (pos >= s && pos < p1) ? cand[pos] : 0u;
+        unsigned long long m = __ballot(val != 0);
+        if (!m) { ch.scan = base + WAVE < p1 ? base + WAVE : p1; continue; }
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            visit(v, cg, q, stk, ch, base + l, (uint32_t) __shfl((int) val, l));
+            const int64_t rel = ch.scan - base;                       // first lane still to be visited
+            m = rel >= WAVE ? 0ull : (m & ~((1ull << rel) - 1));
         }
+        if (ch.scan < base + WAVE) ch.scan = base + WAVE < p1 ? base + WAVE : p1;
     }
 }
 
@@ -508,8 +422,7 @@ __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, 
 // of the block-parallel path (SWSEM_RESOLVE=seq).
 __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *__restrict__ qbuf,
                                                       const Contig *__restrict__ contigs,
-                                                      const Hit *__restrict__ hits,
-                                                      const uint32_t *__restrict__ tileCount,
+                                                      const uint32_t *__restrict__ cand,
                                                       Match *__restrict__ matches, uint32_t *__restrict__ matchCount) {
     __shared__ uint2 ring[RING];
     const Contig cg = contigs[blockIdx.x];
@@ -517,7 +430,8 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
     ch.scan = 0; ch.minTouched = 0; ch.minKeep = 0; ch.visited = 0;
     ArrayStack stk;
     stk.st = matches + cg.matchBase; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
-    run_chain(v, cg, qbuf + cg.qoff, hits, tileCount, cg.tile0, cg.tile0 + cg.ntiles, stk, ch);
+    const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
+    run_chain(v, cg, qbuf + cg.qoff, cand + cg.candBase, 0, npos, stk, ch);
     if (threadIdx.x == 0) matchCount[blockIdx.x] = (uint32_t) stk.sp;
 }
 
@@ -554,30 +468,30 @@ __device__ __forceinline__ void snapshot_top(const Match *st, int sp, Match *out
 __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ rbContig,
-                                                         const Hit *__restrict__ hits,
-                                                         const uint32_t *__restrict__ tileCount,
+                                                         const uint32_t *__restrict__ cand,
                                                          Match *__restrict__ regions, uint32_t cap, uint32_t rb,
                                                          BlockRec *__restrict__ recs) {
     __shared__ uint2 ring[RING];
     const uint32_t g = blockIdx.x;
     const Contig cg = contigs[rbContig[g]];
     const uint32_t b = g - cg.rb0;
-    const uint32_t t0 = cg.tile0 + b * rb;
-    const uint32_t t1 = t0 + rb < cg.tile0 + cg.ntiles ? t0 + rb : cg.tile0 + cg.ntiles;
+    const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
     const int64_t w0 = (int64_t) b * rb * TILE;
+    const int64_t w1 = w0 + (int64_t) rb * TILE < npos ? w0 + (int64_t) rb * TILE : npos;
+    const uint32_t *cd = cand + cg.candBase;
     Chain ch;
     ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0;
     ArrayStack stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
-    if (b) run_chain(v, cg, q, hits, tileCount, t0 - 1, t0, stk, ch);   // warm-up on the previous tile's tail
+    if (b) run_chain(v, cg, q, cd, w0 - OVERLAP, w0, stk, ch);       // warm-up on the previous block's tail
     BlockRec r;
     r.scanB = ch.scan > w0 ? ch.scan : w0;
     r.spB = stk.sp;
     __builtin_amdgcn_s_waitcnt(0);            // the wave's own stack rows are read back below
     snapshot_top(stk.st, stk.sp, r.bTop);
     ch.minTouched = 0x7fffffff; ch.minKeep = stk.sp; ch.visited = 0;
-    run_chain(v, cg, q, hits, tileCount, t0, t1, stk, ch);
+    run_chain(v, cg, q, cd, w0, w1, stk, ch);
     r.scanF = ch.scan;
     r.spF = stk.sp;
     r.minTouched = ch.visited ? ch.minTouched : 0x7fffffff;
@@ -614,8 +528,8 @@ struct TopWin {
 // segment (segStart, keepN) of its region that belongs to the final list, the row offsets and the
 // contig's match count.
 __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__restrict__ qbuf,
-                                                 const Contig *__restrict__ contigs, const Hit *__restrict__ hits,
-                                                 const uint32_t *__restrict__ tileCount, Match *__restrict__ regions,
+                                                 const Contig *__restrict__ contigs, const uint32_t *__restrict__ cand,
+                                                 Match *__restrict__ regions,
                                                  uint32_t cap, uint32_t rb, const BlockRec *__restrict__ recs,
                                                  uint32_t *__restrict__ segStart, uint32_t *__restrict__ keepN,
                                                  int32_t *__restrict__ prev, uint32_t *__restrict__ dstOff,
@@ -636,6 +550,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     uint32_t replayed = 0;
     const BlockRec *rc = recs + cg.rb0;
     const int64_t span = (int64_t) rb * TILE;
+    const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
     for (uint32_t b = 0; b < cg.nrb; b++) {
         const int64_t w0 = (int64_t) b * span;
         if (scanT >= w0 + span) continue;                       // the sequential loop jumped over this block
@@ -683,9 +598,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
             Chain ch;
             ch.scan = scanT; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0;
             vs.own = vs.region + (uint64_t) b * cap; vs.ownN = 0;
-            const uint32_t t0 = cg.tile0 + b * rb;
-            const uint32_t t1 = t0 + rb < cg.tile0 + cg.ntiles ? t0 + rb : cg.tile0 + cg.ntiles;
-            run_chain(v, cg, q, hits, tileCount, t0, t1, vs, ch);
+            run_chain(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch);
             const int n = vs.ownN;
             vs.size_ -= n; vs.ownN = 0; vs.own = nullptr;
             __builtin_amdgcn_s_waitcnt(0);

@@ -77,8 +77,7 @@ struct swsem {
     // --- per-round scratch
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
-    DevBuf<uint32_t> dTileContig, dTileCount, dMatchCount, dRbContig;
-    DevBuf<Hit> dHits;
+    DevBuf<uint32_t> dTileContig, dMatchCount, dRbContig, dCand;
     DevBuf<Match> dMatches, dRegions;
     DevBuf<BlockRec> dRecs;
     DevBuf<uint32_t> dSegStart, dKeepN, dDstOff;
@@ -238,6 +237,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         const uint64_t npos = cg.n >= (uint64_t) h->K ? cg.n - h->K + 1 : 0;
         cg.tile0 = tiles;
         cg.ntiles = (uint32_t) ((npos + TILE - 1) / TILE);
+        cg.candBase = (uint64_t) tiles * TILE;
         cg.matchBase = matchRows;
         matchRows += cg.n / minLen + 2;
         cg.rb0 = rblocks;
@@ -254,8 +254,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if ((r = h->dMatchCount.reserve(n))) return r;
     if ((r = h->dStats.reserve(8))) return r;
     if ((r = h->dTileContig.reserve(std::max<uint32_t>(tiles, 1)))) return r;
-    if ((r = h->dTileCount.reserve(std::max<uint32_t>(tiles, 1)))) return r;
-    if ((r = h->dHits.reserve((size_t) std::max<uint32_t>(tiles, 1) * TILE))) return r;
+    if ((r = h->dCand.reserve((size_t) std::max<uint32_t>(tiles, 1) * TILE))) return r;
     if ((r = h->dMatches.reserve(matchRows))) return r;
     HIPCHK(hipMemcpyAsync(h->dContigs.p, h->contigs.data(), n * sizeof(Contig), hipMemcpyHostToDevice, h->stream));
     if ((r = h->dRbContig.reserve(std::max<uint32_t>(rblocks, 1)))) return r;
@@ -269,18 +268,12 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     const RefView v = h->view();
     if (tiles) {
         h->mark(SWSEM_K_PROBE, true);
-        k_probe<<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dHits.p,
-                                                                  h->dTileCount.p, h->dStats.p);
+        k_probe<<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
         h->mark(SWSEM_K_PROBE, false);
-        h->mark(SWSEM_K_EXTEND, true);
-        k_extend<<<dim3(tiles), dim3(256), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dHits.p,
-                                                                        h->dTileCount.p);
-        h->mark(SWSEM_K_EXTEND, false);
     }
     if (h->seqResolve || tiles == 0) {
         h->mark(SWSEM_K_RESOLVE, true);
-        k_resolve_seq<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dHits.p, h->dTileCount.p,
-                                                            h->dMatches.p, h->dMatchCount.p);
+        k_resolve_seq<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
         h->mark(SWSEM_K_RESOLVE, false);
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
@@ -292,13 +285,13 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if ((r = h->dDstOff.reserve(rblocks))) return r;
         if ((r = h->dPrev.reserve(rblocks))) return r;
         h->mark(SWSEM_K_RESOLVE, true);
-        k_resolve_blocks<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dHits.p,
-                                                                     h->dTileCount.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
+        k_resolve_blocks<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p,
+                                                                     h->dRegions.p, cap, h->rb, h->dRecs.p);
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
-        k_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dHits.p, h->dTileCount.p, h->dRegions.p, cap,
-                                                       h->rb, h->dRecs.p, h->dSegStart.p, h->dKeepN.p, h->dPrev.p,
-                                                       h->dDstOff.p, h->dMatchCount.p, h->dStats.p);
+        k_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, cap, h->rb, h->dRecs.p,
+                                                       h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
+                                                       h->dMatchCount.p, h->dStats.p);
         k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
                                                             h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
         h->mark(SWSEM_K_STITCH, false);
@@ -388,8 +381,8 @@ void swsem_destroy(swsem_t *h) {
     if (h->ref) (void) hipFree(h->ref);
     if (h->ht) (void) hipFree(h->ht);
     if (h->lut) (void) hipFree(h->lut);
-    h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dTileCount.release();
-    h->dMatchCount.release(); h->dHits.release(); h->dMatches.release(); h->dStats.release();
+    h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release();
+    h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
