@@ -84,7 +84,7 @@ struct swsem {
     DevBuf<int32_t> dPrev;
     DevBuf<unsigned long long> dStats;
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
-    uint32_t rb = 4;                       // probe tiles per resolve block (SWSEM_RB)
+    uint32_t rb = 8;                       // probe tiles per resolve block (SWSEM_RB)
     std::vector<Contig> contigs;
     std::vector<uint32_t> matchCount;
     std::vector<swsem_match_t> hostMatches;
