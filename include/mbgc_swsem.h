@@ -123,6 +123,13 @@ int swsem_emit(swsem_t *h, const swsem_emit_params_t *p, int contig, uint64_t lo
                int unmatchedFractionFactor, int64_t processedTargetsCount, int64_t targetIdx,
                const uint64_t *refExtLoadedPos, uint64_t nLoaded, swsem_streams_t *out);
 
+/* The same for several contigs of the batch in one pass; contigIdx == NULL means contigs 0..n-1; the
+ * per-contig arrays may be NULL (no lock, factor 128, processed 0, target 0). Fetch with swsem_emit_result. */
+int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+                     const int *unmatchedFractionFactor, const int64_t *processedTargetsCount, const int64_t *targetIdx,
+                     const uint64_t *refExtLoadedPos, uint64_t nLoaded);
+int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out);
+
 /* ---- test / measurement hooks (not part of the reference surface) */
 int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out);      /* getRef() bytes, .h:104 */
 int swsem_debug_copy_ht(swsem_t *h, uint32_t *out /* [hash_size] 32-bit image as on the CPU */);

@@ -21,7 +21,7 @@ swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circula
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
-swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_debug_copy_ref swsem_debug_copy_ht
+swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_result swsem_debug_copy_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats""".split()
 
 
@@ -96,6 +96,8 @@ def lib():
         L.swsem_emit_params_default.restype = None
         L.swsem_emit.argtypes = [vp, C.POINTER(EmitParams), ci, u64, ci, C.c_int64, C.c_int64, vp, u64,
                                  C.POINTER(Streams)]
+        L.swsem_emit_batch.argtypes = [vp, C.POINTER(EmitParams), ci, vp, vp, vp, vp, vp, vp, u64]
+        L.swsem_emit_result.argtypes = [vp, ci, C.POINTER(Streams)]
         L.swsem_debug_copy_ref.argtypes = [vp, u64, u64, vp]
         L.swsem_debug_copy_ht.argtypes = [vp, vp]
         L.swsem_profile_enable.argtypes = [vp, ci]
@@ -215,6 +217,27 @@ class SlidingWindowSparseEMMatcher:
         for i, name in enumerate(STREAM_NAMES):
             n = st.size[i]
             streams[name] = bytes(np.ctypeslib.as_array(st.data[i], shape=(n,))) if n else b""
+        return st.unmatchedChars, streams, st
+
+    def emit_batch(self, params, contigs=None, locks=None, factors=None, processed=None, target_idx=None, loaded=None, n=None):
+        """processMatches for several contigs of the last batch at once; fetch with emit_result(k)."""
+        def arr(x, dt):
+            return None if x is None else np.ascontiguousarray(x, dtype=dt)
+        ci, lk, fa = arr(contigs, np.int32), arr(locks, np.uint64), arr(factors, np.int32)
+        pr, ti = arr(processed, np.int64), arr(target_idx, np.int64)
+        ld = np.ascontiguousarray(loaded if loaded is not None else [0], dtype=np.uint64)
+        cnt = n if n is not None else (ci.size if ci is not None else self._batch_n)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        _chk(lib().swsem_emit_batch(self.h, C.byref(params), cnt, ptr(ci), ptr(lk), ptr(fa), ptr(pr), ptr(ti), ptr(ld), ld.size))
+        return cnt
+
+    def emit_result(self, k):
+        st = Streams()
+        _chk(lib().swsem_emit_result(self.h, k, C.byref(st)))
+        streams = {}
+        for i, name in enumerate(STREAM_NAMES):
+            sz = st.size[i]
+            streams[name] = bytes(np.ctypeslib.as_array(st.data[i], shape=(sz,))) if sz else b""
         return st.unmatchedChars, streams, st
 
     # --- test / measurement hooks

@@ -1,0 +1,593 @@
+// Per-contig stream emission on the GPU: MBGC_Encoder::processMatches / extendMatchRight /
+// extendMatchLeft (mbgccoder/MBGC_Encoder.cpp:137-427) and ContextAwareMismatchesCoder::mismatch2code
+// (coders/ContextAwareMismatchesCoder.cpp:65-70). The reference's loop is split by what is truly
+// sequential in it:
+//   k_emit_pass1  gap-breaking removal (:153-199). "removed[j]" only depends on removed[j-1] and a
+//                 locally computable predicate, so it is resolved per run of that predicate; the kept
+//                 rows are compacted and unmatchedChars / totalMatched reduced.      [1024 threads/contig]
+//   k_emit_meta   the pairing ring, gap deltas and gap bookkeeping (:229-278) — a chain over matches
+//                 that never looks at sequence bytes; the 64-deep look-ahead of one match is evaluated
+//                 by the 64 lanes of a wave at once.                                  [one wave/contig]
+//   k_emit_bytes  everything that touches bytes is local to the gap between two consecutive matches:
+//                 right extension of the left match, then left extension of the right match, then the
+//                 plain literals. One thread per gap sizes its output, a block scan places every
+//                 piece, the same automata run again and write.                    [1024 threads/contig]
+#include "swsem_device.h"
+#include "../../include/mbgc_swsem.h"
+
+namespace swk {
+
+constexpr int EMIT_THREADS = 1024;
+constexpr uint8_t MATCH_MARK = 0xA5;                 // MBGC_Params.h:45
+constexpr int MAX_EXTEND_MATCH_LEFT_LENGTH = 1 << 24;// MBGC_Params.h:55
+
+struct EMatch {                                      // TextMatch incl. nextSrcRegionLoadingPos scratch
+    uint64_t posSrc, len, posDest, lp;               // lp = getMatchLoadedPos(posSrc)
+};
+
+struct EmitContig {
+    uint64_t qoff, n;                                // contig bytes
+    uint64_t matchBase;                              // rows of the match-finding result
+    uint64_t lock;
+    uint64_t scratchBase;                            // per-match scratch rows (cap rows)
+    uint64_t streamBase[SWSEM_NSTREAMS];             // byte offsets into the stream arena
+    uint32_t cap;                                    // rows reserved (>= matches + 2)
+    int32_t factor;                                  // unmatchedFractionFactor
+    int64_t processed, targetIdx;                    // processedTargetsCount / targetIdx
+};
+
+struct EmitOut {                                     // per contig, read back by the host
+    uint64_t size[SWSEM_NSTREAMS];
+    uint64_t unmatchedChars;                         // or UINT64_MAX = skipped as dissimilar
+    uint64_t extMatched, extMismatches, totalMatched, removed, nmatches;
+};
+
+struct EmitView {
+    const uint8_t *ref, *qbuf;
+    const Match *matches;
+    const uint32_t *matchCount;
+    uint64_t pos1, refLength, maxRefLength;
+    const uint64_t *loaded; uint32_t nLoaded;       // refExtLoadedPosArr
+    swsem_emit_params_t p;
+    // scratch (rows indexed by EmitContig::scratchBase + t)
+    EMatch *em;                                      // compacted matches
+    uint64_t *next0;                                 // upper_bound(loaded, lp)
+    uint8_t *tflag, *removed;
+    uint32_t *keepIdx;
+    uint32_t *meta;                                  // per kept match, see META_*
+    uint32_t *corr;                                  // gapStartIdx when in a gap
+    uint32_t *sz;                                    // 6 u32 per gap task
+    uint8_t *arena;                                  // streams
+    EmitOut *out;
+};
+
+constexpr uint32_t META_SKIPOFF = 1, META_HASGAP = 2, META_ISGAP = 4, META_GSTART = 8, META_GMID = 16, META_GEND = 32;
+// gap delta byte in bits 8..15
+
+__device__ __forceinline__ bool paired(uint64_t aSrc, uint64_t aDst, uint64_t bSrc, uint64_t bDst) {   // TextMatchers.h:42-44
+    return aSrc + bDst == bSrc + aDst;
+}
+
+// coders/ContextAwareMismatchesCoder.h:13-17, .cpp:65-70 (bytes >= 0x80 index the reference's table out
+// of range; they are treated as outside ACGTN, like the oracle does)
+__device__ __forceinline__ int sym5(uint8_t c) {
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1;
+}
+__device__ __forceinline__ uint8_t mismatch2code(uint8_t actual, uint8_t mismatch) {
+    const int a = sym5(actual), b = sym5(mismatch);
+    if (actual == mismatch || a < 0 || b < 0) return mismatch;
+    // rows A,C,G,T,N of mis2code packed 3 bits per entry (diagonal unused)
+    const uint32_t rows[5] = {0 | 2u << 3 | 0u << 6 | 1u << 9 | 3u << 12, 1 | 0u << 3 | 2u << 6 | 0u << 9 | 3u << 12,
+                              0 | 2u << 3 | 0u << 6 | 1u << 9 | 3u << 12, 1 | 0u << 3 | 2u << 6 | 0u << 9 | 3u << 12,
+                              1 | 2u << 3 | 3u << 6 | 0u << 9 | 0u << 12};
+    return (uint8_t) ((rows[a] >> (3 * b)) & 7u);
+}
+
+// getMatchLoadedPos, MBGC_Encoder.cpp:137-141
+__device__ __forceinline__ uint64_t loaded_pos(const EmitView &v, uint64_t pos) {
+    const uint64_t span = v.refLength - 1;
+    const uint64_t back = v.loaded[v.nLoaded - 1];
+    while (pos + span < back) pos += span;
+    return pos;
+}
+
+// block-wide exclusive scan of one u32 per thread (EMIT_THREADS threads); returns the exclusive prefix,
+// *total = sum over the block
+__device__ uint32_t block_scan(uint32_t x, uint32_t *lds /* [EMIT_THREADS / WAVE + 1] */, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    uint32_t inc = x;
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t y = (uint32_t) __shfl_up((int) inc, d);
+        if ((int) lane >= d) inc += y;
+    }
+    __syncthreads();
+    if (lane == WAVE - 1) lds[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < EMIT_THREADS / WAVE; i++) { const uint32_t t = lds[i]; lds[i] = run; run += t; }
+        lds[EMIT_THREADS / WAVE] = run;
+    }
+    __syncthreads();
+    *total = lds[EMIT_THREADS / WAVE];
+    return lds[w] + inc - x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1, MBGC_Encoder.cpp:153-205
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EMIT_THREADS) k_emit_pass1(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
+    __shared__ uint32_t lds[EMIT_THREADS / WAVE + 2];
+    __shared__ unsigned long long red[2];
+    const EmitContig cg = cgs[blockIdx.x];
+    const int64_t n = v.matchCount[which[blockIdx.x]];
+    const Match *M = v.matches + cg.matchBase;
+    const uint8_t *q = v.qbuf + cg.qoff;
+    uint8_t *tf = v.tflag + cg.scratchBase, *rm = v.removed + cg.scratchBase;
+    uint32_t *kidx = v.keepIdx + cg.scratchBase;
+    EMatch *E = v.em + cg.scratchBase;
+    const bool ext = v.p.enableExtensionsWithMismatches != 0;
+    // (a) the locally computable part of the removal test (:176-178), taking j-1 as the kept predecessor
+    for (int64_t j = threadIdx.x; j < n; j += EMIT_THREADS) {
+        bool t = false;
+        if (ext && j >= 1 && j + 1 < n)
+            t = paired(M[j + 1].posSrc, M[j + 1].posDest, M[j - 1].posSrc, M[j - 1].posDest) &&
+                !paired(M[j].posSrc, M[j].posDest, M[j - 1].posSrc, M[j - 1].posDest) &&
+                M[j].len < v.p.gapBreakingMatchMinLength;
+        tf[j] = t;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (b) a removed match keeps its successor (the successor is then paired with the kept predecessor),
+    // so inside a run of the predicate the matches are removed alternately, starting with the first
+    for (int64_t j = threadIdx.x; j < n; j += EMIT_THREADS) {
+        bool r = false;
+        if (tf[j]) {
+            int64_t k = 0;
+            while (j - 1 - k >= 0 && tf[j - 1 - k]) k++;
+            r = (k & 1) == 0;
+        }
+        rm[j] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (c) compaction; an abutting successor of a removed match is extended to the left (:180-186)
+    uint32_t base = 0;
+    for (int64_t j0 = 0; j0 < n; j0 += EMIT_THREADS) {
+        const int64_t j = j0 + threadIdx.x;
+        const uint32_t keep = (j < n && !rm[j]) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan(keep, lds, &tot);
+        if (keep) {
+            EMatch e;
+            e.posSrc = M[j].posSrc; e.len = M[j].len; e.posDest = M[j].posDest;
+            if (j >= 1 && rm[j - 1] && M[j - 1].posDest + M[j - 1].len == M[j].posDest) {
+                int64_t s = (int64_t) e.posSrc, d = (int64_t) e.posDest;
+                uint64_t x = 0;
+                while (d - 1 >= 0 && s - 1 >= 0 && q[d - 1] == v.ref[s - 1]) { d--; s--; x++; }
+                e.posSrc -= x; e.posDest -= x; e.len += x;       // shiftStartPos(-leftExtension)
+            }
+            e.lp = v.p.lazyDecompressionSupport ? loaded_pos(v, e.posSrc) : 0;
+            E[base + ex] = e;
+            kidx[base + ex] = (uint32_t) j;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    const uint32_t nk = base;
+    __threadfence_block();
+    __syncthreads();
+    // (d) unmatchedChars / totalMatched with the reference's integer types (uint32 pos, :145,:193-196)
+    unsigned long long um = 0, tm = 0;
+    for (uint32_t t = threadIdx.x; t < nk; t += EMIT_THREADS) {
+        const uint32_t pos = t ? (uint32_t) (E[t - 1].posDest + E[t - 1].len) : 0u;
+        um += E[t].posDest - (uint64_t) pos;
+        tm += (uint32_t) E[t].len;
+        if (v.p.lazyDecompressionSupport) {                     // std::upper_bound, :254-256
+            uint32_t lo = 0, hi = v.nLoaded;
+            const uint64_t key = E[t].lp;
+            while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (v.loaded[mid] <= key) lo = mid + 1; else hi = mid; }
+            v.next0[cg.scratchBase + t] = lo == v.nLoaded ? UINT64_MAX : v.loaded[lo];
+        }
+    }
+    if (threadIdx.x == 0) { red[0] = 0; red[1] = 0; }
+    __syncthreads();
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        um += (unsigned long long) __shfl_down((long long) um, d);
+        tm += (unsigned long long) __shfl_down((long long) tm, d);
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) { atomicAdd(&red[0], um); atomicAdd(&red[1], tm); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t pos = nk ? (uint32_t) (E[nk - 1].posDest + E[nk - 1].len) : 0u;
+        const int64_t unmatched = (int64_t) (red[0] + (cg.n - (uint64_t) pos));
+        EmitOut o;
+        for (int s = 0; s < SWSEM_NSTREAMS; s++) o.size[s] = 0;
+        o.unmatchedChars = (uint64_t) unmatched;
+        o.extMatched = 0; o.extMismatches = 0;
+        o.totalMatched = (uint32_t) red[1];
+        o.removed = (uint64_t) (n - nk);
+        o.nmatches = nk;
+        // :203-205 with isContigDissimilar, MGMP_Params.h:193-196
+        if (cg.processed < cg.targetIdx - v.p.allowedTargetsOutrunForDissimilarContigs &&
+            cg.n > v.p.minimalLengthForDissimilarContigs &&
+            (uint64_t) (unmatched * (int64_t) (cg.factor / v.p.unmatchedFractionFactorTweakForDissimilarContigs)) > cg.n)
+            o.unmatchedChars = UINT64_MAX;
+        v.out[blockIdx.x] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the pairing / gap chain, MBGC_Encoder.cpp:229-278 (no sequence bytes involved)
+// ------------------------------------------------------------------------------------------------
+constexpr int META_CHUNK = 1024;
+
+__global__ void __launch_bounds__(WAVE) k_emit_meta(EmitView v, const EmitContig *__restrict__ cgs) {
+    __shared__ int64_t sdiag[META_CHUNK + WAVE];
+    __shared__ uint64_t ssrc[META_CHUNK + WAVE];
+    __shared__ uint64_t slp[META_CHUNK + WAVE];
+    __shared__ uint64_t snx0[META_CHUNK + WAVE];
+    __shared__ uint32_t slen[META_CHUNK + WAVE];
+    __shared__ uint64_t snext[128];                  // inherited nextSrcRegionLoadingPos, ring like pairedGap
+    const EmitContig cg = cgs[blockIdx.x];
+    const EmitOut o = v.out[blockIdx.x];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const int64_t n = (int64_t) o.nmatches;
+    const EMatch *E = v.em + cg.scratchBase;
+    const uint32_t lane = threadIdx.x;
+    const bool lazy = v.p.lazyDecompressionSupport != 0, ext = v.p.enableExtensionsWithMismatches != 0;
+    const int depth = v.p.gapDepthOffsetEncoding;
+    unsigned long long claimed = 0;                  // bit g-1: match j+g is already paired (pairedGap ring)
+    bool curClaimed = false;                         // pairedGap[gapCurIdx]
+    int64_t gapStartIdx = -1, gapEndIdx = -1;
+    for (int i = lane; i < 128; i += WAVE) snext[i] = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += META_CHUNK) {
+        const int64_t cn = n - c0 < META_CHUNK + WAVE ? n - c0 : META_CHUNK + WAVE;
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int64_t t = lane; t < cn; t += WAVE) {
+            const EMatch e = E[c0 + t];
+            sdiag[t] = (int64_t) (e.posSrc - e.posDest);
+            ssrc[t] = e.posSrc;
+            slp[t] = e.lp;
+            slen[t] = (uint32_t) e.len;
+            snx0[t] = lazy ? v.next0[cg.scratchBase + c0 + t] : 0;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        const int64_t jend = c0 + META_CHUNK < n ? c0 + META_CHUNK : n;
+        for (int64_t j = c0; j < jend; j++) {
+            const int64_t lj = j - c0;
+            if (ext && j == gapEndIdx) { gapStartIdx = -1; gapEndIdx = -1; }        // :222-225
+            const bool skipOffset = curClaimed;                                     // :229
+            const uint64_t endj = (uint64_t) ((int64_t) ssrc[lj] - sdiag[lj]) + slen[lj];
+            const uint64_t litLeft = (j + 1 < n ? (uint64_t) ((int64_t) ssrc[lj + 1] - sdiag[lj + 1]) : cg.n) - (uint32_t) endj;   // :242 (uint32 pos)
+            const int gCnt = (int) (n - j - 1 < depth ? n - j - 1 : depth);
+            const int g = (int) lane + 1;
+            const bool rule = !lazy && gapStartIdx == -1 && litLeft == 0;            // :247, applies to g == 1
+            uint64_t nextj = snext[j & 127];
+            bool elig = false;
+            if (g <= gCnt) {
+                const bool taken = ((claimed >> lane) & 1ull) || (rule && g == 1);
+                const uint64_t sj = ssrc[lj], sg = ssrc[lj + g];
+                const bool pw = sdiag[lj] == sdiag[lj + g] &&
+                                ((sj > cg.lock && sg > cg.lock) || (sj < cg.lock && sg < cg.lock));   // TextMatchers.h:46-50
+                elig = !taken && pw;
+            }
+            const unsigned long long pm = __ballot(elig);
+            if (lazy && pm) {
+                if (!nextj) nextj = snx0[lj];                                        // :253-257
+                elig = elig && !(slp[lj + g] >= nextj);                              // :258-259
+            }
+            const unsigned long long em = lazy ? __ballot(elig) : pm;
+            uint32_t gapByte = 0;
+            int gf = 0;
+            if (em) {
+                gf = __builtin_ctzll(em) + 1;
+                const unsigned long long below = gf > 1 ? ((1ull << (gf - 1)) - 1) : 0ull;
+                const int reduce = __popcll((claimed | (rule ? 1ull : 0ull)) & below);
+                gapByte = (uint32_t) (gf - reduce);
+                claimed |= 1ull << (gf - 1);                                         // :262
+                if (lazy) snext[(j + gf) & 127] = nextj;                             // :260
+                if (ext && gapEndIdx <= j + gf && gf <= v.p.gapDepthMismatchesEncoding) { gapStartIdx = j; gapEndIdx = j + gf; }
+            }
+            snext[j & 127] = 0;
+            curClaimed = claimed & 1ull;                                             // :272-273: advance the ring
+            claimed >>= 1;
+            const bool gs = gapStartIdx == j, ge = gapEndIdx == j + 1, gm = gapStartIdx < j && j + 1 < gapEndIdx;
+            const bool isGap = gs || gm || ge;
+            if (lane == 0) {
+                v.meta[cg.scratchBase + j] = (skipOffset ? META_SKIPOFF : 0) | (gCnt ? META_HASGAP : 0) | (isGap ? META_ISGAP : 0) |
+                                             (gs ? META_GSTART : 0) | (gm ? META_GMID : 0) | (ge ? META_GEND : 0) | (gapByte << 8);
+                v.corr[cg.scratchBase + j] = isGap ? (uint32_t) gapStartIdx : (uint32_t) j;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// byte-level automata. W = false: only count; W = true: also write.
+// ------------------------------------------------------------------------------------------------
+struct ExtRes { uint32_t consumed, nlit, nfl, matched, mism; };
+
+// extendMatchRight, MBGC_Encoder.cpp:310-371
+template <bool W>
+__device__ ExtRes ext_right(const EmitView &v, const uint8_t *gap, int64_t src, uint64_t length, bool isGap, bool gapStart,
+                            bool gapMiddle, bool gapEnd, uint8_t *lit, uint8_t *fl) {
+    ExtRes r = {0, 0, 0, 0, 0};
+    const swsem_emit_params_t &p = v.p;
+    if (length == 0) {
+        if (gapMiddle) { if (W) fl[0] = 1; r.nfl = 1; }
+        return r;
+    }
+    const uint8_t *ref = v.ref;
+    const bool lazy = p.lazyDecompressionSupport != 0;
+    const int64_t loading = (int64_t) v.pos1;
+    const int64_t srcGuard = src + (int64_t) length;
+    int64_t valid = src + (int64_t) length;
+    if (src == loading) valid = src;
+    if (!isGap) {
+        const int64_t srcEnd = (int64_t) v.maxRefLength;
+        if (valid > srcEnd) valid = srcEnd;
+        if (src <= loading && loading < valid) valid = loading;
+    }
+    uint32_t g = 0;
+    if (gapStart || !isGap) {
+        if (lazy && ref[src] == 0) valid = src;
+        r.mism++;
+        const uint8_t b = p.mismatchesWithExclusion && src < valid ? mismatch2code(ref[src], gap[0]) : gap[0];
+        if (W) lit[r.nlit] = b;
+        r.nlit++;
+        g++;
+    } else
+        src--;
+    int score = p.mmsMismatchesInitialScore;
+    while (++src < valid && (!lazy || ref[src] != 0) && (isGap || score < p.mmsMismatchesScoreThreshold)) {
+        const bool mm = gap[g] != ref[src];
+        if (W) fl[r.nfl] = mm ? 1 : 0;
+        r.nfl++;
+        if (mm) {
+            r.mism++;
+            score += p.mmsMismatchPenalty;
+            const uint8_t b = p.mismatchesWithExclusion ? mismatch2code(ref[src], gap[g]) : gap[g];
+            if (W) lit[r.nlit] = b;
+            r.nlit++;
+        } else {
+            r.matched++;
+            score -= p.mmsMatchBonus;
+            if (score < 0) score = 0;
+        }
+        g++;
+    }
+    while (src++ < srcGuard && (isGap || score < p.mmsMismatchesScoreThreshold)) {
+        if (W) { fl[r.nfl] = 1; lit[r.nlit] = gap[g]; }
+        r.nfl++; r.nlit++; g++;
+        r.mism++;
+        score += p.mmsMismatchPenalty;
+    }
+    if ((isGap && !gapEnd) || (!isGap && score < p.mmsMismatchesScoreThreshold)) { if (W) fl[r.nfl] = 1; r.nfl++; }
+    r.consumed = g;
+    return r;
+}
+
+// extendMatchLeft, MBGC_Encoder.cpp:373-427
+template <bool W>
+__device__ ExtRes ext_left(const EmitView &v, const uint8_t *dest, uint64_t length, const EMatch &m, uint64_t lockPos,
+                           uint8_t *lit, uint8_t *fl) {
+    ExtRes r = {0, 0, 0, 0, 0};
+    const swsem_emit_params_t &p = v.p;
+    const uint8_t *ref = v.ref;
+    const bool lazy = p.lazyDecompressionSupport != 0;
+    const int64_t srcMatch = (int64_t) m.posSrc;
+    int64_t guard = 1;
+    if (guard < srcMatch - MAX_EXTEND_MATCH_LEFT_LENGTH) guard = srcMatch - MAX_EXTEND_MATCH_LEFT_LENGTH;
+    const int64_t srcLock = (int64_t) lockPos;           // SIZE_MAX behaves like -1 here, as ref + SIZE_MAX does there
+    if (guard < srcLock && srcLock <= srcMatch) guard = srcLock;
+    bool guardKnown = true;
+    if (guard < srcMatch - (int64_t) length) { guard = srcMatch - (int64_t) length; guardKnown = false; }
+    if (guard == srcMatch) return r;
+    int64_t src = srcMatch - 1;
+    const uint8_t *gp = dest + m.posDest - 1;
+    bool validRegion = !lazy || ref[src] != 0;
+    r.mism++;
+    {
+        const uint8_t b = p.mismatchesWithExclusion && validRegion ? mismatch2code(ref[src], *gp) : *gp;
+        if (W) lit[r.nlit] = b;
+        r.nlit++;
+    }
+    int score = p.mmsMismatchesInitialScore;
+    while (validRegion && src > guard && score < p.mmsMismatchesScoreThreshold) {
+        --gp; --src;
+        const bool mm = *gp != ref[src];
+        if (lazy && ref[src] == 0) { validRegion = false; src++; gp++; break; }
+        if (W) fl[r.nfl] = mm ? 1 : 0;
+        r.nfl++;
+        if (mm) {
+            score += p.mmsMismatchPenalty;
+            r.mism++;
+            const uint8_t b = p.mismatchesWithExclusion ? mismatch2code(ref[src], *gp) : *gp;
+            if (W) lit[r.nlit] = b;
+            r.nlit++;
+        } else {
+            score -= p.mmsMatchBonus;
+            if (score < 0) score = 0;
+            r.matched++;
+        }
+    }
+    while (!validRegion && src > guard && score < p.mmsMismatchesScoreThreshold) {
+        src--;
+        --gp;
+        if (W) { fl[r.nfl] = 1; lit[r.nlit] = *gp; }
+        r.nfl++; r.nlit++;
+        r.mism++;
+        score += p.mmsMismatchPenalty;
+    }
+    if ((src != guard || !guardKnown) && score < p.mmsMismatchesScoreThreshold) { if (W) fl[r.nfl] = 1; r.nfl++; }
+    r.consumed = (uint32_t) (srcMatch - src);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t frugal_size(uint64_t v) {        // writeUInt64Frugal, utils/helper.cpp:237-246
+    return v < 0xFFFFu ? 2u : (v < 0xFFFFFFFFull ? 6u : 14u);
+}
+__device__ __forceinline__ void put_bytes(uint8_t *d, uint64_t v, int n) {
+    for (int i = 0; i < n; i++) d[i] = (uint8_t) (v >> (8 * i));
+}
+__device__ void frugal_write(uint8_t *d, uint64_t v) {
+    put_bytes(d, v < 0xFFFFu ? v : 0xFFFFu, 2);
+    if (v >= 0xFFFFu) {
+        put_bytes(d + 2, v < 0xFFFFFFFFull ? v : 0xFFFFFFFFull, 4);
+        if (v >= 0xFFFFFFFFull) put_bytes(d + 6, v, 8);
+    }
+}
+
+// Gap task t (0..n): the bytes between kept match t-1 and kept match t (contig start / end at the rims).
+// It owns: the right extension of match t-1, the left extension of match t and the plain literals in
+// front of match t (or the contig tail).
+struct GapSizes { uint32_t rLit, rFl, lLit, lFl, plain, pos; };
+
+// right extension of match t-1 (t >= 1), :279-286. Returns the position after it.
+template <bool W>
+__device__ uint32_t gap_right(const EmitView &v, const EmitContig &cg, const EMatch *E, int64_t n, int64_t t, const uint8_t *q,
+                              uint8_t *rLit, uint8_t *rFl, GapSizes &s, bool &isGapBefore, uint32_t *counters) {
+    const EMatch mp = E[t - 1];
+    const uint32_t meta = v.meta[cg.scratchBase + t - 1];
+    uint32_t pos = (uint32_t) (mp.posDest + mp.len);                                  // uint32_t pos, :145,:240
+    const uint64_t litLeft = (t < n ? E[t].posDest : cg.n) - pos;                     // :242
+    isGapBefore = (meta & META_ISGAP) != 0;
+    if (v.p.enableExtensionsWithMismatches) {
+        const EMatch core = E[v.corr[cg.scratchBase + t - 1]];
+        const int64_t src = isGapBefore ? (int64_t) (core.posSrc + (mp.posDest + mp.len) - core.posDest)
+                                        : (int64_t) (mp.posSrc + mp.len);
+        const ExtRes r = ext_right<W>(v, q + pos, src, litLeft, isGapBefore, (meta & META_GSTART) != 0, (meta & META_GMID) != 0,
+                                      (meta & META_GEND) != 0, rLit, rFl);
+        s.rLit = r.nlit; s.rFl = r.nfl;
+        pos += r.consumed;
+        if (!W) { counters[0] += r.matched; counters[1] += r.mism; }
+    }
+    return pos;
+}
+
+__device__ GapSizes gap_sizes(const EmitView &v, const EmitContig &cg, const EMatch *E, int64_t n, int64_t t, const uint8_t *q,
+                              uint32_t *counters) {
+    GapSizes s = {0, 0, 0, 0, 0, 0};
+    uint32_t pos = 0;
+    bool isGapBefore = false;
+    if (t >= 1) pos = gap_right<false>(v, cg, E, n, t, q, nullptr, nullptr, s, isGapBefore, counters);
+    if (t < n) {
+        const EMatch m = E[t];
+        uint64_t litLeft = m.posDest - pos;                                             // :216
+        if (v.p.enableExtensionsWithMismatches && !isGapBefore && litLeft) {            // :218-221
+            const ExtRes r = ext_left<false>(v, q, litLeft, m, cg.lock, nullptr, nullptr);
+            s.lLit = r.nlit; s.lFl = r.nfl;
+            litLeft -= r.consumed;
+            counters[0] += r.matched; counters[1] += r.mism;
+        }
+        s.plain = (uint32_t) litLeft;
+    } else
+        s.plain = (uint32_t) (cg.n - pos);                                              // :288-289
+    s.pos = pos;
+    return s;
+}
+
+__global__ void __launch_bounds__(EMIT_THREADS) k_emit_bytes(EmitView v, const EmitContig *__restrict__ cgs) {
+    __shared__ uint32_t lds[EMIT_THREADS / WAVE + 2];
+    __shared__ unsigned int cnt[2];
+    const EmitContig cg = cgs[blockIdx.x];
+    const EmitOut o = v.out[blockIdx.x];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const int64_t n = (int64_t) o.nmatches;
+    const EMatch *E = v.em + cg.scratchBase;
+    const uint8_t *q = v.qbuf + cg.qoff;
+    uint32_t *SZ = v.sz + cg.scratchBase * 6;
+    const bool bit40 = v.p.enable40bitReference != 0, frugal = v.p.frugal64bitLenEncoding != 0;
+    if (threadIdx.x == 0) { cnt[0] = 0; cnt[1] = 0; }
+    __syncthreads();
+    // ---- sizes
+    uint32_t cloc[2] = {0, 0};
+    for (int64_t t = threadIdx.x; t <= n; t += EMIT_THREADS) {
+        const GapSizes s = gap_sizes(v, cg, E, n, t, q, cloc);
+        uint32_t *z = SZ + t * 6;
+        z[0] = s.rLit; z[1] = s.rFl; z[2] = s.lLit; z[3] = s.lFl; z[4] = s.plain; z[5] = s.pos;
+    }
+    atomicAdd(&cnt[0], cloc[0]); atomicAdd(&cnt[1], cloc[1]);
+    __threadfence_block();
+    __syncthreads();
+    // ---- placement. Iteration t of the reference's loop emits, in this order:
+    //   literals: [left codes t][plain t] MATCH_MARK [right codes t]      flags: [left flags t][right flags t]
+    // where "right codes t" are produced by gap task t+1. Per-thread contiguous ranges of iterations,
+    // then one block scan per stream.
+    const int64_t iters = n + 1;                                       // iteration n = contig tail (plain only)
+    const int64_t per = (iters + EMIT_THREADS - 1) / EMIT_THREADS;
+    const int64_t t0 = (int64_t) threadIdx.x * per, t1 = t0 + per < iters ? t0 + per : iters;
+    uint32_t sl = 0, sf = 0, so = 0, s5 = 0, sn = 0, sg = 0;
+    for (int64_t t = t0; t < t1; t++) {
+        const uint32_t *z = SZ + t * 6;
+        sl += z[2] + z[4];
+        sf += z[3];
+        if (t < n) {
+            const uint32_t meta = v.meta[cg.scratchBase + t];
+            const uint32_t *zn = SZ + (t + 1) * 6;
+            sl += 1 + zn[0];
+            sf += zn[1];
+            if (!(meta & META_SKIPOFF)) { so += 4; s5 += bit40 ? 1 : 0; }
+            sn += frugal ? frugal_size(E[t].len) : 4u;
+            sg += (meta & META_HASGAP) ? 1u : 0u;
+        }
+    }
+    uint32_t tl, tf_, to, t5, tn, tg;
+    uint32_t ol = block_scan(sl, lds, &tl);
+    uint32_t of = block_scan(sf, lds, &tf_);
+    uint32_t oo = block_scan(so, lds, &to);
+    uint32_t o5 = block_scan(s5, lds, &t5);
+    uint32_t on = block_scan(sn, lds, &tn);
+    uint32_t og = block_scan(sg, lds, &tg);
+    uint8_t *LIT = v.arena + cg.streamBase[SWSEM_LIT], *FL = v.arena + cg.streamBase[SWSEM_FLAGS];
+    uint8_t *OFF = v.arena + cg.streamBase[SWSEM_OFF], *OF5 = v.arena + cg.streamBase[SWSEM_OFF5];
+    uint8_t *LEN = v.arena + cg.streamBase[SWSEM_LEN], *GAP = v.arena + cg.streamBase[SWSEM_GAP];
+    // ---- write: this thread's iterations in order; the extension codes are produced by re-running the
+    // two gap tasks that belong to an iteration (left codes: task t, right codes: task t+1)
+    uint32_t dummy[2];
+    for (int64_t t = t0; t < t1; t++) {
+        const uint32_t *z = SZ + t * 6;
+        uint8_t *lLit = LIT + ol, *lFl = FL + of;
+        uint8_t *plainDst = lLit + z[2];
+        if (t < n) {
+            const uint32_t *zn = SZ + (t + 1) * 6;
+            uint8_t *rLit = plainDst + z[4] + 1, *rFl = lFl + z[3];
+            // left part (and plain literals) of iteration t
+            if (z[2] | z[3]) {
+                const EMatch m = E[t];
+                ext_left<true>(v, q, m.posDest - z[5], m, cg.lock, lLit, lFl);
+            }
+            for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
+            plainDst[z[4]] = MATCH_MARK;
+            // right part of iteration t = first half of gap task t+1
+            if (zn[0] | zn[1]) {
+                GapSizes tmp = {0, 0, 0, 0, 0, 0};
+                bool gb;
+                gap_right<true>(v, cg, E, n, t + 1, q, rLit, rFl, tmp, gb, dummy);
+            }
+            const uint32_t meta = v.meta[cg.scratchBase + t];
+            if (!(meta & META_SKIPOFF)) {
+                put_bytes(OFF + oo, (uint32_t) E[t].posSrc, 4); oo += 4;
+                if (bit40) { OF5[o5] = (uint8_t) (E[t].posSrc >> 32); o5++; }
+            }
+            if (frugal) { frugal_write(LEN + on, E[t].len); on += frugal_size(E[t].len); }
+            else { put_bytes(LEN + on, (uint32_t) E[t].len, 4); on += 4; }
+            if (meta & META_HASGAP) { GAP[og] = (uint8_t) (meta >> 8); og++; }
+            ol += z[2] + z[4] + 1 + zn[0];
+            of += z[3] + zn[1];
+        } else {
+            for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
+            ol += z[4];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        EmitOut *op = v.out + blockIdx.x;
+        op->size[SWSEM_LIT] = tl; op->size[SWSEM_FLAGS] = tf_; op->size[SWSEM_OFF] = to; op->size[SWSEM_OFF5] = t5;
+        op->size[SWSEM_LEN] = tn; op->size[SWSEM_GAP] = tg;
+        op->extMatched = cnt[0]; op->extMismatches = cnt[1];
+    }
+}
+
+}  // namespace swk

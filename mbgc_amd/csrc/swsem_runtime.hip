@@ -4,6 +4,7 @@
 // the hash table and every per-round intermediate live in HBM.
 #include "../../include/mbgc_swsem.h"
 #include "swsem_kernels.hip"
+#include "swsem_emit.hip"
 
 #include <algorithm>
 #include <cstdarg>
@@ -83,6 +84,18 @@ struct swsem {
     DevBuf<uint32_t> dSegStart, dKeepN, dDstOff;
     DevBuf<int32_t> dPrev;
     DevBuf<unsigned long long> dStats;
+    // --- emission scratch
+    DevBuf<EmitContig> dECg;
+    DevBuf<EmitOut> dEOut;
+    DevBuf<int> dEWhich;
+    DevBuf<EMatch> dEM;
+    DevBuf<uint64_t> dENext0, dELoaded;
+    DevBuf<uint8_t> dETf, dERm, dEArena;
+    DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz;
+    std::vector<EmitContig> ecg;
+    std::vector<EmitOut> eout;
+    std::vector<uint8_t> hostStreams;
+    std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 8;                       // probe tiles per resolve block (SWSEM_RB)
     std::vector<Contig> contigs;
@@ -385,6 +398,9 @@ void swsem_destroy(swsem_t *h) {
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
+    h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
+    h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
+    h->dESz.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -592,9 +608,99 @@ void swsem_emit_params_default(swsem_emit_params_t *p, int mode) {
     }
 }
 
-int swsem_emit(swsem_t *, const swsem_emit_params_t *, int, uint64_t, int, int64_t, int64_t, const uint64_t *, uint64_t,
-               swsem_streams_t *) {
-    return fail(SWSEM_EINVAL, "swsem_emit: not built yet");
+// processMatches for `n` contigs of the last batch in one pass (the reference runs it per contig on the
+// worker thread that matched it, MGMP.cpp:381). Results stay on the handle until the next emit call.
+int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+                     const int *factor, const int64_t *processed, const int64_t *targetIdx,
+                     const uint64_t *refExtLoadedPos, uint64_t nLoaded) {
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->batchValid) return fail(SWSEM_EINVAL, "swsem_emit: no match results on the handle");
+    if (n <= 0) return fail(SWSEM_EINVAL, "swsem_emit: empty request");
+    if (p->lazyDecompressionSupport && nLoaded == 0) return fail(SWSEM_EINVAL, "swsem_emit: lazy mode needs refExtLoadedPosArr");
+    if (p->gapDepthOffsetEncoding > 64 || p->gapDepthOffsetEncoding < 0)
+        return fail(SWSEM_EINVAL, "gapDepthOffsetEncoding %d out of range (MAX_GAP_DEPTH / 2)", p->gapDepthOffsetEncoding);
+    int r;
+    if (h->matchCount.size() != h->contigs.size() && (r = fetch_counts(h))) return r;
+    h->ecg.assign(n, EmitContig());
+    std::vector<int> which(n);
+    uint64_t rows = 0, arena = 0;
+    for (int k = 0; k < n; k++) {
+        const int c = contigIdx ? contigIdx[k] : k;
+        if (c < 0 || c >= (int) h->contigs.size()) return fail(SWSEM_EINVAL, "swsem_emit: no contig %d in the batch", c);
+        which[k] = c;
+        EmitContig &e = h->ecg[k];
+        const Contig &cg = h->contigs[c];
+        const uint64_t nm = h->matchCount[c];
+        e.qoff = cg.qoff; e.n = cg.n; e.matchBase = cg.matchBase;
+        e.lock = lockPos ? lockPos[k] : UINT64_MAX;
+        e.scratchBase = rows;
+        e.cap = (uint32_t) (nm + 2);
+        rows += e.cap;
+        e.factor = factor ? factor[k] : 128;
+        e.processed = processed ? processed[k] : 0;
+        e.targetIdx = targetIdx ? targetIdx[k] : 0;
+        const uint64_t szs[SWSEM_NSTREAMS] = {cg.n + nm + 16, 4 * nm + 16, nm + 16, 14 * nm + 16, nm + 16, cg.n + 2 * nm + 16};
+        for (int st = 0; st < SWSEM_NSTREAMS; st++) { e.streamBase[st] = arena; arena += (szs[st] + 15) & ~15ull; }
+    }
+    if ((r = h->dECg.reserve(n)) || (r = h->dEOut.reserve(n)) || (r = h->dEWhich.reserve(n)) || (r = h->dEM.reserve(rows)) ||
+        (r = h->dENext0.reserve(rows)) || (r = h->dETf.reserve(rows)) || (r = h->dERm.reserve(rows)) ||
+        (r = h->dEKeep.reserve(rows)) || (r = h->dEMeta.reserve(rows)) || (r = h->dECorr.reserve(rows)) ||
+        (r = h->dESz.reserve(rows * 6)) || (r = h->dEArena.reserve(arena)) || (r = h->dELoaded.reserve(nLoaded + 1)))
+        return r;
+    HIPCHK(hipMemcpyAsync(h->dECg.p, h->ecg.data(), n * sizeof(EmitContig), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dEWhich.p, which.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (nLoaded) HIPCHK(hipMemcpyAsync(h->dELoaded.p, refExtLoadedPos, nLoaded * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    EmitView v;
+    v.ref = h->ref; v.qbuf = h->qdev; v.matches = h->dMatches.p; v.matchCount = h->dMatchCount.p;
+    v.pos1 = (uint64_t) h->pos1; v.refLength = h->refLength(); v.maxRefLength = h->maxRefLength;
+    v.loaded = h->dELoaded.p; v.nLoaded = (uint32_t) nLoaded; v.p = *p;
+    v.em = h->dEM.p; v.next0 = h->dENext0.p; v.tflag = h->dETf.p; v.removed = h->dERm.p; v.keepIdx = h->dEKeep.p;
+    v.meta = h->dEMeta.p; v.corr = h->dECorr.p; v.sz = h->dESz.p; v.arena = h->dEArena.p; v.out = h->dEOut.p;
+    h->mark(SWSEM_K_EMIT, true);
+    k_emit_pass1<<<dim3(n), dim3(EMIT_THREADS), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
+    k_emit_meta<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_bytes<<<dim3(n), dim3(EMIT_THREADS), 0, h->stream>>>(v, h->dECg.p);
+    h->mark(SWSEM_K_EMIT, false);
+    HIPCHK(hipGetLastError());
+    h->eout.resize(n);
+    HIPCHK(hipMemcpyAsync(h->eout.data(), h->dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    uint64_t tot = 0;
+    h->hostStreamOff.assign((size_t) n * SWSEM_NSTREAMS, 0);
+    for (int k = 0; k < n; k++)
+        for (int st = 0; st < SWSEM_NSTREAMS; st++) { h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st] = tot; tot += h->eout[k].size[st]; }
+    h->hostStreams.resize(tot + 1);
+    for (int k = 0; k < n; k++)
+        for (int st = 0; st < SWSEM_NSTREAMS; st++)
+            if (h->eout[k].size[st])
+                HIPCHK(hipMemcpyAsync(h->hostStreams.data() + h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st],
+                                      h->dEArena.p + h->ecg[k].streamBase[st], h->eout[k].size[st], hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SWSEM_OK;
+}
+
+int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
+    if (k < 0 || k >= (int) h->eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
+    const EmitOut &o = h->eout[k];
+    for (int st = 0; st < SWSEM_NSTREAMS; st++) {
+        out->data[st] = h->hostStreams.data() + h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st];
+        out->size[st] = o.size[st];
+    }
+    out->unmatchedChars = o.unmatchedChars;
+    out->extensionsMatchedChars = o.extMatched;
+    out->extensionsMismatches = o.extMismatches;
+    out->totalMatched = o.totalMatched;
+    out->removedGapBreakingMatches = o.removed;
+    out->nmatches = o.nmatches;
+    return SWSEM_OK;
+}
+
+int swsem_emit(swsem_t *h, const swsem_emit_params_t *p, int contig, uint64_t lockPos, int factor, int64_t processed,
+               int64_t targetIdx, const uint64_t *loaded, uint64_t nLoaded, swsem_streams_t *out) {
+    int r = swsem_emit_batch(h, p, 1, &contig, &lockPos, &factor, &processed, &targetIdx, loaded, nLoaded);
+    if (r) return r;
+    return swsem_emit_result(h, 0, out);
 }
 
 }  // extern "C"

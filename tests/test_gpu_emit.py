@@ -1,0 +1,143 @@
+"""GPU parity of the stream emission (MBGC_Encoder::processMatches on the device) against the CPU
+oracle, driven through the same target loops (tests/_driver.py). Bit-exact on all six streams."""
+import numpy as np
+import pytest
+
+import _driver
+import _orc
+from mbgc_amd import synth
+
+pytestmark = pytest.mark.gpu
+NO_LOCK = _orc.NO_LOCK
+
+
+@pytest.fixture(scope="module")
+def binding():
+    from mbgc_amd import binding as b
+    assert b.lib().swsem_device_count() > 0
+    return b
+
+
+class HipEmitter:
+    """_driver emitter on top of swsem_emit: consumes the match rows the handle holds from the
+    preceding match call (they never leave HBM)."""
+
+    def __init__(self, binding, matcher, params=None):
+        self.b, self.m = binding, matcher
+        self.p = params if params is not None else binding.emit_params(1)
+        self.s = {k: b"" for k in binding.STREAM_NAMES}
+        self.counters = dict(extensionsMatchedChars=0, extensionsMismatches=0, totalMatched=0, removedGapBreakingMatches=0)
+
+    def process(self, m, contig, lock, factor, processed, target_idx, loaded):
+        un, streams, st = self.m.emit(self.p, 0, lock, factor, processed, target_idx, loaded)
+        if un != self.b.SKIPPED:
+            for k in self.s:
+                self.s[k] += streams[k]
+            for k in self.counters:
+                self.counters[k] += getattr(st, k)
+        return un
+
+    def put(self, which, data): self.s[self.b.STREAM_NAMES[which]] += bytes(data)
+    def streams(self): return dict(self.s)
+
+
+def small_collection(n, length, div=0.01, seed=7):
+    base = synth.base_codes(length, seed)
+    return [synth.genome(base, i, div) for i in range(n)]
+
+
+def compare(a, b):
+    for k in b:
+        assert a[k] == b[k], "%s differs (%d vs %d bytes)" % (k, len(a[k]), len(b[k]))
+
+
+@pytest.mark.parametrize("mode,lazy", [(1, True), (1, False), (0, True), (2, True)])
+def test_emission_sequential(binding, mode, lazy):
+    gs = small_collection(5, 150_000, 0.01, seed=11)
+    files = [[g[:70_000], g[70_000:]] for g in gs]
+    lim, _ = _driver.ref_length_limit(len(files), 150_000)
+    margin = 24 if mode >= 2 else 16
+    h = binding.SlidingWindowSparseEMMatcher(lim, skip_margin=margin)
+    o = _orc.OracleMatcher(lim, skip_margin=margin)
+    he = HipEmitter(binding, h, binding.emit_params(mode, lazyDecompressionSupport=int(lazy)))
+    oe = _orc.OracleEmitter(o, _orc.emit_params(mode, lazyDecompressionSupport=int(lazy)))
+    pol = _driver.Policy(mode)
+    a = _driver.encode_sequential(h, he, files, pol, lazy=lazy)
+    b = _driver.encode_sequential(o, oe, files, pol, lazy=lazy)
+    assert a["locks"] == b["locks"] and a["refExtSize"] == b["refExtSize"]
+    compare(he.streams(), oe.streams())
+    oc = oe.counters()
+    for k in he.counters:
+        assert he.counters[k] == oc[k], k
+    assert len(oe.streams()["flags"]) > 1000
+
+
+@pytest.mark.parametrize("round_size", [1, 3, 8])
+def test_emission_rounds_with_locks_and_wrap(binding, round_size):
+    gs = small_collection(17, 120_000, 0.015, seed=3)
+    g0 = [gs[0][:50_000], gs[0][50_000:]]
+    targets = [[g[:40_000], g[40_000:]] for g in gs[1:]]
+    lim = 900_000
+    h = binding.SlidingWindowSparseEMMatcher(lim)
+    o = _orc.OracleMatcher(lim)
+    a = _driver.encode_rounds(h, lambda: HipEmitter(binding, h), g0, targets, round_size)
+    b = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), g0, targets, round_size)
+    assert a["locks"] == b["locks"] and a["refExtSize"] == b["refExtSize"] and a["unmatched"] == b["unmatched"]
+    compare(a["streams"], b["streams"])
+    assert o.loaded_ref_length() > lim
+
+
+def test_emission_mixed_alphabet_and_edges(binding):
+    """lower case, N runs, IUPAC codes, a contig without matches, a tiny contig, an identical contig"""
+    rng = np.random.default_rng(8)
+    base = synth.ACGT[rng.integers(0, 4, 60_000)].copy()
+    base[1000:1400] = ord("N")
+    base[5000:5600] = np.frombuffer(b"acgtnRYKM" * 67, dtype=np.uint8)[:600]
+    def mut(x, rate, seed):
+        r = np.random.default_rng(seed)
+        y = x.copy()
+        idx = np.nonzero(r.random(x.size) < rate)[0]
+        y[idx] = synth.ACGT[r.integers(0, 4, idx.size)]
+        return y
+    files = [[base], [mut(base, 0.02, 1)], [synth.ACGT[rng.integers(0, 4, 9_000)]], [base[:40]], [base.copy()],
+             [mut(base, 0.3, 2)[:20_000], mut(base, 0.005, 3)]]
+    lim, _ = _driver.ref_length_limit(len(files), 60_000)
+    h = binding.SlidingWindowSparseEMMatcher(lim)
+    o = _orc.OracleMatcher(lim)
+    he, oe = HipEmitter(binding, h), _orc.OracleEmitter(o)
+    _driver.encode_sequential(h, he, files)
+    _driver.encode_sequential(o, oe, files)
+    compare(he.streams(), oe.streams())
+
+
+def test_emit_batch_matches_per_contig_calls(binding):
+    import torch
+    gs = small_collection(6, 100_000, 0.01, seed=13)
+    h = binding.SlidingWindowSparseEMMatcher(8_000_000)
+    o = _orc.OracleMatcher(8_000_000)
+    for m in (h, o):
+        m.set_sliding_window_size(16)
+        m.load_ref(gs[0], load_rc=True)
+    contigs = gs[1:]
+    offs = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([c.size for c in contigs])
+    buf = torch.from_numpy(np.concatenate(contigs)).to("cuda:0")
+    locks = [h.acquire_lock() for _ in contigs]
+    assert locks == [o.acquire_lock() for _ in contigs]
+    torch.cuda.synchronize()
+    h.match_batch_dev(buf.data_ptr(), offs, 32, locks)
+    loaded = [h.loading_position()]
+    p = binding.emit_params(1)
+    n = h.emit_batch(p, locks=locks, factors=[128] * len(contigs), processed=[0] * len(contigs),
+                     target_idx=list(range(len(contigs))), loaded=loaded)
+    assert n == len(contigs)
+    for i, c in enumerate(contigs):
+        oe = _orc.OracleEmitter(o)
+        m = o.match(c, 32, locks[i])
+        un = oe.process(m, c, locks[i], 128, 0, i, loaded)
+        got_un, streams, st = h.emit_result(i)
+        if un == _orc.SKIPPED:
+            assert got_un == binding.SKIPPED
+            continue
+        assert got_un == un
+        compare(streams, oe.streams())
