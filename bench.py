@@ -28,37 +28,48 @@ ALG_BYTES_PROBE = 1.0 + 4 * 0.29
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
 
 
-def cpu_baseline(sample_targets, length):
+def cpu_baseline(sample_targets, length, emit):
     """Time the CPU path on a bounded sample of the same workload (rank 0, N = 1): G0(+RC) preloaded,
-    then `sample_targets` targets matched and appended one after another on one core. Uses the
-    reference's own code (oracle/_ref, prebuilt) when it is loadable, else the C restatement."""
+    then `sample_targets` targets matched (matchTexts), emitted (processMatches) and appended (loadRef)
+    one after another on one core. Uses the reference's own code (oracle/_ref, prebuilt from
+    /root/reference) when it is loadable, else the C restatement."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from mbgc_amd import synth
-    kind = "port"
+    import _orc
+    kind, refh = "port", None
     try:
         import _refh
         if not _refh.available():
             raise OSError
         _refh.lib()
-        cls, kind = _refh.RefMatcher, "reference"
+        refh, kind = _refh, "reference"
     except Exception:
-        import _orc
-        cls = _orc.OracleMatcher
+        pass
     base = synth.base_codes(length)
-    m = cls(MAX_REF_LEN)
+    m = refh.RefMatcher(MAX_REF_LEN) if refh else _orc.OracleMatcher(MAX_REF_LEN)
     m.disable_sliding_window()
     m.load_ref(synth.genome(base, 0), load_rc=True)
+    em = None
+    if emit:
+        em = refh.RefEmitter(m, mode=1, lazy=True, n_targets=1) if refh else _orc.OracleEmitter(m)
+    loaded = [m.loading_position()]
     t = 0.0
     for i in range(1, sample_targets + 1):
         g = synth.genome(base, i)
         t0 = time.perf_counter()
-        m.match(g)
+        rows = m.match(g)
+        if em is not None:
+            if refh:
+                em.process(rows, g, 0, _orc.NO_LOCK)
+            else:
+                em.process(rows, g, _orc.NO_LOCK, 128, 0, 0, loaded)
         m.load_ref(g)
         t += time.perf_counter() - t0
     m.close()
+    what = "matchTexts + processMatches + loadRef" if emit else "matchTexts + loadRef"
     return dict(value=sample_targets * length / t / 1e9, unit="Gbases/s", cores=1, kind=kind,
-                sample="G0+RC preloaded, first %d of the 128 targets (%.0f Mbases), matchTexts + loadRef, 1 thread"
-                       % (sample_targets, sample_targets * length / 1e6))
+                sample="G0+RC preloaded, first %d of the 128 targets (%.0f Mbases), %s, 1 thread"
+                       % (sample_targets, sample_targets * length / 1e6, what))
 
 
 def main():
@@ -70,6 +81,7 @@ def main():
     ap.add_argument("--length", type=int, default=GENOME_LEN)
     ap.add_argument("--cpu-sample", type=int, default=24, help="targets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--check", action="store_true", help="compare the first step's matches with the oracle")
+    ap.add_argument("--no-emit", action="store_true", help="matcher only (no stream emission) inside the step")
     args = ap.parse_args()
 
     import torch
@@ -108,7 +120,10 @@ def main():
         bufs.append((torch.from_numpy(arr).to(dev), offs))
     torch.cuda.synchronize()
 
-    runner = RoundRunner(m, rank, world, None, dev)
+    emit = not args.no_emit
+    runner = RoundRunner(m, rank, world, None, dev, lazy=True, emit_params=binding.emit_params(1) if emit else None,
+                         keep_streams=False)
+    runner.start()
     tot_matches = 0
 
     def barrier():
@@ -118,9 +133,11 @@ def main():
         torch.cuda.synchronize()
 
     for s in range(warm):
-        c = runner.run_round(*bufs[s])
-        if args.check and s == 0 and rank == 0:
-            check_against_oracle(m, base, sched[0][0], c, args.length)
+        runner.keep_streams = bool(args.check and s == 0)
+        runner.run_round(*bufs[s])
+        if args.check and s == 0 and rank == 0 and world == 1:
+            check_against_oracle(runner, base, sched[0][0], args.length, emit)
+        runner.keep_streams = False
     m.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
@@ -138,17 +155,19 @@ def main():
     bases_step = R * world * args.length
     value = bases_step * steps / dt / 1e9
     if rank == 0:
-        dom = max(("probe", "extend", "resolve", "insert", "load"), key=lambda k: prof[k][0])
+        dom = max(("probe", "resolve", "stitch", "emit", "insert", "load"), key=lambda k: prof[k][0])
         per_launch_ms = {k: (prof[k][0] / prof[k][1] if prof[k][1] else 0.0) for k in prof}
         probe_ms = per_launch_ms["probe"]
         ach = ALG_BYTES_PROBE * R * args.length / (probe_ms * 1e-3) / 1e9 if probe_ms else 0.0
         out = {
-            "metric": "input Gbases/s (compress path, SlidingWindowSparseEMMatcher only)",
+            "metric": "input Gbases/s (compress hot path, -m1: match-finding + stream emission)" if emit else
+                      "input Gbases/s (compress path, SlidingWindowSparseEMMatcher only)",
             "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 128 synthetic 5 Mbp genomes @99%% identity, matcher only "
-                                   "(probe+verify, extend, resolve, loadRef+insert), round = %d targets/GPU" % R,
+            "config": {"workload": ("configs[1]: 128 synthetic 5 Mbp genomes @99%% identity, 1.28e9-byte reference; step = "
+                                    "matchTexts%s + loadRef of one round of %d targets/GPU") %
+                                   (" + processMatches (six streams, gathered to rank 0)" if emit else "", R),
                        "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": MAX_REF_LEN,
                        "hash_entries": m.hash_size(), "sharding": "file-per-GPU, all-gather of extensions"},
             "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
@@ -157,28 +176,39 @@ def main():
                          "whole_step_frac": round(ALG_BYTES_PER_BASE * value / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items()},
             "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof}, "dominant_kernel": dom,
-            "matches_per_step": tot_matches // steps,
+            "matches_per_step": tot_matches // steps, "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
         }
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def check_against_oracle(m, base, targets, counts, length):
+def check_against_oracle(runner, base, targets, length, emit):
+    """first round: the six streams (or, matcher only, the hash-table image) against the oracle driven
+    through the reference's target loop (tests/_driver.py)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _driver
     import _orc
     from mbgc_amd import synth
     o = _orc.OracleMatcher(MAX_REF_LEN)
-    o.set_sliding_window_size(16)
-    o.load_ref(synth.genome(base, 0), load_rc=True)
-    locks = [o.acquire_lock() for _ in targets]
-    for i, t in enumerate(targets):
-        exp = o.match(synth.genome(base, 1 + t), 32, locks[i])
-        got = m.batch_matches(i, counts[i])
-        assert np.array_equal(exp, got), "target %d differs from the oracle" % t
-    print("check: first round identical to the oracle (%d targets)" % len(targets), file=sys.stderr)
+    if emit:
+        res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [synth.genome(base, 0)],
+                                    [[synth.genome(base, 1 + t)] for t in targets], len(targets))
+        for k, v in res["streams"].items():
+            assert bytes(runner.streams[k]) == v, "stream %s differs from the oracle" % k
+        assert bytes(runner.locks_stream) == res["locks"]
+    else:
+        o.set_sliding_window_size(16)
+        o.load_ref(synth.genome(base, 0), load_rc=True)
+        locks = [o.acquire_lock() for _ in targets]
+        for t, lk in zip(targets, locks):
+            o.load_ref(synth.genome(base, 1 + t))
+            o.load_separator(0)
+            o.release_lock(lk)
+    assert np.array_equal(runner.m.ht(), o.ht()), "hash-table image differs from the oracle"
+    print("check: first round identical to the oracle (%d targets, streams + hash table)" % len(targets), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -70,6 +70,10 @@ uint32_t swsem_get_hash_size(const swsem_t *h);
 int swsem_load_ref(swsem_t *h, const uint8_t *text, uint64_t len, int loadRC, int addSep, int sep);
 int swsem_load_ref_dev(swsem_t *h, const uint8_t *text_dev, uint64_t len, int loadRC, int addSep, int sep);
 int swsem_load_separator(swsem_t *h, int sep);                    /* loadSeparator, .cpp:439-451 */
+/* PgHelpers::upperReverseComplement(src, n, dst) on device buffers, utils/helper.cpp:405-410 — what
+ * processTarget uses to append a contig's reverse complement to the target's extension string
+ * (MGMP.cpp:393-398) */
+int swsem_revcomp_dev(swsem_t *h, const uint8_t *src_dev, uint64_t n, uint8_t *dst_dev);
 
 /* matchTexts(resMatches, destText, destLen, false, false, minMatchLength, matchingLockPos), .cpp:478-492.
  * *matches points into a handle-owned buffer that stays valid until the next match call on the
@@ -129,6 +133,13 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
                      const int *unmatchedFractionFactor, const int64_t *processedTargetsCount, const int64_t *targetIdx,
                      const uint64_t *refExtLoadedPos, uint64_t nLoaded);
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out);
+/* Keep the streams in HBM (no host copy inside swsem_emit_batch; swsem_emit_result then copies on demand)
+ * and pack them, (result, stream) major, into one device buffer — the unit the multi-GPU path gathers to
+ * the rank that feeds the host-side PPMd/LZMA backend. sizes[n*6] and *total are host outputs; a NULL
+ * dst_dev only reports sizes. */
+void swsem_emit_set_host_copy(swsem_t *h, int on);
+int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched /* [n of the last swsem_emit_batch] */);
+int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total);
 
 /* ---- test / measurement hooks (not part of the reference surface) */
 int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out);      /* getRef() bytes, .h:104 */

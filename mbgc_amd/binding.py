@@ -20,8 +20,8 @@ EXPORTS = """swsem_last_error swsem_device_count swsem_create swsem_destroy swse
 swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circular_buffer swsem_get_ref_length
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
-swsem_load_separator swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
-swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_result swsem_debug_copy_ref swsem_debug_copy_ht
+swsem_load_separator swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
+swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats""".split()
 
 
@@ -87,6 +87,7 @@ def lib():
         L.swsem_load_ref.argtypes = [vp, vp, u64, ci, ci, ci]
         L.swsem_load_ref_dev.argtypes = [vp, vp, u64, ci, ci, ci]
         L.swsem_load_separator.argtypes = [vp, ci]
+        L.swsem_revcomp_dev.argtypes = [vp, vp, u64, vp]
         L.swsem_match.argtypes = [vp, vp, u64, C.c_uint32, u64, C.POINTER(vp), pu64]
         L.swsem_match_batch_dev.argtypes = [vp, vp, pu64, ci, C.c_uint32, pu64]
         L.swsem_batch_counts.argtypes = [vp, pu64]
@@ -98,6 +99,10 @@ def lib():
                                  C.POINTER(Streams)]
         L.swsem_emit_batch.argtypes = [vp, C.POINTER(EmitParams), ci, vp, vp, vp, vp, vp, vp, u64]
         L.swsem_emit_result.argtypes = [vp, ci, C.POINTER(Streams)]
+        L.swsem_emit_set_host_copy.argtypes = [vp, ci]
+        L.swsem_emit_set_host_copy.restype = None
+        L.swsem_emit_pack_dev.argtypes = [vp, vp, u64, pu64, pu64]
+        L.swsem_emit_unmatched.argtypes = [vp, pu64]
         L.swsem_debug_copy_ref.argtypes = [vp, u64, u64, vp]
         L.swsem_debug_copy_ht.argtypes = [vp, vp]
         L.swsem_profile_enable.argtypes = [vp, ci]
@@ -165,6 +170,7 @@ class SlidingWindowSparseEMMatcher:
         _chk(lib().swsem_load_ref_dev(self.h, dev_ptr, n, int(load_rc), int(add_sep), sep))
 
     def load_separator(self, sep=0): _chk(lib().swsem_load_separator(self.h, sep))
+    def revcomp_dev(self, src_ptr, n, dst_ptr): _chk(lib().swsem_revcomp_dev(self.h, src_ptr, n, dst_ptr))
 
     # --- matching
     def match(self, q, min_len=32, lock=NO_LOCK):
@@ -230,6 +236,24 @@ class SlidingWindowSparseEMMatcher:
         ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         _chk(lib().swsem_emit_batch(self.h, C.byref(params), cnt, ptr(ci), ptr(lk), ptr(fa), ptr(pr), ptr(ti), ptr(ld), ld.size))
         return cnt
+
+    def emit_set_host_copy(self, on): lib().swsem_emit_set_host_copy(self.h, int(on))
+
+    def emit_pack_sizes(self, n):
+        sizes = np.zeros(n * 6, dtype=np.uint64)
+        tot = C.c_uint64()
+        _chk(lib().swsem_emit_pack_dev(self.h, None, 0, sizes.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(tot)))
+        return sizes.reshape(n, 6), tot.value
+
+    def emit_pack_dev(self, dst_ptr, cap):
+        tot = C.c_uint64()
+        _chk(lib().swsem_emit_pack_dev(self.h, dst_ptr, cap, None, C.byref(tot)))
+        return tot.value
+
+    def emit_unmatched(self, n):
+        out = np.zeros(n, dtype=np.uint64)
+        _chk(lib().swsem_emit_unmatched(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
 
     def emit_result(self, k):
         st = Streams()

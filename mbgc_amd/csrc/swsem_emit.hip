@@ -5,13 +5,15 @@
 //   k_emit_pass1  gap-breaking removal (:153-199). "removed[j]" only depends on removed[j-1] and a
 //                 locally computable predicate, so it is resolved per run of that predicate; the kept
 //                 rows are compacted and unmatchedChars / totalMatched reduced.      [1024 threads/contig]
-//   k_emit_meta   the pairing ring, gap deltas and gap bookkeeping (:229-278) — a chain over matches
+//   k_emit_meta_* the pairing ring, gap deltas and gap bookkeeping (:229-278) — a chain over matches
 //                 that never looks at sequence bytes; the 64-deep look-ahead of one match is evaluated
-//                 by the 64 lanes of a wave at once.                                  [one wave/contig]
-//   k_emit_bytes  everything that touches bytes is local to the gap between two consecutive matches:
+//                 by the 64 lanes of a wave at once, blocks of matches run speculatively in parallel
+//                 and are stitched with the true state.                          [one wave/256 matches]
+//   k_emit_sizes / k_emit_place / k_emit_write
+//                 everything that touches bytes is local to the gap between two consecutive matches:
 //                 right extension of the left match, then left extension of the right match, then the
-//                 plain literals. One thread per gap sizes its output, a block scan places every
-//                 piece, the same automata run again and write.                    [1024 threads/contig]
+//                 plain literals. One thread per gap sizes its output, a block scan per contig places
+//                 every piece, the same automata run again and write.              [one thread/gap]
 #include "swsem_device.h"
 #include "../../include/mbgc_swsem.h"
 
@@ -57,6 +59,7 @@ struct EmitView {
     uint32_t *meta;                                  // per kept match, see META_*
     uint32_t *corr;                                  // gapStartIdx when in a gap
     uint32_t *sz;                                    // 6 u32 per gap task
+    uint32_t *ofs;                                   // 6 u32 per iteration: start offsets in the six streams
     uint8_t *arena;                                  // streams
     EmitOut *out;
 };
@@ -218,89 +221,179 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit_pass1(EmitView v, const E
 }
 
 // ------------------------------------------------------------------------------------------------
-// the pairing / gap chain, MBGC_Encoder.cpp:229-278 (no sequence bytes involved)
+// the pairing / gap chain, MBGC_Encoder.cpp:229-278 (no sequence bytes involved). The chain's state at
+// match j is small — which of the next 64 matches are already paired, the open gap, and the inherited
+// nextSrcRegionLoadingPos values of those 64 matches — and claims reach at most 64 matches ahead, so
+// chains started from an empty state fall into step with the true one after a short warm-up. Every
+// block of META_BLOCK matches is therefore replayed by its own wave after META_WARM warm-up matches
+// (speculation); k_emit_meta_stitch accepts a block when its state at the block start equals the true
+// state and replays it from the true state otherwise — identical results by construction.
 // ------------------------------------------------------------------------------------------------
-constexpr int META_CHUNK = 1024;
+constexpr int META_BLOCK = 256, META_WARM = 128, META_LDS = META_BLOCK + META_WARM + WAVE;
 
-__global__ void __launch_bounds__(WAVE) k_emit_meta(EmitView v, const EmitContig *__restrict__ cgs) {
-    __shared__ int64_t sdiag[META_CHUNK + WAVE];
-    __shared__ uint64_t ssrc[META_CHUNK + WAVE];
-    __shared__ uint64_t slp[META_CHUNK + WAVE];
-    __shared__ uint64_t snx0[META_CHUNK + WAVE];
-    __shared__ uint32_t slen[META_CHUNK + WAVE];
-    __shared__ uint64_t snext[128];                  // inherited nextSrcRegionLoadingPos, ring like pairedGap
-    const EmitContig cg = cgs[blockIdx.x];
-    const EmitOut o = v.out[blockIdx.x];
-    if (o.unmatchedChars == UINT64_MAX) return;
-    const int64_t n = (int64_t) o.nmatches;
+struct MetaState {
+    unsigned long long claimed;      // bit g-1: match j+g is already paired (the pairedGap ring)
+    int64_t gapStartIdx, gapEndIdx;
+    uint32_t curClaimed, pad;        // pairedGap[gapCurIdx]
+    uint64_t nx[WAVE + 1];           // inherited nextSrcRegionLoadingPos of matches j .. j+64
+};
+
+struct MetaLds {
+    int64_t sdiag[META_LDS];
+    uint64_t ssrc[META_LDS], slp[META_LDS], snx0[META_LDS];
+    uint32_t slen[META_LDS];
+    uint64_t snext[128];             // inherited nextSrcRegionLoadingPos, ring like pairedGap
+};
+
+struct MetaRun {
+    unsigned long long claimed;
+    bool curClaimed;
+    int64_t gapStartIdx, gapEndIdx;
+};
+
+__device__ __forceinline__ void meta_load(const EmitView &v, const EmitContig &cg, MetaLds &L, int64_t from, int64_t to, bool lazy) {
     const EMatch *E = v.em + cg.scratchBase;
+    for (int64_t t = from + threadIdx.x; t < to; t += WAVE) {
+        const EMatch e = E[t];
+        const int64_t k = t - from;
+        L.sdiag[k] = (int64_t) (e.posSrc - e.posDest);
+        L.ssrc[k] = e.posSrc;
+        L.slp[k] = e.lp;
+        L.slen[k] = (uint32_t) e.len;
+        L.snx0[k] = lazy ? v.next0[cg.scratchBase + t] : 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+}
+
+// matches [j0, j1) of the chain; LDS holds matches [base, ...) covering j1 + 64
+template <bool WRITE>
+__device__ void meta_run(const EmitView &v, const EmitContig &cg, MetaLds &L, MetaRun &st, int64_t base, int64_t j0, int64_t j1, int64_t n) {
     const uint32_t lane = threadIdx.x;
     const bool lazy = v.p.lazyDecompressionSupport != 0, ext = v.p.enableExtensionsWithMismatches != 0;
     const int depth = v.p.gapDepthOffsetEncoding;
-    unsigned long long claimed = 0;                  // bit g-1: match j+g is already paired (pairedGap ring)
-    bool curClaimed = false;                         // pairedGap[gapCurIdx]
-    int64_t gapStartIdx = -1, gapEndIdx = -1;
-    for (int i = lane; i < 128; i += WAVE) snext[i] = 0;
-    for (int64_t c0 = 0; c0 < n; c0 += META_CHUNK) {
-        const int64_t cn = n - c0 < META_CHUNK + WAVE ? n - c0 : META_CHUNK + WAVE;
-        __builtin_amdgcn_s_waitcnt(0);
-        for (int64_t t = lane; t < cn; t += WAVE) {
-            const EMatch e = E[c0 + t];
-            sdiag[t] = (int64_t) (e.posSrc - e.posDest);
-            ssrc[t] = e.posSrc;
-            slp[t] = e.lp;
-            slen[t] = (uint32_t) e.len;
-            snx0[t] = lazy ? v.next0[cg.scratchBase + c0 + t] : 0;
+    for (int64_t j = j0; j < j1; j++) {
+        const int64_t lj = j - base;
+        if (ext && j == st.gapEndIdx) { st.gapStartIdx = -1; st.gapEndIdx = -1; }        // :222-225
+        const bool skipOffset = st.curClaimed;                                           // :229
+        const uint64_t endj = (uint64_t) ((int64_t) L.ssrc[lj] - L.sdiag[lj]) + L.slen[lj];
+        const uint64_t litLeft = (j + 1 < n ? (uint64_t) ((int64_t) L.ssrc[lj + 1] - L.sdiag[lj + 1]) : cg.n) - (uint32_t) endj;   // :242
+        const int gCnt = (int) (n - j - 1 < depth ? n - j - 1 : depth);
+        const int g = (int) lane + 1;
+        const bool rule = !lazy && st.gapStartIdx == -1 && litLeft == 0;                  // :247, applies to g == 1
+        uint64_t nextj = L.snext[j & 127];
+        bool elig = false;
+        if (g <= gCnt) {
+            const bool taken = ((st.claimed >> lane) & 1ull) || (rule && g == 1);
+            const uint64_t sj = L.ssrc[lj], sg = L.ssrc[lj + g];
+            const bool pw = L.sdiag[lj] == L.sdiag[lj + g] &&
+                            ((sj > cg.lock && sg > cg.lock) || (sj < cg.lock && sg < cg.lock));   // TextMatchers.h:46-50
+            elig = !taken && pw;
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        const int64_t jend = c0 + META_CHUNK < n ? c0 + META_CHUNK : n;
-        for (int64_t j = c0; j < jend; j++) {
-            const int64_t lj = j - c0;
-            if (ext && j == gapEndIdx) { gapStartIdx = -1; gapEndIdx = -1; }        // :222-225
-            const bool skipOffset = curClaimed;                                     // :229
-            const uint64_t endj = (uint64_t) ((int64_t) ssrc[lj] - sdiag[lj]) + slen[lj];
-            const uint64_t litLeft = (j + 1 < n ? (uint64_t) ((int64_t) ssrc[lj + 1] - sdiag[lj + 1]) : cg.n) - (uint32_t) endj;   // :242 (uint32 pos)
-            const int gCnt = (int) (n - j - 1 < depth ? n - j - 1 : depth);
-            const int g = (int) lane + 1;
-            const bool rule = !lazy && gapStartIdx == -1 && litLeft == 0;            // :247, applies to g == 1
-            uint64_t nextj = snext[j & 127];
-            bool elig = false;
-            if (g <= gCnt) {
-                const bool taken = ((claimed >> lane) & 1ull) || (rule && g == 1);
-                const uint64_t sj = ssrc[lj], sg = ssrc[lj + g];
-                const bool pw = sdiag[lj] == sdiag[lj + g] &&
-                                ((sj > cg.lock && sg > cg.lock) || (sj < cg.lock && sg < cg.lock));   // TextMatchers.h:46-50
-                elig = !taken && pw;
-            }
-            const unsigned long long pm = __ballot(elig);
-            if (lazy && pm) {
-                if (!nextj) nextj = snx0[lj];                                        // :253-257
-                elig = elig && !(slp[lj + g] >= nextj);                              // :258-259
-            }
-            const unsigned long long em = lazy ? __ballot(elig) : pm;
-            uint32_t gapByte = 0;
-            int gf = 0;
-            if (em) {
-                gf = __builtin_ctzll(em) + 1;
-                const unsigned long long below = gf > 1 ? ((1ull << (gf - 1)) - 1) : 0ull;
-                const int reduce = __popcll((claimed | (rule ? 1ull : 0ull)) & below);
-                gapByte = (uint32_t) (gf - reduce);
-                claimed |= 1ull << (gf - 1);                                         // :262
-                if (lazy) snext[(j + gf) & 127] = nextj;                             // :260
-                if (ext && gapEndIdx <= j + gf && gf <= v.p.gapDepthMismatchesEncoding) { gapStartIdx = j; gapEndIdx = j + gf; }
-            }
-            snext[j & 127] = 0;
-            curClaimed = claimed & 1ull;                                             // :272-273: advance the ring
-            claimed >>= 1;
-            const bool gs = gapStartIdx == j, ge = gapEndIdx == j + 1, gm = gapStartIdx < j && j + 1 < gapEndIdx;
+        const unsigned long long pm = __ballot(elig);
+        if (lazy && pm) {
+            if (!nextj) nextj = L.snx0[lj];                                                 // :253-257
+            elig = elig && !(L.slp[lj + g] >= nextj);                                       // :258-259
+        }
+        const unsigned long long em = lazy ? __ballot(elig) : pm;
+        uint32_t gapByte = 0;
+        if (em) {
+            const int gf = __builtin_ctzll(em) + 1;
+            const unsigned long long below = gf > 1 ? ((1ull << (gf - 1)) - 1) : 0ull;
+            const int reduce = __popcll((st.claimed | (rule ? 1ull : 0ull)) & below);
+            gapByte = (uint32_t) (gf - reduce);
+            st.claimed |= 1ull << (gf - 1);                                                 // :262
+            if (lazy) L.snext[(j + gf) & 127] = nextj;                                      // :260
+            if (ext && st.gapEndIdx <= j + gf && gf <= v.p.gapDepthMismatchesEncoding) { st.gapStartIdx = j; st.gapEndIdx = j + gf; }
+        }
+        L.snext[j & 127] = 0;
+        st.curClaimed = st.claimed & 1ull;                                                  // :272-273: advance the ring
+        st.claimed >>= 1;
+        if (WRITE) {
+            const bool gs = st.gapStartIdx == j, ge = st.gapEndIdx == j + 1, gm = st.gapStartIdx < j && j + 1 < st.gapEndIdx;
             const bool isGap = gs || gm || ge;
             if (lane == 0) {
                 v.meta[cg.scratchBase + j] = (skipOffset ? META_SKIPOFF : 0) | (gCnt ? META_HASGAP : 0) | (isGap ? META_ISGAP : 0) |
                                              (gs ? META_GSTART : 0) | (gm ? META_GMID : 0) | (ge ? META_GEND : 0) | (gapByte << 8);
-                v.corr[cg.scratchBase + j] = isGap ? (uint32_t) gapStartIdx : (uint32_t) j;
+                v.corr[cg.scratchBase + j] = isGap ? (uint32_t) st.gapStartIdx : (uint32_t) j;
             }
         }
     }
+}
+
+__device__ __forceinline__ void meta_store_state(MetaState *dst, const MetaRun &st, const MetaLds &L, int64_t j) {
+    const uint32_t lane = threadIdx.x;
+    dst->nx[lane] = L.snext[(j + lane) & 127];
+    if (lane == 0) {
+        dst->nx[WAVE] = L.snext[(j + WAVE) & 127];
+        dst->claimed = st.claimed; dst->gapStartIdx = st.gapStartIdx; dst->gapEndIdx = st.gapEndIdx;
+        dst->curClaimed = st.curClaimed ? 1u : 0u; dst->pad = 0;
+    }
+}
+
+// blockIdx.x = block of META_BLOCK matches, blockIdx.y = contig
+__global__ void __launch_bounds__(WAVE) k_emit_meta_blocks(EmitView v, const EmitContig *__restrict__ cgs, MetaState *__restrict__ states,
+                                                           uint32_t maxBlocks) {
+    __shared__ MetaLds L;
+    const EmitContig cg = cgs[blockIdx.y];
+    const EmitOut o = v.out[blockIdx.y];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const int64_t n = (int64_t) o.nmatches;
+    const int64_t j0 = (int64_t) blockIdx.x * META_BLOCK;
+    if (j0 >= n) return;
+    const int64_t j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
+    const int64_t w = j0 >= META_WARM ? j0 - META_WARM : 0;
+    const bool lazy = v.p.lazyDecompressionSupport != 0;
+    for (int i = threadIdx.x; i < 128; i += WAVE) L.snext[i] = 0;
+    meta_load(v, cg, L, w, j1 + WAVE < n ? j1 + WAVE : n, lazy);
+    MetaRun st;
+    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1;
+    meta_run<false>(v, cg, L, st, w, w, j0, n);                     // warm-up, nothing written
+    MetaState *S = states + ((size_t) blockIdx.y * maxBlocks + blockIdx.x) * 2;
+    meta_store_state(S, st, L, j0);
+    meta_run<true>(v, cg, L, st, w, j0, j1, n);
+    meta_store_state(S + 1, st, L, j1);
+}
+
+__global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const EmitContig *__restrict__ cgs, const MetaState *__restrict__ states,
+                                                           uint32_t maxBlocks, unsigned long long *__restrict__ stats) {
+    __shared__ MetaLds L;
+    const EmitContig cg = cgs[blockIdx.x];
+    const EmitOut o = v.out[blockIdx.x];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const int64_t n = (int64_t) o.nmatches;
+    const uint32_t lane = threadIdx.x;
+    const bool lazy = v.p.lazyDecompressionSupport != 0;
+    const int64_t nb = (n + META_BLOCK - 1) / META_BLOCK;
+    MetaRun st;                                                      // true state at the start of block b
+    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1;
+    uint64_t tnx = 0, tnx64 = 0;                                     // true inherited values of matches j0+lane, j0+64
+    uint32_t replayed = 0;
+    for (int64_t b = 0; b < nb; b++) {
+        const int64_t j0 = b * META_BLOCK, j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
+        const MetaState *S = states + ((size_t) blockIdx.x * maxBlocks + b) * 2;
+        bool same = true;
+        if (b > 0) {
+            const bool d = S->nx[lane] != tnx || (lane == 0 && (S->nx[WAVE] != tnx64 || S->claimed != st.claimed ||
+                           S->gapStartIdx != st.gapStartIdx || S->gapEndIdx != st.gapEndIdx ||
+                           (S->curClaimed != 0) != st.curClaimed));
+            same = __ballot(d) == 0;
+        }
+        if (same) {
+            const MetaState *F = S + 1;
+            st.claimed = F->claimed; st.curClaimed = F->curClaimed != 0; st.gapStartIdx = F->gapStartIdx; st.gapEndIdx = F->gapEndIdx;
+            tnx = F->nx[lane]; tnx64 = F->nx[WAVE];
+        } else {
+            // replay the block from the true state
+            for (int i = lane; i < 128; i += WAVE) L.snext[i] = 0;
+            L.snext[(j0 + lane) & 127] = tnx;
+            if (lane == 0) L.snext[(j0 + WAVE) & 127] = tnx64;
+            meta_load(v, cg, L, j0, j1 + WAVE < n ? j1 + WAVE : n, lazy);
+            meta_run<true>(v, cg, L, st, j0, j0, j1, n);
+            tnx = L.snext[(j1 + lane) & 127]; tnx64 = L.snext[(j1 + WAVE) & 127];
+            replayed++;
+        }
+    }
+    if (lane == 0 && replayed) atomicAdd(&stats[6], (unsigned long long) replayed);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,33 +581,43 @@ __device__ GapSizes gap_sizes(const EmitView &v, const EmitContig &cg, const EMa
     return s;
 }
 
-__global__ void __launch_bounds__(EMIT_THREADS) k_emit_bytes(EmitView v, const EmitContig *__restrict__ cgs) {
+// sizes of every gap task. blockIdx.x = chunk of 256 tasks, blockIdx.y = contig
+__global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig *__restrict__ cgs) {
+    const EmitContig cg = cgs[blockIdx.y];
+    const EmitOut o = v.out[blockIdx.y];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const int64_t n = (int64_t) o.nmatches;
+    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    uint32_t cloc[2] = {0, 0};
+    if (t <= n) {
+        const GapSizes s = gap_sizes(v, cg, v.em + cg.scratchBase, n, t, v.qbuf + cg.qoff, cloc);
+        uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
+        z[0] = s.rLit; z[1] = s.rFl; z[2] = s.lLit; z[3] = s.lFl; z[4] = s.plain; z[5] = s.pos;
+    }
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        cloc[0] += (uint32_t) __shfl_down((int) cloc[0], d);
+        cloc[1] += (uint32_t) __shfl_down((int) cloc[1], d);
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && (cloc[0] | cloc[1])) {
+        atomicAdd((unsigned long long *) &v.out[blockIdx.y].extMatched, (unsigned long long) cloc[0]);
+        atomicAdd((unsigned long long *) &v.out[blockIdx.y].extMismatches, (unsigned long long) cloc[1]);
+    }
+}
+
+// placement. Iteration t of the reference's loop emits, in this order:
+//   literals: [left codes t][plain t] MATCH_MARK [right codes t]      flags: [left flags t][right flags t]
+// where "right codes t" are produced by gap task t+1. One workgroup per contig: per-thread contiguous
+// ranges of iterations, one block scan per stream, then the start offsets of every iteration.
+__global__ void __launch_bounds__(EMIT_THREADS) k_emit_place(EmitView v, const EmitContig *__restrict__ cgs) {
     __shared__ uint32_t lds[EMIT_THREADS / WAVE + 2];
-    __shared__ unsigned int cnt[2];
     const EmitContig cg = cgs[blockIdx.x];
     const EmitOut o = v.out[blockIdx.x];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
     const EMatch *E = v.em + cg.scratchBase;
-    const uint8_t *q = v.qbuf + cg.qoff;
-    uint32_t *SZ = v.sz + cg.scratchBase * 6;
+    const uint32_t *SZ = v.sz + cg.scratchBase * 6;
+    uint32_t *OFS = v.ofs + cg.scratchBase * 6;
     const bool bit40 = v.p.enable40bitReference != 0, frugal = v.p.frugal64bitLenEncoding != 0;
-    if (threadIdx.x == 0) { cnt[0] = 0; cnt[1] = 0; }
-    __syncthreads();
-    // ---- sizes
-    uint32_t cloc[2] = {0, 0};
-    for (int64_t t = threadIdx.x; t <= n; t += EMIT_THREADS) {
-        const GapSizes s = gap_sizes(v, cg, E, n, t, q, cloc);
-        uint32_t *z = SZ + t * 6;
-        z[0] = s.rLit; z[1] = s.rFl; z[2] = s.lLit; z[3] = s.lFl; z[4] = s.plain; z[5] = s.pos;
-    }
-    atomicAdd(&cnt[0], cloc[0]); atomicAdd(&cnt[1], cloc[1]);
-    __threadfence_block();
-    __syncthreads();
-    // ---- placement. Iteration t of the reference's loop emits, in this order:
-    //   literals: [left codes t][plain t] MATCH_MARK [right codes t]      flags: [left flags t][right flags t]
-    // where "right codes t" are produced by gap task t+1. Per-thread contiguous ranges of iterations,
-    // then one block scan per stream.
     const int64_t iters = n + 1;                                       // iteration n = contig tail (plain only)
     const int64_t per = (iters + EMIT_THREADS - 1) / EMIT_THREADS;
     const int64_t t0 = (int64_t) threadIdx.x * per, t1 = t0 + per < iters ? t0 + per : iters;
@@ -540,54 +643,68 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit_bytes(EmitView v, const E
     uint32_t o5 = block_scan(s5, lds, &t5);
     uint32_t on = block_scan(sn, lds, &tn);
     uint32_t og = block_scan(sg, lds, &tg);
-    uint8_t *LIT = v.arena + cg.streamBase[SWSEM_LIT], *FL = v.arena + cg.streamBase[SWSEM_FLAGS];
-    uint8_t *OFF = v.arena + cg.streamBase[SWSEM_OFF], *OF5 = v.arena + cg.streamBase[SWSEM_OFF5];
-    uint8_t *LEN = v.arena + cg.streamBase[SWSEM_LEN], *GAP = v.arena + cg.streamBase[SWSEM_GAP];
-    // ---- write: this thread's iterations in order; the extension codes are produced by re-running the
-    // two gap tasks that belong to an iteration (left codes: task t, right codes: task t+1)
-    uint32_t dummy[2];
     for (int64_t t = t0; t < t1; t++) {
+        uint32_t *w = OFS + t * 6;
+        w[0] = ol; w[1] = of; w[2] = oo; w[3] = o5; w[4] = on; w[5] = og;
         const uint32_t *z = SZ + t * 6;
-        uint8_t *lLit = LIT + ol, *lFl = FL + of;
-        uint8_t *plainDst = lLit + z[2];
+        ol += z[2] + z[4];
+        of += z[3];
         if (t < n) {
-            const uint32_t *zn = SZ + (t + 1) * 6;
-            uint8_t *rLit = plainDst + z[4] + 1, *rFl = lFl + z[3];
-            // left part (and plain literals) of iteration t
-            if (z[2] | z[3]) {
-                const EMatch m = E[t];
-                ext_left<true>(v, q, m.posDest - z[5], m, cg.lock, lLit, lFl);
-            }
-            for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
-            plainDst[z[4]] = MATCH_MARK;
-            // right part of iteration t = first half of gap task t+1
-            if (zn[0] | zn[1]) {
-                GapSizes tmp = {0, 0, 0, 0, 0, 0};
-                bool gb;
-                gap_right<true>(v, cg, E, n, t + 1, q, rLit, rFl, tmp, gb, dummy);
-            }
             const uint32_t meta = v.meta[cg.scratchBase + t];
-            if (!(meta & META_SKIPOFF)) {
-                put_bytes(OFF + oo, (uint32_t) E[t].posSrc, 4); oo += 4;
-                if (bit40) { OF5[o5] = (uint8_t) (E[t].posSrc >> 32); o5++; }
-            }
-            if (frugal) { frugal_write(LEN + on, E[t].len); on += frugal_size(E[t].len); }
-            else { put_bytes(LEN + on, (uint32_t) E[t].len, 4); on += 4; }
-            if (meta & META_HASGAP) { GAP[og] = (uint8_t) (meta >> 8); og++; }
-            ol += z[2] + z[4] + 1 + zn[0];
-            of += z[3] + zn[1];
-        } else {
-            for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
-            ol += z[4];
+            const uint32_t *zn = SZ + (t + 1) * 6;
+            ol += 1 + zn[0];
+            of += zn[1];
+            if (!(meta & META_SKIPOFF)) { oo += 4; o5 += bit40 ? 1 : 0; }
+            on += frugal ? frugal_size(E[t].len) : 4u;
+            og += (meta & META_HASGAP) ? 1u : 0u;
         }
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
         EmitOut *op = v.out + blockIdx.x;
         op->size[SWSEM_LIT] = tl; op->size[SWSEM_FLAGS] = tf_; op->size[SWSEM_OFF] = to; op->size[SWSEM_OFF5] = t5;
         op->size[SWSEM_LEN] = tn; op->size[SWSEM_GAP] = tg;
-        op->extMatched = cnt[0]; op->extMismatches = cnt[1];
     }
+}
+
+// write: one thread per iteration; the extension codes are produced by re-running the automata that
+// belong to the iteration (left codes: gap task t, right codes: first half of gap task t+1)
+__global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig *__restrict__ cgs) {
+    const EmitContig cg = cgs[blockIdx.y];
+    const EmitOut o = v.out[blockIdx.y];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const int64_t n = (int64_t) o.nmatches;
+    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (t > n) return;
+    const EMatch *E = v.em + cg.scratchBase;
+    const uint8_t *q = v.qbuf + cg.qoff;
+    const uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
+    const uint32_t *w = v.ofs + (cg.scratchBase + t) * 6;
+    const bool bit40 = v.p.enable40bitReference != 0, frugal = v.p.frugal64bitLenEncoding != 0;
+    uint8_t *lLit = v.arena + cg.streamBase[SWSEM_LIT] + w[0], *lFl = v.arena + cg.streamBase[SWSEM_FLAGS] + w[1];
+    uint8_t *plainDst = lLit + z[2];
+    for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
+    if (t == n) return;
+    const uint32_t *zn = z + 6;
+    uint8_t *rLit = plainDst + z[4] + 1, *rFl = lFl + z[3];
+    if (z[2] | z[3]) {
+        const EMatch m = E[t];
+        ext_left<true>(v, q, m.posDest - z[5], m, cg.lock, lLit, lFl);
+    }
+    plainDst[z[4]] = MATCH_MARK;
+    if (zn[0] | zn[1]) {
+        GapSizes tmp = {0, 0, 0, 0, 0, 0};
+        bool gb;
+        uint32_t dummy[2];
+        gap_right<true>(v, cg, E, n, t + 1, q, rLit, rFl, tmp, gb, dummy);
+    }
+    const uint32_t meta = v.meta[cg.scratchBase + t];
+    if (!(meta & META_SKIPOFF)) {
+        put_bytes(v.arena + cg.streamBase[SWSEM_OFF] + w[2], (uint32_t) E[t].posSrc, 4);
+        if (bit40) v.arena[cg.streamBase[SWSEM_OFF5] + w[3]] = (uint8_t) (E[t].posSrc >> 32);
+    }
+    if (frugal) frugal_write(v.arena + cg.streamBase[SWSEM_LEN] + w[4], E[t].len);
+    else put_bytes(v.arena + cg.streamBase[SWSEM_LEN] + w[4], (uint32_t) E[t].len, 4);
+    if (meta & META_HASGAP) v.arena[cg.streamBase[SWSEM_GAP] + w[5]] = (uint8_t) (meta >> 8);
 }
 
 }  // namespace swk

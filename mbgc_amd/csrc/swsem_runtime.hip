@@ -91,11 +91,13 @@ struct swsem {
     DevBuf<EMatch> dEM;
     DevBuf<uint64_t> dENext0, dELoaded;
     DevBuf<uint8_t> dETf, dERm, dEArena;
-    DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz;
+    DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs;
+    DevBuf<MetaState> dEStates;
     std::vector<EmitContig> ecg;
     std::vector<EmitOut> eout;
     std::vector<uint8_t> hostStreams;
     std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
+    bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 8;                       // probe tiles per resolve block (SWSEM_RB)
     std::vector<Contig> contigs;
@@ -400,7 +402,7 @@ void swsem_destroy(swsem_t *h) {
     h->dPrev.release(); h->dRbContig.release();
     h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
     h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
-    h->dESz.release();
+    h->dESz.release(); h->dEOfs.release(); h->dEStates.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -543,6 +545,20 @@ int swsem_match(swsem_t *h, const uint8_t *query, uint64_t len, uint32_t minLen,
     return SWSEM_OK;
 }
 
+// PgHelpers::upperReverseComplement on device buffers (utils/helper.cpp:405-410): lets the caller build a
+// target's extension string "contig + RC(contig)" (MGMP.cpp:389-398) without leaving HBM.
+int swsem_revcomp_dev(swsem_t *h, const uint8_t *src_dev, uint64_t n, uint8_t *dst_dev) {
+    HIPCHK(hipSetDevice(h->device));
+    if (n == 0) return SWSEM_OK;
+    const uint64_t thr = (n + 3) / 4;
+    const unsigned blocks = (unsigned) std::min<uint64_t>((thr + 255) / 256, 8192);
+    h->mark(SWSEM_K_LOAD, true);
+    k_load_rc<<<dim3(blocks), dim3(256), 0, h->stream>>>(src_dev, dst_dev, n, h->lut);
+    h->mark(SWSEM_K_LOAD, false);
+    HIPCHK(hipGetLastError());
+    return SWSEM_OK;
+}
+
 int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->ref + from, n, hipMemcpyDeviceToHost));
@@ -645,7 +661,7 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     if ((r = h->dECg.reserve(n)) || (r = h->dEOut.reserve(n)) || (r = h->dEWhich.reserve(n)) || (r = h->dEM.reserve(rows)) ||
         (r = h->dENext0.reserve(rows)) || (r = h->dETf.reserve(rows)) || (r = h->dERm.reserve(rows)) ||
         (r = h->dEKeep.reserve(rows)) || (r = h->dEMeta.reserve(rows)) || (r = h->dECorr.reserve(rows)) ||
-        (r = h->dESz.reserve(rows * 6)) || (r = h->dEArena.reserve(arena)) || (r = h->dELoaded.reserve(nLoaded + 1)))
+        (r = h->dESz.reserve(rows * 6)) || (r = h->dEOfs.reserve(rows * 6)) || (r = h->dEArena.reserve(arena)) || (r = h->dELoaded.reserve(nLoaded + 1)))
         return r;
     HIPCHK(hipMemcpyAsync(h->dECg.p, h->ecg.data(), n * sizeof(EmitContig), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dEWhich.p, which.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -657,10 +673,19 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     v.loaded = h->dELoaded.p; v.nLoaded = (uint32_t) nLoaded; v.p = *p;
     v.em = h->dEM.p; v.next0 = h->dENext0.p; v.tflag = h->dETf.p; v.removed = h->dERm.p; v.keepIdx = h->dEKeep.p;
     v.meta = h->dEMeta.p; v.corr = h->dECorr.p; v.sz = h->dESz.p; v.arena = h->dEArena.p; v.out = h->dEOut.p;
+    uint64_t maxRows = 0;
+    for (int k = 0; k < n; k++) maxRows = std::max<uint64_t>(maxRows, h->ecg[k].cap);
+    const uint32_t metaBlocks = (uint32_t) ((maxRows + META_BLOCK - 1) / META_BLOCK);
+    const uint32_t taskChunks = (uint32_t) ((maxRows + 255) / 256);
+    if ((r = h->dEStates.reserve((size_t) n * metaBlocks * 2))) return r;
+    v.ofs = h->dEOfs.p;
     h->mark(SWSEM_K_EMIT, true);
     k_emit_pass1<<<dim3(n), dim3(EMIT_THREADS), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
-    k_emit_meta<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_bytes<<<dim3(n), dim3(EMIT_THREADS), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_meta_blocks<<<dim3(metaBlocks, n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p, metaBlocks);
+    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p, metaBlocks, h->dStats.p);
+    k_emit_sizes<<<dim3(taskChunks, n), dim3(256), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_place<<<dim3(n), dim3(EMIT_THREADS), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_write<<<dim3(taskChunks, n), dim3(256), 0, h->stream>>>(v, h->dECg.p);
     h->mark(SWSEM_K_EMIT, false);
     HIPCHK(hipGetLastError());
     h->eout.resize(n);
@@ -671,6 +696,7 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     for (int k = 0; k < n; k++)
         for (int st = 0; st < SWSEM_NSTREAMS; st++) { h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st] = tot; tot += h->eout[k].size[st]; }
     h->hostStreams.resize(tot + 1);
+    if (!h->emitHostCopy) return SWSEM_OK;
     for (int k = 0; k < n; k++)
         for (int st = 0; st < SWSEM_NSTREAMS; st++)
             if (h->eout[k].size[st])
@@ -680,8 +706,41 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     return SWSEM_OK;
 }
 
+void swsem_emit_set_host_copy(swsem_t *h, int on) { h->emitHostCopy = on != 0; }
+
+// unmatchedChars (the return value of processMatches, SWSEM_SKIPPED when skipped) of every result
+int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched) {
+    for (size_t k = 0; k < h->eout.size(); k++) unmatched[k] = h->eout[k].unmatchedChars;
+    return SWSEM_OK;
+}
+
+// Packs every stream of the last emit batch back to back, (result, stream) major, into a device buffer.
+int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total) {
+    HIPCHK(hipSetDevice(h->device));
+    uint64_t tot = 0;
+    for (size_t k = 0; k < h->eout.size(); k++)
+        for (int st = 0; st < SWSEM_NSTREAMS; st++) {
+            const uint64_t sz = h->eout[k].size[st];
+            if (sizes) sizes[k * SWSEM_NSTREAMS + st] = sz;
+            if (dst_dev && sz) {
+                if (tot + sz > cap) return fail(SWSEM_EINVAL, "swsem_emit_pack_dev: buffer too small");
+                HIPCHK(hipMemcpyAsync(dst_dev + tot, h->dEArena.p + h->ecg[k].streamBase[st], sz, hipMemcpyDeviceToDevice, h->stream));
+            }
+            tot += sz;
+        }
+    if (total) *total = tot;
+    return SWSEM_OK;
+}
+
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
     if (k < 0 || k >= (int) h->eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
+    if (!h->emitHostCopy) {
+        for (int st = 0; st < SWSEM_NSTREAMS; st++)
+            if (h->eout[k].size[st])
+                HIPCHK(hipMemcpyAsync(h->hostStreams.data() + h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st],
+                                      h->dEArena.p + h->ecg[k].streamBase[st], h->eout[k].size[st], hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     const EmitOut &o = h->eout[k];
     for (int st = 0; st < SWSEM_NSTREAMS; st++) {
         out->data[st] = h->hostStreams.data() + h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st];

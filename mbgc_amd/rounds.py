@@ -1,26 +1,71 @@
-"""Deterministic round schedule of the match-finding path, single- and multi-GPU.
+"""Deterministic round schedule of the compress hot path, single- and multi-GPU.
 
 The reference's worker threads (MultipleGenomeMatchingProcessor::processTarget, MGMP.cpp:340-429)
 match several targets concurrently against one shared reference and a finalizer loads their
-extensions in target order (:433-468). Here a *round* makes that schedule explicit: the targets of a
-round take their lock positions at the same pos1, are matched against the frozen reference — shard
-`rank` of them on GPU `rank`, no collective — and then every replica loads every extension of the
-round, in target order, so all replicas stay bit-identical. The only exchange step is the all-gather
-of the extension bytes (RCCL over xGMI; gloo in the CPU tests).
+extensions in target order (:433-468). A *round* makes that schedule explicit: the targets of a round
+take their lock positions at the same pos1 (:353-358), are matched and emitted against the frozen
+reference — shard `rank` of them on GPU `rank`, no collective — and then every replica loads every
+extension of the round, in target order, so all replicas stay bit-identical. The exchange steps are
+the all-gather of the extension bytes and the gather of the emitted stream bytes to rank 0, which
+feeds the (unchanged, host-side) PPMd/LZMA backend: RCCL over xGMI on GPUs, gloo in the CPU tests.
 
-PyTorch is plumbing only: device buffers, the process group and the collective."""
+PyTorch is plumbing only: device buffers, the process group and the collectives."""
 import numpy as np
 import torch
 
 NO_LOCK = 2 ** 64 - 1
+SKIPPED = 2 ** 64 - 1
+SEQ_SEPARATOR = 0xA2        # MBGC_Params.h:46, appended to the literals after every contig (MBGC_Encoder.cpp:489-491)
+FILE_SEPARATOR = 0xBB       # MBGC_Params.h:47, appended to the flags after every target (:493-496)
+STREAMS = ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags")
+
+
+class Policy:
+    """Reference-extension predicates, matching/MGMP_Params.h:175-196, with the -m presets of
+    mbgccoder/MBGC_Params.h:886-922."""
+
+    def __init__(self, mode=1):
+        self.mode = mode
+        self.factor = 128                            # currentUnmatchedFractionFactor
+        self.rc_factor = 128 if mode >= 2 else 8     # unmatchedFractionRCFactor
+
+    def proper_for_ext(self, n, unmatched): return unmatched * self.factor > n
+    def proper_for_rc_ext(self, n, unmatched): return unmatched * self.rc_factor > n
+
+
+def frugal64(v):
+    """PgHelpers::writeUInt64Frugal, utils/helper.cpp:237-246."""
+    out = int(min(v, 0xFFFF)).to_bytes(2, "little")
+    if v >= 0xFFFF:
+        out += int(min(v, 0xFFFFFFFF)).to_bytes(4, "little")
+        if v >= 0xFFFFFFFF:
+            out += int(v).to_bytes(8, "little")
+    return out
 
 
 class RoundRunner:
-    def __init__(self, matcher, rank=0, world=1, group=None, device="cuda:0", lazy=True):
+    """matcher: mbgc_amd.binding.SlidingWindowSparseEMMatcher (or any object with the same surface)."""
+
+    def __init__(self, matcher, rank=0, world=1, group=None, device="cuda:0", lazy=True, emit_params=None,
+                 policy=None, keep_streams=True):
         self.m, self.rank, self.world, self.group = matcher, rank, world, group
         self.device = torch.device(device)
         self.lazy = lazy
-        self.targets_done = 0
+        self.p = emit_params                         # None: matcher only, every contig extends the reference
+        self.policy = policy or Policy()
+        self.keep_streams = keep_streams
+        self.targets_done = 0                        # processedTargetsCount
+        self.loaded = None                           # refExtLoadedPosArr, MBGC_Encoder.cpp:789-791
+        self.streams = {k: bytearray() for k in STREAMS}     # merged in target order on rank 0 (:542-556)
+        self.locks_stream = bytearray()              # :563
+        self.ref_ext_sizes = bytearray()             # :559-560
+        self.stream_bytes = 0
+        if self.p is not None:
+            matcher.emit_set_host_copy(False)
+
+    def start(self):
+        """call after G0 has been loaded (encode(), MBGC_Encoder.cpp:789-791)"""
+        self.loaded = [self.m.loading_position()]
 
     # ---- exchange -----------------------------------------------------------------------------
     def _allgather_bytes(self, local):
@@ -32,62 +77,205 @@ class RoundRunner:
         sizes = [torch.zeros_like(n) for _ in range(self.world)]
         dist.all_gather(sizes, n, group=self.group)
         sizes = [int(s.item()) for s in sizes]
-        mx = max(sizes)
+        mx = max(max(sizes), 1)
         pad = torch.zeros(mx, dtype=torch.uint8, device=self.device)
         pad[: local.numel()] = local
         out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
         dist.all_gather_into_tensor(out, pad, group=self.group)
         return [out[r * mx: r * mx + sizes[r]] for r in range(self.world)]
 
-    # ---- one round ----------------------------------------------------------------------------
-    def run_round(self, qbuf, offsets, ext_of=None, min_len=32):
-        """qbuf: uint8 device tensor with this rank's contigs back to back (one target = one entry of
-        `offsets`; a multi-contig target is passed as consecutive entries by the caller through
-        `ext_of`). Every rank must pass the same number of targets. Returns this rank's match counts.
+    def _allgather_ints(self, vals):
+        t = torch.tensor(list(vals), dtype=torch.int64, device=self.device)
+        parts = self._allgather_bytes(t.view(torch.uint8))
+        return [p.view(torch.int64).tolist() for p in parts]
 
-        ext_of(rank_local_index, counts) -> (start, end) byte range of qbuf to append to the reference
-        for that target, or None; default: the whole contig (the 99 %-identity regime, where every
-        contig passes isContigProperForRefExtension, MGMP_Params.h:179-186)."""
+    # ---- one round ----------------------------------------------------------------------------
+    def run_round(self, qbuf, offsets, targets=None, min_len=32):
+        """qbuf: uint8 device tensor holding this rank's contigs of the round back to back, contig c at
+        [offsets[c], offsets[c+1]). targets[c] = index (0..T-1) of the local target contig c belongs to
+        (default: one contig per target). Every rank passes the same number of targets T; globally the
+        round's targets are ordered rank-major. Returns this rank's match counts per contig."""
         m = self.m
-        nloc = len(offsets) - 1
-        ntot = nloc * self.world
-        # lock positions: all targets of the round are acquired at the same pos1 (MGMP.cpp:353-358)
-        locks = [m.acquire_lock() for _ in range(ntot)]
-        mine = [locks[self.rank * nloc + i] for i in range(nloc)]
-        m.match_batch_dev(qbuf.data_ptr(), offsets, min_len, mine)
-        counts = m.batch_counts()
-        # extensions of this rank, then the exchange
-        spans = []
-        for i in range(nloc):
-            sp = (int(offsets[i]), int(offsets[i + 1])) if ext_of is None else ext_of(i, counts)
-            spans.append(sp)
-        if self.world == 1:
-            for i, sp in enumerate(spans):
-                self._finalize(qbuf, sp, locks[i])
-        else:
-            parts = [qbuf[s:e] for (s, e) in [sp for sp in spans if sp is not None]]
-            local = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=self.device)
-            lens = torch.tensor([0 if sp is None else sp[1] - sp[0] for sp in spans], dtype=torch.int64, device=self.device)
-            all_ext = self._allgather_bytes(local)
-            all_lens = self._allgather_bytes(lens.view(torch.uint8))
-            for r in range(self.world):                       # target order = rank-major inside the round
-                ln = all_lens[r].view(torch.int64).tolist()
-                pos = 0
-                for i in range(nloc):
-                    sp = None if ln[i] == 0 else (pos, pos + ln[i])
-                    self._finalize(all_ext[r], sp, locks[r * nloc + i])
-                    pos += ln[i]
+        ncont = len(offsets) - 1
+        targets = list(range(ncont)) if targets is None else list(targets)
+        T = max(targets) + 1 if targets else 0
+        ntot = T * self.world
+        first = self.targets_done                   # global index of the round's first target
+        locks = [m.acquire_lock() for _ in range(ntot)]                     # MGMP.cpp:353-358
+        lock_of = [locks[self.rank * T + targets[c]] for c in range(ncont)]
+        pending = list(range(ncont))                # contigs still to be matched + emitted
+        counts = np.zeros(ncont, dtype=np.uint64)
+        unmatched = [None] * ncont
+        packs = []                                  # (contig ids, sizes, device tensor) of accepted emissions
+        finalized = 0                               # targets of the round already loaded into the reference
+        ext_done = {}
+        while True:
+            if pending:
+                cnt = self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
+                                  [lock_of[c] for c in pending], min_len)
+                for k, c in enumerate(pending):
+                    counts[c] = cnt[k]
+                if self.p is not None:
+                    tgt = [first + self.rank * T + targets[c] for c in pending]
+                    m.emit_batch(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
+                                 [self.targets_done + finalized] * len(pending), tgt, self.loaded, n=len(pending))
+                    un = m.emit_unmatched(len(pending))
+                else:
+                    un = [int(offsets[c + 1] - offsets[c]) for c in pending]     # matcher only: always extend
+                skipped_local = [c for k, c in enumerate(pending) if int(un[k]) == SKIPPED]
+                good = [(k, c) for k, c in enumerate(pending) if int(un[k]) != SKIPPED]
+                for k, c in good:
+                    unmatched[c] = int(un[k])
+                if self.p is not None and good:
+                    packs.append(self._pack([k for k, _ in good], [c for _, c in good], len(pending)))
+            else:
+                skipped_local = []
+            # the first target (global order) holding a dissimilar contig cuts the round (MGMP.cpp:382-388:
+            # "discard, wait until the earlier targets are loaded, retry")
+            first_skip_local = min([self.rank * T + targets[c] for c in skipped_local], default=ntot)
+            first_skip = min(x[0] for x in self._allgather_ints([first_skip_local])) if self.world > 1 else first_skip_local
+            upto = first_skip                       # targets [finalized, upto) are complete on every rank
+            # everything the sequential schedule would do AFTER the skipping contig is redone against the
+            # extended reference: the rest of that target and all later targets of the round
+            cut = min([c for c in skipped_local if self.rank * T + targets[c] == first_skip], default=ncont)
+            redo = [c for c in range(ncont) if self.rank * T + targets[c] > first_skip or
+                    (self.rank * T + targets[c] == first_skip and c >= cut)]
+            self._finalize_range(qbuf, offsets, targets, T, locks, unmatched, finalized, upto, ext_done)
+            finalized = upto
+            if finalized >= ntot:
+                break
+            # retry: the skipping contig itself, and every contig of the targets after it
+            pending = sorted(redo)
+            for c in pending:
+                unmatched[c] = None
+            packs = [self._drop(pk, pending) for pk in packs]
+        if self.p is not None:
+            self._collect_streams(packs, targets, T, offsets)
         self.targets_done += ntot
         return counts
 
-    def _finalize(self, buf, span, lock):
-        """finalizeParallelProcessingOfTarget for one target (MGMP.cpp:440-457, MBGC_Encoder.cpp:557-562)."""
+    def _match(self, qbuf, spans, locks, min_len):
+        """match contigs given as byte spans of qbuf. match_batch_dev takes offsets of back-to-back
+        contigs; arbitrary spans are expressed relative to the lowest start."""
+        contiguous = all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        if contiguous:
+            base = spans[0][0]
+            offs = np.array([s - base for s, _ in spans] + [spans[-1][1] - base], dtype=np.uint64)
+            self.m.match_batch_dev(qbuf.data_ptr() + base, offs, min_len, locks)
+        else:
+            parts = [qbuf[s:e] for s, e in spans]
+            self._tmp = torch.cat(parts)
+            offs = np.zeros(len(spans) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([e - s for s, e in spans])
+            self.m.match_batch_dev(self._tmp.data_ptr(), offs, min_len, locks)
+        return self.m.batch_counts()
+
+    def _pack(self, ks, cs, n_emitted):
+        sizes, total = self.m.emit_pack_sizes(n_emitted)
+        buf = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        self.m.emit_pack_dev(buf.data_ptr(), buf.numel())
+        starts = np.zeros(n_emitted * 6 + 1, dtype=np.int64)
+        starts[1:] = np.cumsum(sizes.reshape(-1))
+        return dict(cs=cs, ks=ks, sizes=sizes, starts=starts, buf=buf)
+
+    @staticmethod
+    def _drop(pk, redo):
+        keep = [i for i, c in enumerate(pk["cs"]) if c not in redo]
+        pk["cs"] = [pk["cs"][i] for i in keep]
+        pk["ks"] = [pk["ks"][i] for i in keep]
+        return pk
+
+    def _finalize_range(self, qbuf, offsets, targets, T, locks, unmatched, lo, hi, ext_done):
+        """finalizeParallelProcessingOfTarget for the round's targets [lo, hi) in order (MGMP.cpp:433-468)."""
+        if hi <= lo:
+            return
         m = self.m
-        if span is not None and span[1] > span[0]:
-            m.load_ref_dev(buf.data_ptr() + span[0], span[1] - span[0], False, True, 0)
-        if self.lazy:
+        # extension string of every local target in range: contig, then its reverse complement (:389-398)
+        my = [t for t in range(lo, hi) if t // T == self.rank] if self.world > 1 else list(range(lo, hi))
+        pieces, lens = [], []
+        for t in my:
+            lt = t - self.rank * T
+            parts = []
+            for c in range(len(targets)):
+                if targets[c] != lt:
+                    continue
+                s, e = int(offsets[c]), int(offsets[c + 1])
+                n, un = e - s, unmatched[c]
+                if self.policy.proper_for_ext(n, un):
+                    parts.append(qbuf[s:e])
+                if self.p is not None and self.policy.proper_for_rc_ext(n, un):
+                    rc = torch.empty(n, dtype=torch.uint8, device=self.device)
+                    m.revcomp_dev(qbuf.data_ptr() + s, n, rc.data_ptr())
+                    parts.append(rc)
+            ext = torch.cat(parts) if len(parts) > 1 else (parts[0] if parts else qbuf[0:0])
+            pieces.append(ext)
+            lens.append(ext.numel())
+        if self.world == 1:
+            for t, ext in zip(my, pieces):
+                self._finalize_one(ext, locks[t])
+            return
+        local = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=self.device)
+        all_ext = self._allgather_bytes(local)
+        all_lens = self._allgather_ints(lens + [-1])           # -1 terminator keeps the tensor non-empty
+        cur = [0] * self.world
+        idx = [0] * self.world
+        for t in range(lo, hi):                                # global target order = rank-major in the round
+            r = t // T
+            ln = all_lens[r][idx[r]]
+            self._finalize_one(all_ext[r][cur[r]: cur[r] + ln], locks[t])
+            cur[r] += ln
+            idx[r] += 1
+
+    def _finalize_one(self, ext, lock):
+        m = self.m
+        start = m.loaded_ref_length()
+        if ext.numel():
+            m.load_ref_dev(ext.data_ptr(), ext.numel(), False, True, 0)                 # :441-443
+        if self.lazy:                                                                    # MBGC_Encoder.cpp:557-562
             m.load_separator(0)
-        m.release_lock(lock)
+            self.ref_ext_sizes += frugal64(m.loaded_ref_length() - start)
+            if self.loaded is not None:
+                self.loaded.append(m.loaded_ref_length())
+        self.locks_stream += int(lock).to_bytes(8, "little")                            # :563
+        m.release_lock(lock)                                                             # MGMP.cpp:456
+
+    def _collect_streams(self, packs, targets, T, offsets):
+        """per-target stream merge in target order on rank 0 (MBGC_Encoder.cpp:542-556)."""
+        # order this rank's emitted contigs by contig index, pack their six streams into one tensor
+        items = []
+        for pk in packs:
+            for k, c in zip(pk["ks"], pk["cs"]):
+                items.append((c, pk, k))
+        items.sort(key=lambda x: x[0])
+        chunks, meta = [], []
+        for c, pk, k in items:
+            s0, s1 = int(pk["starts"][k * 6]), int(pk["starts"][k * 6 + 6])
+            chunks.append(pk["buf"][s0:s1])
+            meta.extend([c] + [int(x) for x in pk["sizes"][k]])
+        local = torch.cat(chunks) if chunks else torch.empty(0, dtype=torch.uint8, device=self.device)
+        all_bytes = self._allgather_bytes(local) if self.world > 1 else [local]
+        all_meta = self._allgather_ints(meta + [-1]) if self.world > 1 else [meta + [-1]]
+        self.stream_bytes += sum(int(b.numel()) for b in all_bytes)
+        if self.rank != 0 or not self.keep_streams:
+            return
+        for r in range(self.world):
+            host = all_bytes[r].cpu().numpy().tobytes()
+            mt = all_meta[r][:-1]
+            pos = 0
+            per_target = {}
+            for i in range(0, len(mt), 7):
+                c, sizes = mt[i], mt[i + 1: i + 7]
+                st = {}
+                for name, sz in zip(STREAMS, sizes):
+                    st[name] = host[pos: pos + sz]
+                    pos += sz
+                per_target.setdefault(targets[c], []).append(st)
+            for lt in range(T):
+                for st in per_target.get(lt, []):
+                    for name in STREAMS:
+                        self.streams[name] += st[name]
+                    self.streams["literals"].append(SEQ_SEPARATOR)
+                self.streams["flags"].append(FILE_SEPARATOR)
 
 
 def round_schedule(n_targets, per_rank, world):

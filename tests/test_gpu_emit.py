@@ -141,3 +141,34 @@ def test_emit_batch_matches_per_contig_calls(binding):
             continue
         assert got_un == un
         compare(streams, oe.streams())
+
+
+def test_round_runner_equals_driver_rounds(binding):
+    """mbgc_amd.rounds.RoundRunner (the product's round protocol, device-resident) against the reference
+    loop restated in tests/_driver.py driven on the oracle: same streams, lock and refExtSize bytes."""
+    import torch
+    from mbgc_amd.rounds import RoundRunner
+    gs = small_collection(13, 90_000, 0.012, seed=5)
+    lim = 3_000_000
+    h = binding.SlidingWindowSparseEMMatcher(lim)
+    o = _orc.OracleMatcher(lim)
+    R = 4
+    # oracle side
+    b = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], R)
+    # device side
+    h.set_sliding_window_size(16)
+    h.load_ref(gs[0], load_rc=True)
+    runner = RoundRunner(h, 0, 1, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1))
+    runner.start()
+    for r0 in range(1, len(gs), R):
+        chunk = gs[r0:r0 + R]
+        buf = torch.from_numpy(np.concatenate(chunk)).to("cuda:0")
+        offs = np.zeros(len(chunk) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([c.size for c in chunk])
+        torch.cuda.synchronize()
+        runner.run_round(buf, offs)
+    for k in b["streams"]:
+        assert bytes(runner.streams[k]) == b["streams"][k], k
+    assert bytes(runner.locks_stream) == b["locks"] and bytes(runner.ref_ext_sizes) == b["refExtSize"]
+    assert h.loaded_ref_length() == o.loaded_ref_length()
+    assert np.array_equal(h.ht(), o.ht())
