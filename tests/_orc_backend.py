@@ -1,0 +1,77 @@
+"""The CPU oracle behind the *device* surface of mbgc_amd.binding.SlidingWindowSparseEMMatcher
+(match_batch_dev / emit_batch / emit_pack_dev / load_ref_dev / revcomp_dev on raw pointers), so the
+round protocol (mbgc_amd.rounds) can be exercised without a GPU: world_size-2 gloo tests run it on
+CPU tensors. Test infrastructure only."""
+import ctypes as C
+
+import numpy as np
+
+import _driver
+import _orc
+
+
+def _view(ptr, n):
+    if n == 0:
+        return np.zeros(0, dtype=np.uint8)
+    return np.ctypeslib.as_array(C.cast(int(ptr), C.POINTER(C.c_uint8)), shape=(int(n),))
+
+
+class OracleDeviceMatcher:
+    def __init__(self, max_ref_len, **kw):
+        self.o = _orc.OracleMatcher(max_ref_len, **kw)
+        self._contigs, self._locks, self._matches, self._em = [], [], [], []
+
+    # pass-through state API
+    def __getattr__(self, name):
+        return getattr(self.o, name)
+
+    def load_ref_dev(self, ptr, n, load_rc=False, add_sep=True, sep=0):
+        self.o.load_ref(_view(ptr, n).copy(), load_rc, add_sep, sep)
+
+    def revcomp_dev(self, src, n, dst):
+        _view(dst, n)[:] = _driver.revcomp(_view(src, n))
+
+    def match_batch_dev(self, ptr, offsets, min_len=32, locks=None):
+        offs = [int(x) for x in offsets]
+        n = len(offs) - 1
+        self._contigs = [_view(ptr + offs[i], offs[i + 1] - offs[i]).copy() for i in range(n)]
+        self._locks = [int(x) for x in locks] if locks is not None else [_orc.NO_LOCK] * n
+        self._matches = [self.o.match(c, min_len, lk) for c, lk in zip(self._contigs, self._locks)]
+
+    def batch_counts(self):
+        return np.array([len(m) for m in self._matches], dtype=np.uint64)
+
+    def batch_matches(self, i, count):
+        return self._matches[i][: int(count)]
+
+    def emit_set_host_copy(self, on):
+        pass
+
+    def emit_batch(self, params, contigs=None, locks=None, factors=None, processed=None, target_idx=None, loaded=None, n=None):
+        n = n if n is not None else len(self._contigs)
+        self._em = []
+        for k in range(n):
+            c = k if contigs is None else int(contigs[k])
+            em = _orc.OracleEmitter(self.o, params)
+            un = em.process(self._matches[c], self._contigs[c], int(locks[k]) if locks is not None else _orc.NO_LOCK,
+                            int(factors[k]) if factors is not None else 128, int(processed[k]) if processed is not None else 0,
+                            int(target_idx[k]) if target_idx is not None else 0, loaded)
+            self._em.append((un, em))
+        return n
+
+    def emit_unmatched(self, n):
+        return np.array([u for u, _ in self._em[:n]], dtype=np.uint64)
+
+    def emit_pack_sizes(self, n):
+        sizes = np.zeros((n, 6), dtype=np.uint64)
+        for k, (un, em) in enumerate(self._em[:n]):
+            if un != _orc.SKIPPED:
+                sizes[k] = [len(em.stream(i)) for i in range(6)]
+        return sizes, int(sizes.sum())
+
+    def emit_pack_dev(self, dst, cap):
+        blob = b"".join(em.stream(i) for un, em in self._em if un != _orc.SKIPPED for i in range(6))
+        assert len(blob) <= cap
+        if blob:
+            _view(dst, len(blob))[:] = np.frombuffer(blob, dtype=np.uint8)
+        return len(blob)

@@ -1,0 +1,100 @@
+"""The round protocol (mbgc_amd.rounds.RoundRunner) on CPU: single process and world_size-2 gloo, with
+the oracle behind the device surface. Checks the host logic the GPUs run under: lock positions,
+extension policy (incl. reverse-complement extensions), the dissimilar-contig retry, the exchange of
+extensions, replica consistency and the target-order merge of the streams on rank 0."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import _driver
+import _orc
+import _orc_backend
+from mbgc_amd import synth
+from mbgc_amd.rounds import RoundRunner, round_schedule
+
+LIM = 3_000_000
+
+
+def collection(n, length, div, seed):
+    base = synth.base_codes(length, seed)
+    return [synth.genome(base, i, div) for i in range(n)]
+
+
+def reference_result(gs, round_size, contigs_per_target=1):
+    o = _orc.OracleMatcher(LIM)
+    targets = [split(g, contigs_per_target) for g in gs[1:]]
+    res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], targets, round_size)
+    return res, o.ht(), o.loaded_ref_length()
+
+
+def split(g, k):
+    cuts = [0] + [g.size * i // k + (7 * i) % 13 for i in range(1, k)] + [g.size]
+    return [g[cuts[i]:cuts[i + 1]] for i in range(k)]
+
+
+def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None):
+    m = _orc_backend.OracleDeviceMatcher(LIM)
+    m.set_sliding_window_size(16)
+    m.load_ref(gs[0], load_rc=True)
+    runner = RoundRunner(m, rank, world, group, "cpu", lazy=True, emit_params=_orc.emit_params(1))
+    runner.start()
+    for rnd in round_schedule(len(gs) - 1, per_rank, world):
+        mine = rnd[rank]
+        contigs, tg = [], []
+        for lt, t in enumerate(mine):
+            for c in split(gs[1 + t], contigs_per_target):
+                contigs.append(c)
+                tg.append(lt)
+        buf = torch.from_numpy(np.concatenate(contigs).copy())
+        offs = np.zeros(len(contigs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([c.size for c in contigs])
+        runner.run_round(buf, offs, tg)
+    return runner, m
+
+
+@pytest.mark.parametrize("div,cpt", [(0.012, 1), (0.012, 3), (0.06, 2)])
+def test_single_process_runner_equals_reference_loop(div, cpt):
+    gs = collection(9, 60_000, div, seed=17)      # 6 % divergence forces dissimilar-contig retries
+    runner, m = run_rank(0, 1, gs, 4, cpt)
+    res, ht, loaded = reference_result(gs, 4, cpt)
+    for k, v in res["streams"].items():
+        assert bytes(runner.streams[k]) == v, k
+    assert bytes(runner.locks_stream) == res["locks"]
+    assert bytes(runner.ref_ext_sizes) == res["refExtSize"]
+    assert m.loaded_ref_length() == loaded and np.array_equal(m.ht(), ht)
+
+
+def _worker(rank, world, port, outdir, div, cpt):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    gs = collection(9, 60_000, div, seed=17)
+    runner, m = run_rank(rank, world, gs, 2, cpt)
+    np.save(os.path.join(outdir, "ht%d.npy" % rank), m.ht())
+    if rank == 0:
+        for k, v in runner.streams.items():
+            open(os.path.join(outdir, k), "wb").write(bytes(v))
+        open(os.path.join(outdir, "locks"), "wb").write(bytes(runner.locks_stream))
+        open(os.path.join(outdir, "refext"), "wb").write(bytes(runner.ref_ext_sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("div,cpt", [(0.012, 1), (0.06, 2)])
+def test_world_size_2_gloo(tmp_path, div, cpt):
+    """2 ranks x 2 targets per round == one process with rounds of 4; replicas bit-identical"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), div, cpt), nprocs=2, join=True)
+    gs = collection(9, 60_000, div, seed=17)
+    res, ht, _ = reference_result(gs, 4, cpt)
+    for k, v in res["streams"].items():
+        assert (tmp_path / k).read_bytes() == v, k
+    assert (tmp_path / "locks").read_bytes() == res["locks"]
+    assert (tmp_path / "refext").read_bytes() == res["refExtSize"]
+    h0, h1 = np.load(tmp_path / "ht0.npy"), np.load(tmp_path / "ht1.npy")
+    assert np.array_equal(h0, ht) and np.array_equal(h1, ht)
