@@ -141,6 +141,12 @@ void swsem_emit_set_host_copy(swsem_t *h, int on);
 int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched /* [n of the last swsem_emit_batch] */);
 int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total);
 
+/* ---- device-memory plumbing for host code that stays free of HIP headers (the C++ facade) */
+int swsem_dev_malloc(swsem_t *h, uint64_t bytes, void **out_dev);
+int swsem_dev_free(swsem_t *h, void *p_dev);
+int swsem_dev_upload(swsem_t *h, void *dst_dev, const void *src_host, uint64_t bytes);   /* synchronous */
+int swsem_dev_copy(swsem_t *h, void *dst_dev, const void *src_dev, uint64_t bytes);      /* on the handle's stream */
+
 /* ---- test / measurement hooks (not part of the reference surface) */
 int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out);      /* getRef() bytes, .h:104 */
 int swsem_debug_copy_ht(swsem_t *h, uint32_t *out /* [hash_size] 32-bit image as on the CPU */);

@@ -545,6 +545,31 @@ int swsem_match(swsem_t *h, const uint8_t *query, uint64_t len, uint32_t minLen,
     return SWSEM_OK;
 }
 
+// plain device-memory helpers so that host code above this ABI needs no HIP headers
+int swsem_dev_malloc(swsem_t *h, uint64_t bytes, void **out) {
+    HIPCHK(hipSetDevice(h->device));
+    *out = nullptr;
+    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) return fail(SWSEM_ENOMEM, "device allocation of %llu bytes failed", (unsigned long long) bytes);
+    return SWSEM_OK;
+}
+int swsem_dev_free(swsem_t *h, void *p) {
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (p) HIPCHK(hipFree(p));
+    return SWSEM_OK;
+}
+int swsem_dev_upload(swsem_t *h, void *dst_dev, const void *src, uint64_t bytes) {
+    HIPCHK(hipSetDevice(h->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SWSEM_OK;
+}
+int swsem_dev_copy(swsem_t *h, void *dst_dev, const void *src_dev, uint64_t bytes) {
+    HIPCHK(hipSetDevice(h->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, h->stream));
+    return SWSEM_OK;
+}
+
 // PgHelpers::upperReverseComplement on device buffers (utils/helper.cpp:405-410): lets the caller build a
 // target's extension string "contig + RC(contig)" (MGMP.cpp:389-398) without leaving HBM.
 int swsem_revcomp_dev(swsem_t *h, const uint8_t *src_dev, uint64_t n, uint8_t *dst_dev) {

@@ -1,0 +1,113 @@
+// Host-side drivers of the compress hot path with the reference's class names and hook surface:
+//   MultipleGenomeMatchingProcessor  matching/MultipleGenomeMatchingProcessor.{h,cpp}  (file list, G0
+//       reference, matcher sizing, the two target loops, in-order reference extension)
+//   MBGC_Encoder                     mbgccoder/MBGC_Encoder.{h,cpp}:128-564,759-807      (the hooks
+//       that collect the match/literal byte streams; the PPMd/LZMA backend is NOT part of this repo:
+//       the collected streams are what the reference hands to prepareAndCompressStreams, :615-732)
+// Policy (which contigs extend the reference, dissimilar-contig retry, lock bookkeeping) stays on the
+// host exactly as in the reference; everything that touches sequence bytes runs through the C ABI.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sw_matcher.h"
+
+struct MGMP_Params {                                   // matching/MGMP_Params.h (only what this path reads)
+    int k = 32, k1 = 16, k2 = 1;                       // :199-202
+    uint8_t skipMargin = 16;                           // :203 (24 in -m2/-m3, MBGC_Params.h:908-909)
+    int referenceFactor = -1;                          // ADJUSTED_REFERENCE_FACTOR_FLAG, :24,:205
+    int referenceSlidingWindowFactor = 16;             // :206
+    bool enable40bitReference = true;                  // :208
+    bool circularReference = true;                     // :209
+    uint8_t bigReferenceCompressorRatio = 16;          // :210 (4 in -m2/-m3)
+    bool refRegionSeparators = true;                   // :12
+    int currentUnmatchedFractionFactor = 128;          // :71
+    int unmatchedFractionRCFactor = 8;                 // :73 (128 in -m2/-m3)
+    bool rcInReference = true;                         // !isRCinReferenceDisabled(), :82-84
+    bool sequentialMatching = false;                   // :218
+    int roundSize = 8;                                 // targets per round (the deterministic stand-in for matcherWorkingThreads, :22)
+    static const uint64_t MIN_BASIC_BLOCK_SIZE = 1 << 21;                 // :48
+    static const uint64_t REFERENCE_LENGTH_LIMIT = (uint64_t) UINT32_MAX << 8;   // :55
+    bool isContigProperForRefExtension(uint64_t len, uint64_t unmatched, int f) const { return unmatched * f > len; }      // :179-186
+    bool isContigProperForRefRCExtension(uint64_t len, uint64_t unmatched, int f) const { return unmatched * f > len; }    // :188-190
+};
+
+struct MBGC_Params : MGMP_Params {                     // mbgccoder/MBGC_Params.h (only what this path reads)
+    uint8_t coderMode = 1;
+    bool lazyDecompressionSupport = true;              // :38
+    swsem_emit_params_t emit;
+    int device = 0;
+    MBGC_Params() { setCompressionMode(1); }
+    void setCompressionMode(int mode);                 // :886-922
+};
+
+struct Contig { std::string header, seq; };
+bool readFastaFile(const std::string &path, std::vector<Contig> &out, uint64_t *fileSize);   // kseq_read_lossless_fasta stand-in
+
+class MultipleGenomeMatchingProcessor {
+protected:
+    MGMP_Params *params;
+    SlidingWindowSparseEMMatcher *matcher = nullptr;
+    std::vector<std::string> fileNames;
+    uint32_t filesCount = 0, targetsCount = 0;
+    int64_t processedTargetsCount = 0;
+    uint64_t refG0InitPos = 0, refFinalTotalLength = 0, totalFilesLength = 0, largestContigSize = 0;
+    size_t resCount = 0, unmatchedCharsAll = 0, totalMatchedAll = 0, totalDestLenAll = 0;
+    std::vector<size_t> matchingLocksPos;
+    std::vector<uint8_t> unmatchedFractionFactors;
+    int device = 0;
+
+    const size_t PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY = SIZE_MAX;     // MGMP.h:97
+
+    void loadG0Ref(const std::string &refName);                                        // MGMP.cpp:66-150
+    void initMatcher(const char *refStr, size_t refStrSize, size_t basicRefLength);     // :152-192
+    void performMatching();                                                             // :568-606
+    void processTargetsWithParallelIO();                                                // :232-313  (-t1)
+    void processTargetsRounds();                                                        // :340-468 as deterministic rounds
+
+    // hooks, MGMP.h:79-115
+    virtual void initStreamsForG0Ref() = 0;
+    virtual void processG0RefContig(const char *seq, size_t len) = 0;
+    virtual size_t processMatches(size_t destLen, int targetIdx, size_t matchingLockPos) = 0;   // consumes the handle's last match
+    virtual void processAfterSequence(uint32_t targetIdx) = 0;
+    virtual void processAfterTarget(uint32_t targetIdx) = 0;
+    virtual void processAfterTargetWithParallelIO(size_t matcherLoaderStartPos) = 0;
+    virtual void initParallelProcessing() = 0;
+    virtual void finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t matcherLoaderStartPos) = 0;
+    virtual void takeRoundStreams(uint32_t targetIdx, EmittedStreams &s) = 0;           // per-target stream append in round mode
+    virtual const swsem_emit_params_t &emitParams() const = 0;
+    virtual const std::vector<size_t> &loadedPositions() const = 0;
+
+public:
+    explicit MultipleGenomeMatchingProcessor(MGMP_Params *p) : params(p) {}
+    virtual ~MultipleGenomeMatchingProcessor() { delete matcher; }
+};
+
+class MBGC_Encoder : public MultipleGenomeMatchingProcessor {
+    MBGC_Params *params;
+    std::vector<size_t> refExtLoadedPosArr;                                             // MBGC_Encoder.h:48
+    std::vector<EmittedStreams> targetStreams;                                          // per-target streams (round mode)
+
+    void initStreamsForG0Ref() override;                                                // ENC.cpp:25-32
+    void processG0RefContig(const char *seq, size_t len) override;                      // :34-37
+    size_t processMatches(size_t destLen, int targetIdx, size_t matchingLockPos) override;      // :143-308 on the device
+    void processAfterSequence(uint32_t targetIdx) override;                             // :489-491
+    void processAfterTarget(uint32_t targetIdx) override;                               // :493-496
+    void processAfterTargetWithParallelIO(size_t matcherLoaderStartPos) override;       // :498-509
+    void initParallelProcessing() override;                                             // :516-528
+    void finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t matcherLoaderStartPos) override;   // :542-564
+    void takeRoundStreams(uint32_t targetIdx, EmittedStreams &s) override;
+    const swsem_emit_params_t &emitParams() const override { return params->emit; }
+    const std::vector<size_t> &loadedPositions() const override { return refExtLoadedPosArr; }
+
+public:
+    // the streams the reference enrols at ENC.cpp:779-787 (+ the two it writes beside them)
+    std::string literals, mapOff, mapOff5thByte, mapLen, gapDeltas, gapMismatchesFlags, locksPosStream, refExtSizeStream;
+    size_t extensionsMatchedCharsAll = 0, extensionsMismatchesAll = 0, removedGapBreakingMatchesAll = 0;
+
+    explicit MBGC_Encoder(MBGC_Params *p) : MultipleGenomeMatchingProcessor(p), params(p) { device = p->device; }
+    void encode(const std::vector<std::string> &files);                                 // :759-807 up to performMatching()
+    size_t exactMatches() const { return resCount; }
+    size_t unmatchedChars() const { return unmatchedCharsAll; }
+};

@@ -1,0 +1,119 @@
+#include "sw_matcher.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+using PgTools::TextMatch;
+
+void SlidingWindowSparseEMMatcher::die(const char *what) const {
+    // the reference prints its message and exits (e.g. SlidingWindowSparseEMMatcher.cpp:82-85,186-187,389-390,481-482)
+    fprintf(stderr, "%s: %s\n\n", what, swsem_last_error());
+    exit(EXIT_FAILURE);
+}
+
+SlidingWindowSparseEMMatcher::SlidingWindowSparseEMMatcher(size_t refLengthLimit, uint32_t targetMatchLength, int k1, int k2,
+                                                           int skipMargin, int device) {
+    check(swsem_create(&h, refLengthLimit, (int) targetMatchLength, k1, k2, skipMargin, device), "Error initializing ExpSparseMEM");
+}
+
+SlidingWindowSparseEMMatcher::~SlidingWindowSparseEMMatcher() { swsem_destroy(h); }
+
+void SlidingWindowSparseEMMatcher::disableSlidingWindow() { swsem_disable_sliding_window(h); }
+void SlidingWindowSparseEMMatcher::disableCircularBuffer() { swsem_disable_circular_buffer(h); }
+void SlidingWindowSparseEMMatcher::setSlidingWindowSize(uint8_t factor) { swsem_set_sliding_window_size(h, factor); }
+size_t SlidingWindowSparseEMMatcher::getMaxRefLength() const { return swsem_get_max_ref_length(h); }
+size_t SlidingWindowSparseEMMatcher::getRefLength() const { return swsem_get_ref_length(h); }
+size_t SlidingWindowSparseEMMatcher::getLoadingPosition() const { return swsem_get_loading_position(h); }
+size_t SlidingWindowSparseEMMatcher::getLoadedRefLength() const { return swsem_get_loaded_ref_length(h); }
+void SlidingWindowSparseEMMatcher::setPosition(size_t refPos, int laps) { swsem_set_position(h, refPos, laps); }
+size_t SlidingWindowSparseEMMatcher::acquireWorkerMatchingLockPos() { return swsem_acquire_lock(h); }
+
+void SlidingWindowSparseEMMatcher::releaseWorkerMatchingLockPos(size_t lockValue) {
+    check(swsem_release_lock(h, lockValue), "ERROR");
+}
+
+void SlidingWindowSparseEMMatcher::loadRef(const char *refText, size_t refLength, bool loadRCRef, bool addRegionSeparators,
+                                           char regionSeparator) {
+    check(swsem_load_ref(h, (const uint8_t *) refText, refLength, loadRCRef, addRegionSeparators, (unsigned char) regionSeparator), "loadRef");
+}
+
+void SlidingWindowSparseEMMatcher::loadRefDev(const uint8_t *textDev, size_t len, bool loadRC, bool addSep, char sep) {
+    check(swsem_load_ref_dev(h, textDev, len, loadRC, addSep, (unsigned char) sep), "loadRef");
+}
+
+void SlidingWindowSparseEMMatcher::loadSeparator(char regionSeparator) {
+    check(swsem_load_separator(h, (unsigned char) regionSeparator), "loadSeparator");
+}
+
+void SlidingWindowSparseEMMatcher::matchTexts(std::vector<TextMatch> &res, const std::string &destText, bool destIsRef,
+                                              bool revComplMatching, uint32_t minMatchLength, size_t matchingLockPos) {
+    matchTexts(res, destText.data(), destText.size(), destIsRef, revComplMatching, minMatchLength, matchingLockPos);
+}
+
+void SlidingWindowSparseEMMatcher::matchTexts(std::vector<TextMatch> &res, const char *destText, size_t destLen, bool destIsRef,
+                                              bool revComplMatching, uint32_t minMatchLength, size_t matchingLockPos) {
+    if (destIsRef || revComplMatching) {        // SlidingWindowSparseEMMatcher.cpp:185-188
+        fprintf(stderr, "Source as destination and reverse-complement matching modes unsupported\n\n");
+        exit(EXIT_FAILURE);
+    }
+    res.clear();                                // .cpp:484
+    const swsem_match_t *m = nullptr;
+    uint64_t n = 0;
+    check(swsem_match(h, (const uint8_t *) destText, destLen, minMatchLength, matchingLockPos, &m, &n), "matchTexts");
+    res.reserve(n);
+    for (uint64_t i = 0; i < n; i++) res.emplace_back(m[i].posSrcText, m[i].length, m[i].posDestText);
+}
+
+static void take(const swsem_streams_t &st, EmittedStreams &out) {
+    for (int s = 0; s < SWSEM_NSTREAMS; s++) out.s[s].assign((const char *) st.data[s], st.size[s]);
+    out.unmatchedChars = st.unmatchedChars;
+    out.extensionsMatchedChars = st.extensionsMatchedChars;
+    out.extensionsMismatches = st.extensionsMismatches;
+    out.totalMatched = st.totalMatched;
+    out.removedGapBreakingMatches = st.removedGapBreakingMatches;
+    out.nmatches = st.nmatches;
+}
+
+size_t SlidingWindowSparseEMMatcher::processMatches(const swsem_emit_params_t &p, size_t matchingLockPos, int factor,
+                                                    int64_t processed, int64_t targetIdx, const std::vector<size_t> &loaded,
+                                                    EmittedStreams &out) {
+    swsem_streams_t st;
+    std::vector<uint64_t> ld(loaded.begin(), loaded.end());
+    check(swsem_emit(h, &p, 0, matchingLockPos, factor, processed, targetIdx, ld.data(), ld.size(), &st), "processMatches");
+    take(st, out);
+    return st.unmatchedChars;
+}
+
+void SlidingWindowSparseEMMatcher::matchRound(const uint8_t *contigsDev, const std::vector<uint64_t> &offsets, uint32_t minLen,
+                                              const std::vector<uint64_t> &lockPos, std::vector<uint64_t> &counts) {
+    const int n = (int) offsets.size() - 1;
+    check(swsem_match_batch_dev(h, contigsDev, offsets.data(), n, minLen, lockPos.empty() ? nullptr : lockPos.data()), "matchTexts");
+    counts.assign(n, 0);
+    check(swsem_batch_counts(h, counts.data()), "matchTexts");
+}
+
+void SlidingWindowSparseEMMatcher::emitRound(const swsem_emit_params_t &p, const std::vector<uint64_t> &lockPos,
+                                             const std::vector<int> &factors, const std::vector<int64_t> &processed,
+                                             const std::vector<int64_t> &targetIdx, const std::vector<size_t> &loaded,
+                                             std::vector<EmittedStreams> &out) {
+    const int n = (int) lockPos.size();
+    std::vector<uint64_t> ld(loaded.begin(), loaded.end());
+    check(swsem_emit_batch(h, &p, n, nullptr, lockPos.data(), factors.data(), processed.data(), targetIdx.data(), ld.data(), ld.size()),
+          "processMatches");
+    out.assign(n, EmittedStreams());
+    for (int k = 0; k < n; k++) {
+        swsem_streams_t st;
+        check(swsem_emit_result(h, k, &st), "processMatches");
+        take(st, out[k]);
+    }
+}
+
+uint8_t *SlidingWindowSparseEMMatcher::devAlloc(size_t bytes) {
+    void *p = nullptr;
+    check(swsem_dev_malloc(h, bytes, &p), "device allocation");
+    return (uint8_t *) p;
+}
+void SlidingWindowSparseEMMatcher::devFree(uint8_t *p) { check(swsem_dev_free(h, p), "device free"); }
+void SlidingWindowSparseEMMatcher::devUpload(uint8_t *dst, const void *src, size_t bytes) { check(swsem_dev_upload(h, dst, src, bytes), "upload"); }
+void SlidingWindowSparseEMMatcher::devCopy(uint8_t *dst, const uint8_t *src, size_t bytes) { check(swsem_dev_copy(h, dst, src, bytes), "copy"); }
+void SlidingWindowSparseEMMatcher::devRevComp(const uint8_t *src, size_t n, uint8_t *dst) { check(swsem_revcomp_dev(h, src, n, dst), "revcomp"); }

@@ -1,0 +1,88 @@
+"""End to end through the C++ host classes (mbgc_amd/host: MBGC_Encoder / MultipleGenomeMatchingProcessor /
+SlidingWindowSparseEMMatcher facade over the C ABI) and the mbgc-hip tool:
+  * BASELINE.json configs[0]: the reference's three bundled Listeria genomes, `-t1` schedule — every raw
+    stream must equal what the reference CLI (`mbgc-dev c -t1` + `v -D`, run in the build container)
+    produced (digests in tests/golden/listeria/expected_t1.json);
+  * the round schedule on synthetic multi-contig files against the oracle-driven reference loop."""
+import hashlib
+import json
+import lzma
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _driver
+import _orc
+from mbgc_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "mbgc_amd", "mbgc-hip")
+LIST = os.path.join(ROOT, "tests", "golden", "listeria")
+
+
+def run_tool(args, cwd):
+    r = subprocess.run([TOOL] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_listeria_t1_streams_equal_reference_cli(tmp_path):
+    exp = json.load(open(os.path.join(LIST, "expected_t1.json")))
+    names = []
+    for f in exp["files"]:
+        data = lzma.open(os.path.join(LIST, f + ".xz")).read()
+        (tmp_path / f).write_bytes(data)
+        names.append(str(tmp_path / f))
+    (tmp_path / "seqlist.txt").write_text("\n".join(names) + "\n")
+    out = run_tool(["c", "-t1", "seqlist.txt", "lm"], str(tmp_path))
+    assert "exact matches total: 29731" in out
+    assert "removed matches breaking gaps total: 1418" in out
+    assert "swsMEM unmatched chars: 5009573" in out
+    assert "final unmatched chars: 3652988" in out
+    for name, e in exp["streams"].items():
+        b = (tmp_path / ("lm." + name)).read_bytes()
+        assert len(b) == e["bytes"], name
+        assert hashlib.md5(b).hexdigest() == e["md5"], name
+
+
+def split(g, k):
+    cuts = [0] + [g.size * i // k + (7 * i) % 13 for i in range(1, k)] + [g.size]
+    return [g[cuts[i]:cuts[i + 1]] for i in range(k)]
+
+
+@pytest.mark.parametrize("args,rs", [(["-t1"], 0), (["-R", "3"], 3), (["-R", "8"], 8)])
+def test_synthetic_files_equal_oracle_driver(tmp_path, args, rs):
+    base = synth.base_codes(70_000, 55)
+    gs = [synth.genome(base, i, 0.015) for i in range(8)]
+    files = [split(g, 2) for g in gs]
+    paths = []
+    for i, contigs in enumerate(files):
+        p = tmp_path / ("g%02d.fa" % i)
+        with open(p, "wb") as f:
+            for j, c in enumerate(contigs):
+                f.write(synth.fasta_bytes(c, i * 10 + j))
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    run_tool(["c"] + args + ["list.txt", "out"], str(tmp_path))
+    fsize = os.path.getsize(paths[0])
+    if rs == 0:
+        lim, _ = _driver.ref_length_limit(len(files), fsize)
+        o = _orc.OracleMatcher(lim)
+        oe = _orc.OracleEmitter(o)
+        res = _driver.encode_sequential(o, oe, files)
+        streams = oe.streams()
+        g0lit = files[0][0].tobytes() + b"\xa2"
+    else:
+        lim, _ = _driver.ref_length_limit(len(files), sum(c.size for c in files[0]))
+        o = _orc.OracleMatcher(lim)
+        res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), files[0], files[1:], rs)
+        streams = res["streams"]
+        g0lit = b"".join(c.tobytes() + b"\xa2" for c in files[0])
+    got = {k: (tmp_path / ("out." + k)).read_bytes() for k in ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags", "locksPos", "refExtSize")}
+    assert got["literals"] == g0lit + streams["literals"]
+    for k in ("mapOff", "mapOff5th", "mapLen", "gapDelta", "flags"):
+        assert got[k] == streams[k], k
+    assert got["locksPos"] == res["locks"] and got["refExtSize"] == res["refExtSize"]
