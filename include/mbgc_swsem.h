@@ -154,6 +154,7 @@ enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2, SWSEM_K_EXTEND =
        SWSEM_K_STITCH = 5, SWSEM_K_EMIT = 6, SWSEM_K_COUNT = 7 };
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream; the accumulated
  * device time (ms) and launch count per kernel family are read back with swsem_profile_get. */
+int swsem_debug_block_times(swsem_t *h, uint64_t *out /* [cap][3]: ticks, candidates visited, stack rows */, uint64_t cap, uint64_t *nblocks);
 int swsem_profile_enable(swsem_t *h, int on);
 int swsem_profile_get(swsem_t *h, double ms[SWSEM_K_COUNT], uint64_t launches[SWSEM_K_COUNT]);
 /* counters of the last batch (after swsem_batch_counts): [0] query bases, [1] hash-table probes,

@@ -139,9 +139,16 @@ struct Chain {
     int32_t minTouched;    // lowest stack index examined since the last reset (-1: walked off the bottom)
     int32_t minKeep;       // lowest keepCount of an emission since the last reset
     int32_t visited;       // hits visited since the last reset
+    uint32_t cands;        // candidates fetched (diagnostics)
 };
 
 constexpr int RING = 64;
+
+// wave-uniform values belong in SGPRs: lane reads with a uniform lane index / first-lane broadcasts keep
+// the whole automaton on the scalar unit and out of the vector register file
+__device__ __forceinline__ uint32_t rl32(uint32_t x, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) x, lane); }
+__device__ __forceinline__ uint32_t rfl32(uint32_t x) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) x); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t x) { return ((uint64_t) rfl32((uint32_t) (x >> 32)) << 32) | rfl32((uint32_t) x); }
 constexpr int OVERLAP = 1024;          // warm-up positions of a speculative block chain (<= TILE)
 constexpr int SNAP = 4;                // stack elements snapshotted at a block boundary / end
 
@@ -154,9 +161,9 @@ struct ArrayStack {
     __device__ __forceinline__ void get(int idx, int64_t &posDest, int64_t &len) {
         if (idx >= ringLow) {
             const uint2 e = ring[idx & (RING - 1)];
-            posDest = e.x; len = e.y;
+            posDest = rfl32(e.x); len = rfl32(e.y);
         } else {
-            posDest = (int64_t) st[idx].posDest; len = (int64_t) st[idx].len;
+            posDest = (int64_t) rfl64(st[idx].posDest); len = (int64_t) rfl64(st[idx].len);
         }
     }
     // resMatches.resize(keep); resMatches.push_back(m)   (.cpp:299-300)
@@ -173,40 +180,49 @@ struct ArrayStack {
 // The true match list of a contig while the stitch kernel assembles it: a chain of per-block
 // segments (block b contributes region_b[segStart[b] .. +keepN[b])), newest segment on top, plus the
 // pushes of the block being replayed ("own"). Elements are only ever consulted from the top down.
+// The newest segment's row count and predecessor live in registers (topKeep, topPrev); keepN[] in
+// memory is valid for every segment below it.
 struct VirtStack {
     Match *region;            // block regions of this contig
     uint32_t cap;             // rows per block region
     uint32_t *segStart, *keepN;
     int32_t *prev;
     int32_t segTop;           // newest non-empty segment, -1 if none
+    int32_t topKeep, topPrev; // rows / predecessor of segTop
     int32_t size_;            // rows in the whole list
     Match *own; int32_t ownN; // pushes of the block being replayed
     int32_t curSeg, curLocal, curR;   // cursor: element curLocal of segment curSeg is curR rows below the top of the segments
     __device__ __forceinline__ int size() const { return size_; }
+    __device__ __forceinline__ int keep_of(int seg) const { return seg == segTop ? topKeep : (int) rfl32(keepN[seg]); }
+    __device__ __forceinline__ int prev_of(int seg) const { return seg == segTop ? topPrev : (int) rfl32((uint32_t) prev[seg]); }
     __device__ const Match *at(int idx) {
         const int below = size_ - ownN;              // rows held by the segments
         if (idx >= below) return own + (idx - below);
         const int r = below - 1 - idx;
-        if (curSeg < 0 || curR > r) { curSeg = segTop; curLocal = (int32_t) keepN[segTop] - 1; curR = 0; }
+        if (curSeg < 0 || curR > r) { curSeg = segTop; curLocal = topKeep - 1; curR = 0; }
         while (curR < r) {
             const int step = r - curR < curLocal ? r - curR : curLocal;
             if (step > 0) { curLocal -= step; curR += step; }
-            else { curSeg = prev[curSeg]; curLocal = (int32_t) keepN[curSeg] - 1; curR++; }
+            else { curSeg = prev_of(curSeg); curLocal = keep_of(curSeg) - 1; curR++; }
         }
-        return region + (uint64_t) curSeg * cap + segStart[curSeg] + curLocal;
+        return region + (uint64_t) curSeg * cap + rfl32(segStart[curSeg]) + curLocal;
     }
     __device__ __forceinline__ void get(int idx, int64_t &posDest, int64_t &len) {
         const Match *m = at(idx);
-        posDest = (int64_t) m->posDest; len = (int64_t) m->len;
+        posDest = (int64_t) rfl64(m->posDest); len = (int64_t) rfl64(m->len);
     }
     __device__ void pop_segments(int p) {
         const bool l0 = (threadIdx.x & (WAVE - 1)) == 0;
         while (p > 0) {
-            const int k = (int) keepN[segTop];
-            const int take = k < p ? k : p;
-            if (l0) keepN[segTop] = (uint32_t) (k - take);
+            const int take = topKeep < p ? topKeep : p;
+            topKeep -= take;
             p -= take;
-            if (take == k) segTop = prev[segTop];
+            if (topKeep == 0) {                      // the segment is gone: its predecessor becomes the top
+                if (l0) keepN[segTop] = 0;
+                const int nt = topPrev;
+                if (nt >= 0) { topKeep = (int) rfl32(keepN[nt]); topPrev = (int) rfl32((uint32_t) prev[nt]); }
+                segTop = nt;
+            }
         }
         curSeg = -1;
     }
@@ -221,11 +237,17 @@ struct VirtStack {
     }
     __device__ void push_segment(int b, uint32_t start, uint32_t n) {
         if (n == 0) return;
-        if ((threadIdx.x & (WAVE - 1)) == 0) { segStart[b] = start; keepN[b] = n; prev[b] = segTop; }
+        if ((threadIdx.x & (WAVE - 1)) == 0) {
+            if (segTop >= 0) keepN[segTop] = (uint32_t) topKeep;
+            segStart[b] = start; prev[b] = segTop;
+        }
+        topPrev = segTop;
         segTop = b;
+        topKeep = (int32_t) n;
         size_ += (int32_t) n;
         curSeg = -1;
     }
+    __device__ void flush() { if (segTop >= 0 && (threadIdx.x & (WAVE - 1)) == 0) keepN[segTop] = (uint32_t) topKeep; }
 };
 
 // Wave-cooperative exact comparison, 256 bytes per step: equal bytes of a[n..limit) vs b[n..limit)
@@ -251,7 +273,7 @@ __device__ uint64_t wave_lcp_fwd(const uint8_t *a, const uint8_t *b, uint64_t n,
         const unsigned long long bal = __ballot(stop);
         if (bal) {
             const int l = __builtin_ctzll(bal);
-            return n + 4 * (uint64_t) l + (uint32_t) __shfl((int) eq, l);
+            return n + 4 * (uint64_t) l + rl32(eq, l);
         }
         n += 4 * WAVE;
         if (steps && --steps == 0 && n < limit) { more = true; return n; }
@@ -279,7 +301,7 @@ __device__ uint64_t wave_lcp_bwd(const uint8_t *a, const uint8_t *b, uint64_t n,
         const unsigned long long bal = __ballot(stop);
         if (bal) {
             const int l = __builtin_ctzll(bal);
-            return n + 4 * (uint64_t) l + (uint32_t) __shfl((int) eq, l);
+            return n + 4 * (uint64_t) l + rl32(eq, l);
         }
         n += 4 * WAVE;
         if (steps && --steps == 0 && n < limit) { more = true; return n; }
@@ -371,11 +393,15 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
 }
 
 // A visited candidate: verify the K-mer (memcmp(curr1, curr2, K), .cpp:298 — a failed candidate changes
-// no state in the reference either), take the first 256-byte step of the right run (.cpp:227-246) and
-// of the left run, all loads of the three comparisons in flight together, then run the automaton.
+// no state in the reference either) and take the first step of the right run (.cpp:227-246) and of the
+// left run. The first step is one byte per lane (64 bytes per side = one sector each for the reference
+// and the query: runs between 1 %-divergent genomes average ~50 bytes, wider steps only move unused
+// bytes); the loads of all three comparisons are issued before any of them is consumed, so a visit
+// costs one memory round trip. Longer runs continue 256 bytes per step (wave_lcp_fwd / wave_lcp_bwd).
 template <class Stack>
 __device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stack &stk, Chain &ch, int64_t i, uint32_t val) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
+    ch.cands++;
     const uint64_t c = (uint64_t) val << v.k1ord;                     // htDecodePos, .h:133
     uint64_t lo, hi;
     window_ok(v, cg.lock, c, lo, hi);
@@ -385,36 +411,55 @@ __device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stac
     const uint64_t limR = ra < rb ? ra : rb;
     const uint64_t d = c - lo;
     const uint64_t limL = (uint64_t) i < d ? (uint64_t) i : d;
+    const bool inR = lane < limR, inL = lane < limL, isK = (int) lane < (int) (K / 4);
     uint32_t xk = 0;
-    if ((int) lane < (int) (K / 4)) xk = ld_u32(r0 + 4 * lane) ^ ld_u32(q0 + 4 * lane);
-    bool moreR, moreL;
-    const uint64_t rext = wave_lcp_fwd(r0 + K, q0 + K, 0, limR, 1, moreR);
-    const uint64_t ell = wave_lcp_bwd(r0, q0, 0, limL, 1, moreL);
+    uint8_t ar = 0, br = 0, al = 0, bl = 0;
+    if (isK) xk = ld_u32(r0 + 4 * lane) ^ ld_u32(q0 + 4 * lane);
+    if (inR) { ar = r0[K + lane]; br = q0[K + lane]; }
+    if (inL) { al = r0[-(int64_t) lane - 1]; bl = q0[-(int64_t) lane - 1]; }
     if (__ballot(xk != 0)) { ch.scan = i + 1; return; }
+    const unsigned long long sr = __ballot(!inR || ar != br), sl = __ballot(!inL || al != bl);
+    // the first stopping lane is the first mismatch or the first byte past the limit
+    const uint64_t rext = sr ? (uint64_t) __builtin_ctzll(sr) : (uint64_t) WAVE;
+    const uint64_t ell = sl ? (uint64_t) __builtin_ctzll(sl) : (uint64_t) WAVE;
     process_hit(v, cg, q, stk, ch, c, i, (int64_t) ell, (int64_t) rext, (int64_t) (d > 0xFFFFFFFFull ? 0xFFFFFFFFull : d),
-                (moreL ? HIT_CAPL : 0u) | (moreR ? HIT_CAPR : 0u));
+                (sl ? 0u : HIT_CAPL) | (sr ? 0u : HIT_CAPR));
 }
 
 // Runs the chain over the candidates at query positions [p0, p1) of one contig (p1 <= positions).
+// Four 64-position batches of the candidate array are fetched per round trip; a jump that lands inside
+// the fetched window (the common case: matches of ~100 bases) costs no further load.
 template <class Stack>
 __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
                           int64_t p0, int64_t p1, Stack &stk, Chain &ch) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
+    constexpr int NB = 4;
     while (true) {
         const int64_t s = ch.scan > p0 ? ch.scan : p0;
         if (s >= p1) break;
         const int64_t base = s & ~(int64_t) (WAVE - 1);
-        const int64_t pos = base + lane;
-        const uint32_t val = (pos >= s && pos < p1) ? cand[pos] : 0u;
-        unsigned long long m = __ballot(val != 0);
-        if (!m) { ch.scan = base + WAVE < p1 ? base + WAVE : p1; continue; }
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            visit(v, cg, q, stk, ch, base + l, (uint32_t) __shfl((int) val, l));
-            const int64_t rel = ch.scan - base;                       // first lane still to be visited
-            m = rel >= WAVE ? 0ull : (m & ~((1ull << rel) - 1));
+        uint32_t w[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int64_t pos = base + k * WAVE + lane;
+            w[k] = (pos >= s && pos < p1) ? cand[pos] : 0u;
         }
-        if (ch.scan < base + WAVE) ch.scan = base + WAVE < p1 ? base + WAVE : p1;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int64_t bk = base + k * WAVE;
+            if (bk >= p1) break;
+            if (ch.scan >= bk + WAVE) continue;                       // jumped over this batch
+            unsigned long long m = __ballot(w[k] != 0);
+            const int64_t rel0 = ch.scan - bk;
+            if (rel0 > 0) m &= ~((1ull << rel0) - 1);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                visit(v, cg, q, stk, ch, bk + l, rl32(w[k], l));
+                const int64_t rel = ch.scan - bk;                     // first lane still to be visited
+                m = rel >= WAVE ? 0ull : (m & ~((1ull << rel) - 1));
+            }
+            if (ch.scan < bk + WAVE) ch.scan = bk + WAVE < p1 ? bk + WAVE : p1;
+        }
     }
 }
 
@@ -427,7 +472,7 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
     __shared__ uint2 ring[RING];
     const Contig cg = contigs[blockIdx.x];
     Chain ch;
-    ch.scan = 0; ch.minTouched = 0; ch.minKeep = 0; ch.visited = 0;
+    ch.scan = 0; ch.minTouched = 0; ch.minKeep = 0; ch.visited = 0; ch.cands = 0;
     ArrayStack stk;
     stk.st = matches + cg.matchBase; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
@@ -452,6 +497,8 @@ struct __attribute__((aligned(16))) BlockRec {
     int32_t spB, spF;      // stack size at the boundary / at the end
     int32_t minTouched;    // lowest index examined while replaying the own tiles (INT_MAX: nothing visited)
     int32_t minKeep;       // rows of the boundary stack that survived the own tiles (<= spB)
+    uint64_t cycles;       // s_memtime ticks spent by the block's wave (diagnostics: swsem_debug_block_times)
+    uint32_t visits, emits;
     Match bTop[SNAP];      // newest rows at the boundary, newest first
     Match fTop[SNAP];      // newest rows at the end, newest first
 };
@@ -480,7 +527,8 @@ __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_
     const int64_t w1 = w0 + (int64_t) rb * TILE < npos ? w0 + (int64_t) rb * TILE : npos;
     const uint32_t *cd = cand + cg.candBase;
     Chain ch;
-    ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0;
+    ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0;
+    const uint64_t tstart = __builtin_amdgcn_s_memtime();
     ArrayStack stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
@@ -498,6 +546,8 @@ __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_
     r.minKeep = ch.minKeep < r.spB ? ch.minKeep : r.spB;
     __builtin_amdgcn_s_waitcnt(0);
     snapshot_top(stk.st, stk.sp, r.fTop);
+    r.cycles = __builtin_amdgcn_s_memtime() - tstart;
+    r.visits = ch.cands; r.emits = (uint32_t) (stk.sp);
     if (threadIdx.x == 0) recs[g] = r;
 }
 
@@ -505,28 +555,11 @@ __device__ __forceinline__ bool same_match(const Match &a, const Match &b) {
     return a.posSrc == b.posSrc && a.len == b.len && a.posDest == b.posDest;
 }
 
-// newest-first window over the true list, kept in registers (static indices only)
-struct TopWin {
-    Match e[SNAP];
-    int known;
-    __device__ __forceinline__ void drop(int p) {
-        for (int k = 0; k < p && k < SNAP; k++) {
-#pragma unroll
-            for (int j = 0; j + 1 < SNAP; j++) e[j] = e[j + 1];
-        }
-        known = known > p ? known - p : 0;
-    }
-    __device__ __forceinline__ void prepend(const Match &m) {
-#pragma unroll
-        for (int j = SNAP - 1; j > 0; j--) e[j] = e[j - 1];
-        e[0] = m;
-        known = known < SNAP ? known + 1 : SNAP;
-    }
-};
-
 // One wave per contig: walk the resolve blocks with the true state (see above). Outputs per block the
 // segment (segStart, keepN) of its region that belongs to the final list, the row offsets and the
-// contig's match count.
+// contig's match count. The walk is a dependent chain executed by a single wave, so everything in it
+// is either scalar (readfirstlane'd record fields) or one lane-parallel LDS operation: the newest
+// SNAP true rows live in LDS as 3*SNAP u64 words and are compared / rebuilt by 3*SNAP lanes at once.
 __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__restrict__ qbuf,
                                                  const Contig *__restrict__ contigs, const uint32_t *__restrict__ cand,
                                                  Match *__restrict__ regions,
@@ -541,62 +574,82 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     VirtStack vs;
     vs.region = regions + (uint64_t) cg.rb0 * cap; vs.cap = cap;
     vs.segStart = segStart + cg.rb0; vs.keepN = keepN + cg.rb0; vs.prev = prev + cg.rb0;
-    vs.segTop = -1; vs.size_ = 0; vs.own = nullptr; vs.ownN = 0; vs.curSeg = -1; vs.curLocal = 0; vs.curR = 0;
+    vs.segTop = -1; vs.topKeep = 0; vs.topPrev = -1; vs.size_ = 0; vs.own = nullptr; vs.ownN = 0; vs.curSeg = -1; vs.curLocal = 0; vs.curR = 0;
     for (uint32_t b = lane; b < cg.nrb; b += WAVE) { vs.keepN[b] = 0; vs.segStart[b] = 0; }
     __builtin_amdgcn_s_waitcnt(0);
     int64_t scanT = 0;                 // true scan position
-    TopWin top;                        // newest true rows
-    top.known = 0;
+    constexpr int TW = 3 * SNAP;       // u64 words of the newest-rows window
+    __shared__ uint64_t ptop[TW];      // newest true rows, newest first, {posSrc, len, posDest} each
+    int known = 0;                     // rows of ptop that are valid
     uint32_t replayed = 0;
     const BlockRec *rc = recs + cg.rb0;
     const int64_t span = (int64_t) rb * TILE;
     const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
+    constexpr int STAGE = 16;          // block records fetched per coalesced burst
+    __shared__ uint4 srec[STAGE * sizeof(BlockRec) / 16];
     for (uint32_t b = 0; b < cg.nrb; b++) {
+        if (b % STAGE == 0) {
+            const uint32_t nrec = cg.nrb - b < STAGE ? cg.nrb - b : STAGE;
+            const uint4 *src = (const uint4 *) (rc + b);
+            for (uint32_t i = lane; i < nrec * (sizeof(BlockRec) / 16); i += WAVE) srec[i] = src[i];
+            __builtin_amdgcn_s_waitcnt(0);
+        }
         const int64_t w0 = (int64_t) b * span;
         if (scanT >= w0 + span) continue;                       // the sequential loop jumped over this block
-        const BlockRec r = rc[b];
-        const bool visited = r.minTouched != 0x7fffffff;
+        const BlockRec *r = (const BlockRec *) (srec + (b % STAGE) * (sizeof(BlockRec) / 16));
+        const int64_t rScanB = (int64_t) rfl64((uint64_t) r->scanB), rScanF = (int64_t) rfl64((uint64_t) r->scanF);
+        const int spB = (int) rfl32((uint32_t) r->spB), spF = (int) rfl32((uint32_t) r->spF);
+        const int minTouched = (int) rfl32((uint32_t) r->minTouched), minKeep = (int) rfl32((uint32_t) r->minKeep);
+        const uint64_t *bw = (const uint64_t *) r->bTop, *fw = (const uint64_t *) r->fTop;
+        const bool visited = minTouched != 0x7fffffff;
         bool ok;
         if (b == 0) ok = true;                                  // block 0 started from the true (empty) state
         else {
-            ok = (scanT > w0 ? scanT : w0) == r.scanB;
+            ok = (scanT > w0 ? scanT : w0) == rScanB;
             if (ok && visited) {
                 // rows of the boundary stack the block looked at (all of them + "nothing below" when it
                 // walked off the bottom)
-                const int cmp = r.minTouched < 0 ? r.spB : r.spB - r.minTouched;
-                if (r.minTouched < 0) ok = vs.size_ == r.spB && r.spB <= SNAP;
+                const int cmp = minTouched < 0 ? spB : spB - minTouched;
+                if (minTouched < 0) ok = vs.size_ == spB && spB <= SNAP;
                 else ok = cmp <= SNAP && cmp <= vs.size_;
-                if (ok && cmp > top.known) {                    // refresh the true newest rows from the list
+                if (ok && cmp > known) {                        // refresh the true newest rows from the list
                     __builtin_amdgcn_s_waitcnt(0);
                     const int n = vs.size_ < SNAP ? vs.size_ : SNAP;
-#pragma unroll
-                    for (int j = 0; j < SNAP; j++)
-                        if (j < n) top.e[j] = *vs.at(vs.size_ - 1 - j);
-                    top.known = n;
+                    for (int j = 0; j < n; j++) {
+                        const Match *m = vs.at(vs.size_ - 1 - j);
+                        if (lane < 3) ptop[3 * j + lane] = ((const uint64_t *) m)[lane];
+                    }
+                    known = n;
                 }
-#pragma unroll
-                for (int j = 0; j < SNAP; j++)
-                    if (ok && j < cmp) ok = same_match(top.e[j], r.bTop[j]);
+                if (ok) {
+                    const bool diff = (int) lane < 3 * cmp && bw[lane < TW ? lane : 0] != ptop[lane < TW ? lane : 0];
+                    ok = __ballot(diff) == 0;
+                }
             }
         }
         if (ok) {
             if (visited || b == 0) {
-                const int popB = r.spB - r.minKeep;
-                const int npush = r.spF - r.minKeep;
+                const int popB = spB - minKeep;
+                const int npush = spF - minKeep;
                 if (popB > 0) vs.pop_segments(popB);
                 vs.size_ -= popB;
-                vs.push_segment((int) b, (uint32_t) r.minKeep, (uint32_t) npush);
-                top.drop(popB);
-                if (npush >= SNAP) top.known = 0;               // fully replaced by the block's own rows
-#pragma unroll
-                for (int j = SNAP - 1; j >= 0; j--)
-                    if (j < npush) top.prepend(r.fTop[j]);
-                scanT = r.scanF;
+                vs.push_segment((int) b, (uint32_t) minKeep, (uint32_t) npush);
+                // newest rows after the block: its pushes first, then what is left of the old window
+                const int keepOld = known > popB ? known - popB : 0;
+                if (lane < TW) {
+                    const int row = lane / 3, fld = lane % 3;
+                    uint64_t x = 0;
+                    if (row < npush) x = fw[lane];
+                    else if (row - npush < keepOld) x = ptop[3 * (row - npush + popB) + fld];
+                    ptop[lane] = x;
+                }
+                known = npush + keepOld < SNAP ? npush + keepOld : SNAP;
+                scanT = rScanF;
             }
         } else {
             // replay the block from the true state; its rows replace the speculative ones in the region
             Chain ch;
-            ch.scan = scanT; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0;
+            ch.scan = scanT; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0;
             vs.own = vs.region + (uint64_t) b * cap; vs.ownN = 0;
             run_chain(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch);
             const int n = vs.ownN;
@@ -604,11 +657,12 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
             __builtin_amdgcn_s_waitcnt(0);
             vs.push_segment((int) b, 0, (uint32_t) n);
             scanT = ch.scan;
-            top.known = 0;
+            known = 0;
             replayed++;
         }
     }
     // row offsets of the surviving segments (ascending block order = list order)
+    vs.flush();
     __builtin_amdgcn_s_waitcnt(0);
     uint32_t run = 0;
     for (uint32_t b0 = 0; b0 < cg.nrb; b0 += WAVE) {

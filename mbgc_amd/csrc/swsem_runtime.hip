@@ -99,7 +99,7 @@ struct swsem {
     std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
-    uint32_t rb = 8;                       // probe tiles per resolve block (SWSEM_RB)
+    uint32_t rb = 4;                       // probe tiles per resolve block (SWSEM_RB)
     std::vector<Contig> contigs;
     std::vector<uint32_t> matchCount;
     std::vector<swsem_match_t> hostMatches;
@@ -598,6 +598,19 @@ int swsem_debug_copy_ht(swsem_t *h, uint32_t *out) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, tmp.p, (size_t) h->hash_size * 4, hipMemcpyDeviceToHost));
     tmp.release();
+    return SWSEM_OK;
+}
+
+// diagnostics: per resolve block of the last batch {ticks, candidates visited, rows on the stack}
+int swsem_debug_block_times(swsem_t *h, uint64_t *out, uint64_t cap, uint64_t *n) {
+    uint64_t nb = 0;
+    for (auto &c : h->contigs) nb += c.nrb;
+    *n = nb;
+    if (nb > cap) nb = cap;
+    std::vector<BlockRec> tmp(nb);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (nb) HIPCHK(hipMemcpy(tmp.data(), h->dRecs.p, nb * sizeof(BlockRec), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < nb; i++) { out[3 * i] = tmp[i].cycles; out[3 * i + 1] = tmp[i].visits; out[3 * i + 2] = tmp[i].emits; }
     return SWSEM_OK;
 }
 
