@@ -60,6 +60,8 @@ struct EmitView {
     uint32_t *corr;                                  // gapStartIdx when in a gap
     uint32_t *sz;                                    // 6 u32 per gap task
     uint32_t *ofs;                                   // 6 u32 per iteration: start offsets in the six streams
+    uint32_t *chunkCnt;                              // [contig][chunk] kept-match counts / offsets, 6 sums per chunk for placement
+    uint32_t ncontigs;
     uint8_t *arena;                                  // streams
     EmitOut *out;
 };
@@ -94,9 +96,10 @@ __device__ __forceinline__ uint64_t loaded_pos(const EmitView &v, uint64_t pos) 
     return pos;
 }
 
-// block-wide exclusive scan of one u32 per thread (EMIT_THREADS threads); returns the exclusive prefix,
-// *total = sum over the block
-__device__ uint32_t block_scan(uint32_t x, uint32_t *lds /* [EMIT_THREADS / WAVE + 1] */, uint32_t *total) {
+// block-wide exclusive scan of one u32 per thread (NT threads); returns the exclusive prefix,
+// *total = sum over the block. lds: NT / WAVE + 1 words.
+template <int NT>
+__device__ uint32_t block_scan(uint32_t x, uint32_t *lds, uint32_t *total) {
     const uint32_t lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     uint32_t inc = x;
     for (int d = 1; d < WAVE; d <<= 1) {
@@ -108,116 +111,161 @@ __device__ uint32_t block_scan(uint32_t x, uint32_t *lds /* [EMIT_THREADS / WAVE
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int i = 0; i < EMIT_THREADS / WAVE; i++) { const uint32_t t = lds[i]; lds[i] = run; run += t; }
-        lds[EMIT_THREADS / WAVE] = run;
+        for (int i = 0; i < NT / WAVE; i++) { const uint32_t t = lds[i]; lds[i] = run; run += t; }
+        lds[NT / WAVE] = run;
     }
     __syncthreads();
-    *total = lds[EMIT_THREADS / WAVE];
+    *total = lds[NT / WAVE];
     return lds[w] + inc - x;
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1, MBGC_Encoder.cpp:153-205
+// pass 1, MBGC_Encoder.cpp:153-205. Grid kernels: blockIdx.x = chunk of CH matches, blockIdx.y = contig.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EMIT_THREADS) k_emit_pass1(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
-    __shared__ uint32_t lds[EMIT_THREADS / WAVE + 2];
-    __shared__ unsigned long long red[2];
-    const EmitContig cg = cgs[blockIdx.x];
-    const int64_t n = v.matchCount[which[blockIdx.x]];
+constexpr int CH = 256;
+
+// (a) the locally computable part of the removal test (:176-178), taking j-1 as the kept predecessor
+__global__ void __launch_bounds__(CH) k_emit_p1_flags(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
+    const EmitContig cg = cgs[blockIdx.y];
+    const int64_t n = v.matchCount[which[blockIdx.y]];
+    const int64_t j = (int64_t) blockIdx.x * CH + threadIdx.x;
+    if (j >= n) return;
     const Match *M = v.matches + cg.matchBase;
-    const uint8_t *q = v.qbuf + cg.qoff;
-    uint8_t *tf = v.tflag + cg.scratchBase, *rm = v.removed + cg.scratchBase;
-    uint32_t *kidx = v.keepIdx + cg.scratchBase;
-    EMatch *E = v.em + cg.scratchBase;
-    const bool ext = v.p.enableExtensionsWithMismatches != 0;
-    // (a) the locally computable part of the removal test (:176-178), taking j-1 as the kept predecessor
-    for (int64_t j = threadIdx.x; j < n; j += EMIT_THREADS) {
-        bool t = false;
-        if (ext && j >= 1 && j + 1 < n)
-            t = paired(M[j + 1].posSrc, M[j + 1].posDest, M[j - 1].posSrc, M[j - 1].posDest) &&
-                !paired(M[j].posSrc, M[j].posDest, M[j - 1].posSrc, M[j - 1].posDest) &&
-                M[j].len < v.p.gapBreakingMatchMinLength;
-        tf[j] = t;
-    }
-    __threadfence_block();
+    bool t = false;
+    if (v.p.enableExtensionsWithMismatches && j >= 1 && j + 1 < n)
+        t = paired(M[j + 1].posSrc, M[j + 1].posDest, M[j - 1].posSrc, M[j - 1].posDest) &&
+            !paired(M[j].posSrc, M[j].posDest, M[j - 1].posSrc, M[j - 1].posDest) &&
+            M[j].len < v.p.gapBreakingMatchMinLength;
+    v.tflag[cg.scratchBase + j] = t;
+}
+
+// (b) a removed match keeps its successor (the successor is then paired with the kept predecessor), so
+// inside a run of the predicate the matches are removed alternately, starting with the first. Also
+// counts the kept matches of the chunk.
+__global__ void __launch_bounds__(CH) k_emit_p1_removed(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which,
+                                                        uint32_t maxChunks) {
+    __shared__ uint32_t cnt;
+    const EmitContig cg = cgs[blockIdx.y];
+    const int64_t n = v.matchCount[which[blockIdx.y]];
+    const int64_t j = (int64_t) blockIdx.x * CH + threadIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    // (b) a removed match keeps its successor (the successor is then paired with the kept predecessor),
-    // so inside a run of the predicate the matches are removed alternately, starting with the first
-    for (int64_t j = threadIdx.x; j < n; j += EMIT_THREADS) {
+    const uint8_t *tf = v.tflag + cg.scratchBase;
+    bool keep = false;
+    if (j < n) {
         bool r = false;
         if (tf[j]) {
             int64_t k = 0;
             while (j - 1 - k >= 0 && tf[j - 1 - k]) k++;
             r = (k & 1) == 0;
         }
-        rm[j] = r;
+        v.removed[cg.scratchBase + j] = r;
+        keep = !r;
     }
-    __threadfence_block();
+    const unsigned long long bal = __ballot(keep);
+    if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&cnt, (uint32_t) __popcll(bal));
     __syncthreads();
-    // (c) compaction; an abutting successor of a removed match is extended to the left (:180-186)
+    if (threadIdx.x == 0) v.chunkCnt[(size_t) blockIdx.y * maxChunks + blockIdx.x] = cnt;
+}
+
+// (c) per contig: exclusive scan of the chunk counts; resets the per-contig accumulators
+__global__ void __launch_bounds__(CH) k_emit_p1_scan(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which,
+                                                     uint32_t maxChunks) {
+    __shared__ uint32_t lds[CH / WAVE + 2];
+    const int64_t n = v.matchCount[which[blockIdx.x]];
+    const uint32_t nch = (uint32_t) ((n + CH - 1) / CH);
+    uint32_t *cc = v.chunkCnt + (size_t) blockIdx.x * maxChunks;
     uint32_t base = 0;
-    for (int64_t j0 = 0; j0 < n; j0 += EMIT_THREADS) {
-        const int64_t j = j0 + threadIdx.x;
-        const uint32_t keep = (j < n && !rm[j]) ? 1u : 0u;
+    for (uint32_t c0 = 0; c0 < nch; c0 += CH) {
+        const uint32_t c = c0 + threadIdx.x;
+        const uint32_t x = c < nch ? cc[c] : 0;
         uint32_t tot;
-        const uint32_t ex = block_scan(keep, lds, &tot);
-        if (keep) {
-            EMatch e;
-            e.posSrc = M[j].posSrc; e.len = M[j].len; e.posDest = M[j].posDest;
-            if (j >= 1 && rm[j - 1] && M[j - 1].posDest + M[j - 1].len == M[j].posDest) {
-                int64_t s = (int64_t) e.posSrc, d = (int64_t) e.posDest;
-                uint64_t x = 0;
-                while (d - 1 >= 0 && s - 1 >= 0 && q[d - 1] == v.ref[s - 1]) { d--; s--; x++; }
-                e.posSrc -= x; e.posDest -= x; e.len += x;       // shiftStartPos(-leftExtension)
-            }
-            e.lp = v.p.lazyDecompressionSupport ? loaded_pos(v, e.posSrc) : 0;
-            E[base + ex] = e;
-            kidx[base + ex] = (uint32_t) j;
-        }
+        const uint32_t ex = block_scan<CH>(x, lds, &tot);
+        if (c < nch) cc[c] = base + ex;
         base += tot;
         __syncthreads();
     }
-    const uint32_t nk = base;
-    __threadfence_block();
-    __syncthreads();
-    // (d) unmatchedChars / totalMatched with the reference's integer types (uint32 pos, :145,:193-196)
-    unsigned long long um = 0, tm = 0;
-    for (uint32_t t = threadIdx.x; t < nk; t += EMIT_THREADS) {
-        const uint32_t pos = t ? (uint32_t) (E[t - 1].posDest + E[t - 1].len) : 0u;
-        um += E[t].posDest - (uint64_t) pos;
-        tm += (uint32_t) E[t].len;
-        if (v.p.lazyDecompressionSupport) {                     // std::upper_bound, :254-256
-            uint32_t lo = 0, hi = v.nLoaded;
-            const uint64_t key = E[t].lp;
-            while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (v.loaded[mid] <= key) lo = mid + 1; else hi = mid; }
-            v.next0[cg.scratchBase + t] = lo == v.nLoaded ? UINT64_MAX : v.loaded[lo];
-        }
+    if (threadIdx.x == 0) {
+        EmitOut o;
+        for (int s = 0; s < SWSEM_NSTREAMS; s++) o.size[s] = 0;
+        o.unmatchedChars = 0; o.extMatched = 0; o.extMismatches = 0; o.totalMatched = 0;
+        o.removed = (uint64_t) (n - base);
+        o.nmatches = base;
+        v.out[blockIdx.x] = o;
     }
-    if (threadIdx.x == 0) { red[0] = 0; red[1] = 0; }
-    __syncthreads();
+}
+
+// (d) compaction; an abutting successor of a removed match is extended to the left (:180-186)
+__global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which,
+                                                        uint32_t maxChunks) {
+    __shared__ uint32_t lds[CH / WAVE + 2];
+    const EmitContig cg = cgs[blockIdx.y];
+    const int64_t n = v.matchCount[which[blockIdx.y]];
+    if ((int64_t) blockIdx.x * CH >= n) return;
+    const int64_t j = (int64_t) blockIdx.x * CH + threadIdx.x;
+    const Match *M = v.matches + cg.matchBase;
+    const uint8_t *q = v.qbuf + cg.qoff, *rm = v.removed + cg.scratchBase;
+    const uint32_t keep = (j < n && !rm[j]) ? 1u : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_scan<CH>(keep, lds, &tot);
+    if (!keep) return;
+    const uint32_t t = v.chunkCnt[(size_t) blockIdx.y * maxChunks + blockIdx.x] + ex;
+    EMatch e;
+    e.posSrc = M[j].posSrc; e.len = M[j].len; e.posDest = M[j].posDest;
+    if (j >= 1 && rm[j - 1] && M[j - 1].posDest + M[j - 1].len == M[j].posDest) {
+        int64_t s = (int64_t) e.posSrc, d = (int64_t) e.posDest;
+        uint64_t x = 0;
+        while (d - 1 >= 0 && s - 1 >= 0 && q[d - 1] == v.ref[s - 1]) { d--; s--; x++; }
+        e.posSrc -= x; e.posDest -= x; e.len += x;               // shiftStartPos(-leftExtension)
+    }
+    e.lp = v.p.lazyDecompressionSupport ? loaded_pos(v, e.posSrc) : 0;
+    v.em[cg.scratchBase + t] = e;
+    v.keepIdx[cg.scratchBase + t] = (uint32_t) j;
+    if (v.p.lazyDecompressionSupport) {                           // std::upper_bound, :254-256
+        uint32_t lo = 0, hi = v.nLoaded;
+        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (v.loaded[mid] <= e.lp) lo = mid + 1; else hi = mid; }
+        v.next0[cg.scratchBase + t] = lo == v.nLoaded ? UINT64_MAX : v.loaded[lo];
+    }
+}
+
+// (e) unmatchedChars / totalMatched with the reference's integer types (uint32 pos, :145,:193-196)
+__global__ void __launch_bounds__(CH) k_emit_p1_sums(EmitView v, const EmitContig *__restrict__ cgs) {
+    const EmitContig cg = cgs[blockIdx.y];
+    const uint32_t nk = (uint32_t) v.out[blockIdx.y].nmatches;
+    const uint32_t t = blockIdx.x * CH + threadIdx.x;
+    const EMatch *E = v.em + cg.scratchBase;
+    unsigned long long um = 0, tm = 0;
+    if (t < nk) {
+        const uint32_t pos = t ? (uint32_t) (E[t - 1].posDest + E[t - 1].len) : 0u;
+        um = E[t].posDest - (uint64_t) pos;
+        tm = (uint32_t) E[t].len;
+    }
     for (int d = WAVE / 2; d > 0; d >>= 1) {
         um += (unsigned long long) __shfl_down((long long) um, d);
         tm += (unsigned long long) __shfl_down((long long) tm, d);
     }
-    if ((threadIdx.x & (WAVE - 1)) == 0) { atomicAdd(&red[0], um); atomicAdd(&red[1], tm); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t pos = nk ? (uint32_t) (E[nk - 1].posDest + E[nk - 1].len) : 0u;
-        const int64_t unmatched = (int64_t) (red[0] + (cg.n - (uint64_t) pos));
-        EmitOut o;
-        for (int s = 0; s < SWSEM_NSTREAMS; s++) o.size[s] = 0;
-        o.unmatchedChars = (uint64_t) unmatched;
-        o.extMatched = 0; o.extMismatches = 0;
-        o.totalMatched = (uint32_t) red[1];
-        o.removed = (uint64_t) (n - nk);
-        o.nmatches = nk;
-        // :203-205 with isContigDissimilar, MGMP_Params.h:193-196
-        if (cg.processed < cg.targetIdx - v.p.allowedTargetsOutrunForDissimilarContigs &&
-            cg.n > v.p.minimalLengthForDissimilarContigs &&
-            (uint64_t) (unmatched * (int64_t) (cg.factor / v.p.unmatchedFractionFactorTweakForDissimilarContigs)) > cg.n)
-            o.unmatchedChars = UINT64_MAX;
-        v.out[blockIdx.x] = o;
+    if ((threadIdx.x & (WAVE - 1)) == 0 && (um | tm)) {
+        atomicAdd((unsigned long long *) &v.out[blockIdx.y].unmatchedChars, um);
+        atomicAdd((unsigned long long *) &v.out[blockIdx.y].totalMatched, tm);
     }
+}
+
+// (f) tail literal + the dissimilarity early-out (:200-205, isContigDissimilar MGMP_Params.h:193-196)
+__global__ void k_emit_p1_finish(EmitView v, const EmitContig *__restrict__ cgs) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (int) v.ncontigs) return;
+    const EmitContig cg = cgs[k];
+    EmitOut *o = v.out + k;
+    const uint32_t nk = (uint32_t) o->nmatches;
+    const EMatch *E = v.em + cg.scratchBase;
+    const uint32_t pos = nk ? (uint32_t) (E[nk - 1].posDest + E[nk - 1].len) : 0u;
+    const int64_t unmatched = (int64_t) (o->unmatchedChars + (cg.n - (uint64_t) pos));
+    o->totalMatched = (uint32_t) o->totalMatched;
+    o->unmatchedChars = (uint64_t) unmatched;
+    if (cg.processed < cg.targetIdx - v.p.allowedTargetsOutrunForDissimilarContigs &&
+        cg.n > v.p.minimalLengthForDissimilarContigs &&
+        (uint64_t) (unmatched * (int64_t) (cg.factor / v.p.unmatchedFractionFactorTweakForDissimilarContigs)) > cg.n)
+        o->unmatchedChars = UINT64_MAX;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -606,63 +654,95 @@ __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig
 
 // placement. Iteration t of the reference's loop emits, in this order:
 //   literals: [left codes t][plain t] MATCH_MARK [right codes t]      flags: [left flags t][right flags t]
-// where "right codes t" are produced by gap task t+1. One workgroup per contig: per-thread contiguous
-// ranges of iterations, one block scan per stream, then the start offsets of every iteration.
-__global__ void __launch_bounds__(EMIT_THREADS) k_emit_place(EmitView v, const EmitContig *__restrict__ cgs) {
-    __shared__ uint32_t lds[EMIT_THREADS / WAVE + 2];
-    const EmitContig cg = cgs[blockIdx.x];
-    const EmitOut o = v.out[blockIdx.x];
+// where "right codes t" are produced by gap task t+1. Three steps: per-chunk sums of what every
+// iteration adds to each of the six streams, a per-contig scan over the chunks, and the start offsets
+// of every iteration inside its chunk.
+struct IterSizes { uint32_t s[6]; };
+__device__ __forceinline__ IterSizes iter_sizes(const EmitView &v, const EmitContig &cg, int64_t n, int64_t t) {
+    IterSizes r;
+    const uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
+    r.s[0] = z[2] + z[4]; r.s[1] = z[3]; r.s[2] = 0; r.s[3] = 0; r.s[4] = 0; r.s[5] = 0;
+    if (t < n) {
+        const uint32_t meta = v.meta[cg.scratchBase + t];
+        r.s[0] += 1 + z[6];
+        r.s[1] += z[7];
+        if (!(meta & META_SKIPOFF)) { r.s[2] = 4; r.s[3] = v.p.enable40bitReference ? 1 : 0; }
+        r.s[4] = v.p.frugal64bitLenEncoding ? frugal_size(v.em[cg.scratchBase + t].len) : 4u;
+        r.s[5] = (meta & META_HASGAP) ? 1u : 0u;
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(CH) k_emit_place_sums(EmitView v, const EmitContig *__restrict__ cgs, uint32_t maxChunks) {
+    __shared__ uint32_t acc[6];
+    const EmitContig cg = cgs[blockIdx.y];
+    const EmitOut o = v.out[blockIdx.y];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
-    const EMatch *E = v.em + cg.scratchBase;
-    const uint32_t *SZ = v.sz + cg.scratchBase * 6;
-    uint32_t *OFS = v.ofs + cg.scratchBase * 6;
-    const bool bit40 = v.p.enable40bitReference != 0, frugal = v.p.frugal64bitLenEncoding != 0;
-    const int64_t iters = n + 1;                                       // iteration n = contig tail (plain only)
-    const int64_t per = (iters + EMIT_THREADS - 1) / EMIT_THREADS;
-    const int64_t t0 = (int64_t) threadIdx.x * per, t1 = t0 + per < iters ? t0 + per : iters;
-    uint32_t sl = 0, sf = 0, so = 0, s5 = 0, sn = 0, sg = 0;
-    for (int64_t t = t0; t < t1; t++) {
-        const uint32_t *z = SZ + t * 6;
-        sl += z[2] + z[4];
-        sf += z[3];
-        if (t < n) {
-            const uint32_t meta = v.meta[cg.scratchBase + t];
-            const uint32_t *zn = SZ + (t + 1) * 6;
-            sl += 1 + zn[0];
-            sf += zn[1];
-            if (!(meta & META_SKIPOFF)) { so += 4; s5 += bit40 ? 1 : 0; }
-            sn += frugal ? frugal_size(E[t].len) : 4u;
-            sg += (meta & META_HASGAP) ? 1u : 0u;
-        }
+    if ((int64_t) blockIdx.x * CH > n) return;
+    if (threadIdx.x < 6) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t t = (int64_t) blockIdx.x * CH + threadIdx.x;
+    IterSizes r = {{0, 0, 0, 0, 0, 0}};
+    if (t <= n) r = iter_sizes(v, cg, n, t);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        uint32_t x = r.s[k];
+        for (int d = WAVE / 2; d > 0; d >>= 1) x += (uint32_t) __shfl_down((int) x, d);
+        if ((threadIdx.x & (WAVE - 1)) == 0 && x) atomicAdd(&acc[k], x);
     }
-    uint32_t tl, tf_, to, t5, tn, tg;
-    uint32_t ol = block_scan(sl, lds, &tl);
-    uint32_t of = block_scan(sf, lds, &tf_);
-    uint32_t oo = block_scan(so, lds, &to);
-    uint32_t o5 = block_scan(s5, lds, &t5);
-    uint32_t on = block_scan(sn, lds, &tn);
-    uint32_t og = block_scan(sg, lds, &tg);
-    for (int64_t t = t0; t < t1; t++) {
-        uint32_t *w = OFS + t * 6;
-        w[0] = ol; w[1] = of; w[2] = oo; w[3] = o5; w[4] = on; w[5] = og;
-        const uint32_t *z = SZ + t * 6;
-        ol += z[2] + z[4];
-        of += z[3];
-        if (t < n) {
-            const uint32_t meta = v.meta[cg.scratchBase + t];
-            const uint32_t *zn = SZ + (t + 1) * 6;
-            ol += 1 + zn[0];
-            of += zn[1];
-            if (!(meta & META_SKIPOFF)) { oo += 4; o5 += bit40 ? 1 : 0; }
-            on += frugal ? frugal_size(E[t].len) : 4u;
-            og += (meta & META_HASGAP) ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x < 6) v.chunkCnt[((size_t) blockIdx.y * maxChunks + blockIdx.x) * 6 + threadIdx.x] = acc[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(CH) k_emit_place_scan(EmitView v, const EmitContig *__restrict__ cgs, uint32_t maxChunks) {
+    __shared__ uint32_t lds[CH / WAVE + 2];
+    const EmitOut o = v.out[blockIdx.x];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const uint32_t nch = (uint32_t) ((o.nmatches + 1 + CH - 1) / CH);
+    uint32_t *cc = v.chunkCnt + (size_t) blockIdx.x * maxChunks * 6;
+    uint32_t base[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t c0 = 0; c0 < nch; c0 += CH) {
+        const uint32_t c = c0 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint32_t x = c < nch ? cc[(size_t) c * 6 + k] : 0;
+            uint32_t tot;
+            const uint32_t ex = block_scan<CH>(x, lds, &tot);
+            if (c < nch) cc[(size_t) c * 6 + k] = base[k] + ex;
+            base[k] += tot;
+            __syncthreads();
         }
     }
     if (threadIdx.x == 0) {
         EmitOut *op = v.out + blockIdx.x;
-        op->size[SWSEM_LIT] = tl; op->size[SWSEM_FLAGS] = tf_; op->size[SWSEM_OFF] = to; op->size[SWSEM_OFF5] = t5;
-        op->size[SWSEM_LEN] = tn; op->size[SWSEM_GAP] = tg;
+        op->size[SWSEM_LIT] = base[0]; op->size[SWSEM_FLAGS] = base[1]; op->size[SWSEM_OFF] = base[2]; op->size[SWSEM_OFF5] = base[3];
+        op->size[SWSEM_LEN] = base[4]; op->size[SWSEM_GAP] = base[5];
+    }
+}
+
+__global__ void __launch_bounds__(CH) k_emit_place_final(EmitView v, const EmitContig *__restrict__ cgs, uint32_t maxChunks) {
+    __shared__ uint32_t lds[CH / WAVE + 2];
+    const EmitContig cg = cgs[blockIdx.y];
+    const EmitOut o = v.out[blockIdx.y];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const int64_t n = (int64_t) o.nmatches;
+    if ((int64_t) blockIdx.x * CH > n) return;
+    const int64_t t = (int64_t) blockIdx.x * CH + threadIdx.x;
+    IterSizes r = {{0, 0, 0, 0, 0, 0}};
+    if (t <= n) r = iter_sizes(v, cg, n, t);
+    const uint32_t *cb = v.chunkCnt + ((size_t) blockIdx.y * maxChunks + blockIdx.x) * 6;
+    uint32_t out[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        uint32_t tot;
+        out[k] = cb[k] + block_scan<CH>(r.s[k], lds, &tot);
+        __syncthreads();
+    }
+    if (t <= n) {
+        uint32_t *w = v.ofs + (cg.scratchBase + t) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; k++) w[k] = out[k];
     }
 }
 

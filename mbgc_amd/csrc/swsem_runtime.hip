@@ -91,7 +91,7 @@ struct swsem {
     DevBuf<EMatch> dEM;
     DevBuf<uint64_t> dENext0, dELoaded;
     DevBuf<uint8_t> dETf, dERm, dEArena;
-    DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs;
+    DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs, dEChunk;
     DevBuf<MetaState> dEStates;
     std::vector<EmitContig> ecg;
     std::vector<EmitOut> eout;
@@ -402,7 +402,7 @@ void swsem_destroy(swsem_t *h) {
     h->dPrev.release(); h->dRbContig.release();
     h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
     h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
-    h->dESz.release(); h->dEOfs.release(); h->dEStates.release();
+    h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -714,16 +714,27 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     uint64_t maxRows = 0;
     for (int k = 0; k < n; k++) maxRows = std::max<uint64_t>(maxRows, h->ecg[k].cap);
     const uint32_t metaBlocks = (uint32_t) ((maxRows + META_BLOCK - 1) / META_BLOCK);
-    const uint32_t taskChunks = (uint32_t) ((maxRows + 255) / 256);
+    const uint32_t chunks = (uint32_t) ((maxRows + CH - 1) / CH);
     if ((r = h->dEStates.reserve((size_t) n * metaBlocks * 2))) return r;
+    if ((r = h->dEChunk.reserve((size_t) n * chunks * 6))) return r;
     v.ofs = h->dEOfs.p;
+    v.chunkCnt = h->dEChunk.p;
+    v.ncontigs = (uint32_t) n;
+    const dim3 grid2(chunks, n);
     h->mark(SWSEM_K_EMIT, true);
-    k_emit_pass1<<<dim3(n), dim3(EMIT_THREADS), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
+    k_emit_p1_flags<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
+    k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p, chunks);
+    k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p, chunks);
+    k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p, chunks);
+    k_emit_p1_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_p1_finish<<<dim3((n + 63) / 64), dim3(64), 0, h->stream>>>(v, h->dECg.p);
     k_emit_meta_blocks<<<dim3(metaBlocks, n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p, metaBlocks);
     k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p, metaBlocks, h->dStats.p);
-    k_emit_sizes<<<dim3(taskChunks, n), dim3(256), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_place<<<dim3(n), dim3(EMIT_THREADS), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_write<<<dim3(taskChunks, n), dim3(256), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_sizes<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
+    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
+    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
+    k_emit_write<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
     h->mark(SWSEM_K_EMIT, false);
     HIPCHK(hipGetLastError());
     h->eout.resize(n);
