@@ -70,6 +70,12 @@ uint32_t swsem_get_hash_size(const swsem_t *h);
 int swsem_load_ref(swsem_t *h, const uint8_t *text, uint64_t len, int loadRC, int addSep, int sep);
 int swsem_load_ref_dev(swsem_t *h, const uint8_t *text_dev, uint64_t len, int loadRC, int addSep, int sep);
 int swsem_load_separator(swsem_t *h, int sep);                    /* loadSeparator, .cpp:439-451 */
+/* finalizeParallelProcessingOfTarget for n targets in target order (MGMP.cpp:440-457 + MBGC_Encoder.cpp:557-562):
+ * per target loadRef(ext, len, false, addSep, sep), then — lazy mode — loadSeparator(sep), then
+ * releaseWorkerMatchingLockPos(lockPos[i]) (lockPos may be NULL). loadedAfter[i] receives
+ * getLoadedRefLength() after target i. One call per round instead of 3 n. */
+int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
+                           int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter);
 /* PgHelpers::upperReverseComplement(src, n, dst) on device buffers, utils/helper.cpp:405-410 — what
  * processTarget uses to append a contig's reverse complement to the target's extension string
  * (MGMP.cpp:393-398) */

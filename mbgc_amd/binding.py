@@ -20,7 +20,7 @@ EXPORTS = """swsem_last_error swsem_device_count swsem_create swsem_destroy swse
 swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circular_buffer swsem_get_ref_length
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
-swsem_load_separator swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
+swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
 swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_copy""".split()
 
@@ -88,6 +88,7 @@ def lib():
         L.swsem_load_ref_dev.argtypes = [vp, vp, u64, ci, ci, ci]
         L.swsem_load_separator.argtypes = [vp, ci]
         L.swsem_revcomp_dev.argtypes = [vp, vp, u64, vp]
+        L.swsem_finalize_targets.argtypes = [vp, ci, vp, pu64, ci, ci, ci, pu64, pu64]
         L.swsem_match.argtypes = [vp, vp, u64, C.c_uint32, u64, C.POINTER(vp), pu64]
         L.swsem_match_batch_dev.argtypes = [vp, vp, pu64, ci, C.c_uint32, pu64]
         L.swsem_batch_counts.argtypes = [vp, pu64]
@@ -170,6 +171,19 @@ class SlidingWindowSparseEMMatcher:
         _chk(lib().swsem_load_ref_dev(self.h, dev_ptr, n, int(load_rc), int(add_sep), sep))
 
     def load_separator(self, sep=0): _chk(lib().swsem_load_separator(self.h, sep))
+
+    def finalize_targets(self, ext_ptrs, ext_lens, locks, lazy=True, add_sep=True, sep=0):
+        """loadRef(ext) [+ loadSeparator] + releaseWorkerMatchingLockPos for n targets in order; returns
+        getLoadedRefLength() after each target."""
+        n = len(ext_lens)
+        ptrs = (C.c_void_p * n)(*[int(p) for p in ext_ptrs])
+        lens = np.ascontiguousarray(ext_lens, dtype=np.uint64)
+        lk = np.ascontiguousarray(locks, dtype=np.uint64)
+        out = np.zeros(n, dtype=np.uint64)
+        P = C.POINTER(C.c_uint64)
+        _chk(lib().swsem_finalize_targets(self.h, n, ptrs, lens.ctypes.data_as(P), int(add_sep), sep, int(lazy),
+                                          lk.ctypes.data_as(P), out.ctypes.data_as(P)))
+        return out
     def revcomp_dev(self, src_ptr, n, dst_ptr): _chk(lib().swsem_revcomp_dev(self.h, src_ptr, n, dst_ptr))
 
     # --- matching

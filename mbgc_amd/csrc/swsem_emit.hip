@@ -62,6 +62,7 @@ struct EmitView {
     uint32_t *ofs;                                   // 6 u32 per iteration: start offsets in the six streams
     uint32_t *chunkCnt;                              // [contig][chunk] kept-match counts / offsets, 6 sums per chunk for placement
     uint32_t ncontigs;
+    uint64_t *packBase;                              // [contig][stream] start of the stream in the packed arena
     uint8_t *arena;                                  // streams
     EmitOut *out;
 };
@@ -721,6 +722,17 @@ __global__ void __launch_bounds__(CH) k_emit_place_scan(EmitView v, const EmitCo
     }
 }
 
+// the six streams of all contigs back to back, (contig, stream) major: the arena is written packed
+__global__ void k_emit_packoffs(EmitView v) {
+    if (threadIdx.x | blockIdx.x) return;
+    uint64_t run = 0;
+    for (uint32_t k = 0; k < v.ncontigs; k++)
+        for (int s = 0; s < SWSEM_NSTREAMS; s++) {
+            v.packBase[(size_t) k * SWSEM_NSTREAMS + s] = run;
+            run += v.out[k].unmatchedChars == UINT64_MAX ? 0 : v.out[k].size[s];
+        }
+}
+
 __global__ void __launch_bounds__(CH) k_emit_place_final(EmitView v, const EmitContig *__restrict__ cgs, uint32_t maxChunks) {
     __shared__ uint32_t lds[CH / WAVE + 2];
     const EmitContig cg = cgs[blockIdx.y];
@@ -760,7 +772,8 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
     const uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
     const uint32_t *w = v.ofs + (cg.scratchBase + t) * 6;
     const bool bit40 = v.p.enable40bitReference != 0, frugal = v.p.frugal64bitLenEncoding != 0;
-    uint8_t *lLit = v.arena + cg.streamBase[SWSEM_LIT] + w[0], *lFl = v.arena + cg.streamBase[SWSEM_FLAGS] + w[1];
+    const uint64_t *pb = v.packBase + (size_t) blockIdx.y * SWSEM_NSTREAMS;
+    uint8_t *lLit = v.arena + pb[SWSEM_LIT] + w[0], *lFl = v.arena + pb[SWSEM_FLAGS] + w[1];
     uint8_t *plainDst = lLit + z[2];
     for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
     if (t == n) return;
@@ -779,12 +792,12 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
     }
     const uint32_t meta = v.meta[cg.scratchBase + t];
     if (!(meta & META_SKIPOFF)) {
-        put_bytes(v.arena + cg.streamBase[SWSEM_OFF] + w[2], (uint32_t) E[t].posSrc, 4);
-        if (bit40) v.arena[cg.streamBase[SWSEM_OFF5] + w[3]] = (uint8_t) (E[t].posSrc >> 32);
+        put_bytes(v.arena + pb[SWSEM_OFF] + w[2], (uint32_t) E[t].posSrc, 4);
+        if (bit40) v.arena[pb[SWSEM_OFF5] + w[3]] = (uint8_t) (E[t].posSrc >> 32);
     }
-    if (frugal) frugal_write(v.arena + cg.streamBase[SWSEM_LEN] + w[4], E[t].len);
-    else put_bytes(v.arena + cg.streamBase[SWSEM_LEN] + w[4], (uint32_t) E[t].len, 4);
-    if (meta & META_HASGAP) v.arena[cg.streamBase[SWSEM_GAP] + w[5]] = (uint8_t) (meta >> 8);
+    if (frugal) frugal_write(v.arena + pb[SWSEM_LEN] + w[4], E[t].len);
+    else put_bytes(v.arena + pb[SWSEM_LEN] + w[4], (uint32_t) E[t].len, 4);
+    if (meta & META_HASGAP) v.arena[pb[SWSEM_GAP] + w[5]] = (uint8_t) (meta >> 8);
 }
 
 }  // namespace swk

@@ -89,7 +89,7 @@ struct swsem {
     DevBuf<EmitOut> dEOut;
     DevBuf<int> dEWhich;
     DevBuf<EMatch> dEM;
-    DevBuf<uint64_t> dENext0, dELoaded;
+    DevBuf<uint64_t> dENext0, dELoaded, dEPack;
     DevBuf<uint8_t> dETf, dERm, dEArena;
     DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs, dEChunk;
     DevBuf<MetaState> dEStates;
@@ -98,6 +98,8 @@ struct swsem {
     std::vector<uint8_t> hostStreams;
     std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
+    bool hostStreamsValid = false;
+    uint64_t packedBytes = 0;
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 4;                       // probe tiles per resolve block (SWSEM_RB)
     std::vector<Contig> contigs;
@@ -402,7 +404,7 @@ void swsem_destroy(swsem_t *h) {
     h->dPrev.release(); h->dRbContig.release();
     h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
     h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
-    h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release();
+    h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release(); h->dEPack.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -492,6 +494,22 @@ int swsem_load_separator(swsem_t *h, int sep) {
     else
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1++, (uint8_t) sep);
     HIPCHK(hipGetLastError());
+    return SWSEM_OK;
+}
+
+// finalizeParallelProcessingOfTarget for n targets in order (MGMP.cpp:440-457, MBGC_Encoder.cpp:557-562):
+// loadRef of the target's extension, the lazy-mode region separator, release of its lock position.
+// loadedAfter[i] = getLoadedRefLength() after target i (what the encoder appends to refExtLoadedPosArr).
+int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
+                           int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter) {
+    HIPCHK(hipSetDevice(h->device));
+    for (int i = 0; i < n; i++) {
+        int r;
+        if (ext_len[i] && (r = load_pieces(h, ext_dev[i], ext_len[i], false, addSep != 0, sep))) return r;
+        if (lazySeparator && (r = swsem_load_separator(h, sep))) return r;
+        if (loadedAfter) loadedAfter[i] = swsem_get_loaded_ref_length(h);
+        if (lockPos && (r = swsem_release_lock(h, lockPos[i]))) return r;
+    }
     return SWSEM_OK;
 }
 
@@ -717,6 +735,8 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     const uint32_t chunks = (uint32_t) ((maxRows + CH - 1) / CH);
     if ((r = h->dEStates.reserve((size_t) n * metaBlocks * 2))) return r;
     if ((r = h->dEChunk.reserve((size_t) n * chunks * 6))) return r;
+    if ((r = h->dEPack.reserve((size_t) n * SWSEM_NSTREAMS))) return r;
+    v.packBase = h->dEPack.p;
     v.ofs = h->dEOfs.p;
     v.chunkCnt = h->dEChunk.p;
     v.ncontigs = (uint32_t) n;
@@ -733,6 +753,7 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     k_emit_sizes<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
     k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
     k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
+    k_emit_packoffs<<<1, 1, 0, h->stream>>>(v);
     k_emit_place_final<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
     k_emit_write<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
     h->mark(SWSEM_K_EMIT, false);
@@ -743,15 +764,19 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     uint64_t tot = 0;
     h->hostStreamOff.assign((size_t) n * SWSEM_NSTREAMS, 0);
     for (int k = 0; k < n; k++)
-        for (int st = 0; st < SWSEM_NSTREAMS; st++) { h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st] = tot; tot += h->eout[k].size[st]; }
+        for (int st = 0; st < SWSEM_NSTREAMS; st++) {
+            if (h->eout[k].unmatchedChars == UINT64_MAX) h->eout[k].size[st] = 0;
+            h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st] = tot;       // == packBase on the device
+            tot += h->eout[k].size[st];
+        }
+    h->packedBytes = tot;
     h->hostStreams.resize(tot + 1);
-    if (!h->emitHostCopy) return SWSEM_OK;
-    for (int k = 0; k < n; k++)
-        for (int st = 0; st < SWSEM_NSTREAMS; st++)
-            if (h->eout[k].size[st])
-                HIPCHK(hipMemcpyAsync(h->hostStreams.data() + h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st],
-                                      h->dEArena.p + h->ecg[k].streamBase[st], h->eout[k].size[st], hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->hostStreamsValid = false;
+    if (h->emitHostCopy) {
+        if (tot) HIPCHK(hipMemcpyAsync(h->hostStreams.data(), h->dEArena.p, tot, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->hostStreamsValid = true;
+    }
     return SWSEM_OK;
 }
 
@@ -763,32 +788,27 @@ int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched) {
     return SWSEM_OK;
 }
 
-// Packs every stream of the last emit batch back to back, (result, stream) major, into a device buffer.
+// The arena is written packed — every stream of the last emit batch back to back, (result, stream)
+// major — so handing it on is one device-to-device copy.
 int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total) {
     HIPCHK(hipSetDevice(h->device));
-    uint64_t tot = 0;
-    for (size_t k = 0; k < h->eout.size(); k++)
-        for (int st = 0; st < SWSEM_NSTREAMS; st++) {
-            const uint64_t sz = h->eout[k].size[st];
-            if (sizes) sizes[k * SWSEM_NSTREAMS + st] = sz;
-            if (dst_dev && sz) {
-                if (tot + sz > cap) return fail(SWSEM_EINVAL, "swsem_emit_pack_dev: buffer too small");
-                HIPCHK(hipMemcpyAsync(dst_dev + tot, h->dEArena.p + h->ecg[k].streamBase[st], sz, hipMemcpyDeviceToDevice, h->stream));
-            }
-            tot += sz;
-        }
-    if (total) *total = tot;
+    if (sizes)
+        for (size_t k = 0; k < h->eout.size(); k++)
+            for (int st = 0; st < SWSEM_NSTREAMS; st++) sizes[k * SWSEM_NSTREAMS + st] = h->eout[k].size[st];
+    if (dst_dev && h->packedBytes) {
+        if (h->packedBytes > cap) return fail(SWSEM_EINVAL, "swsem_emit_pack_dev: buffer too small");
+        HIPCHK(hipMemcpyAsync(dst_dev, h->dEArena.p, h->packedBytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (total) *total = h->packedBytes;
     return SWSEM_OK;
 }
 
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
     if (k < 0 || k >= (int) h->eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
-    if (!h->emitHostCopy) {
-        for (int st = 0; st < SWSEM_NSTREAMS; st++)
-            if (h->eout[k].size[st])
-                HIPCHK(hipMemcpyAsync(h->hostStreams.data() + h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st],
-                                      h->dEArena.p + h->ecg[k].streamBase[st], h->eout[k].size[st], hipMemcpyDeviceToHost, h->stream));
+    if (!h->hostStreamsValid) {
+        if (h->packedBytes) HIPCHK(hipMemcpyAsync(h->hostStreams.data(), h->dEArena.p, h->packedBytes, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        h->hostStreamsValid = true;
     }
     const EmitOut &o = h->eout[k];
     for (int st = 0; st < SWSEM_NSTREAMS; st++) {

@@ -211,33 +211,35 @@ class RoundRunner:
             pieces.append(ext)
             lens.append(ext.numel())
         if self.world == 1:
-            for t, ext in zip(my, pieces):
-                self._finalize_one(ext, locks[t])
+            self._finalize_many(pieces, [locks[t] for t in my])
             return
         local = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=self.device)
         all_ext = self._allgather_bytes(local)
         all_lens = self._allgather_ints(lens + [-1])           # -1 terminator keeps the tensor non-empty
         cur = [0] * self.world
         idx = [0] * self.world
+        exts = []
         for t in range(lo, hi):                                # global target order = rank-major in the round
             r = t // T
             ln = all_lens[r][idx[r]]
-            self._finalize_one(all_ext[r][cur[r]: cur[r] + ln], locks[t])
+            exts.append(all_ext[r][cur[r]: cur[r] + ln])
             cur[r] += ln
             idx[r] += 1
+        self._finalize_many(exts, [locks[t] for t in range(lo, hi)])
 
-    def _finalize_one(self, ext, lock):
+    def _finalize_many(self, exts, locks):
+        """finalizeParallelProcessingOfTarget for consecutive targets in one call into the library:
+        loadRef(ext), lazy-mode separator, lock release (MGMP.cpp:440-457, MBGC_Encoder.cpp:557-563)"""
         m = self.m
-        start = m.loaded_ref_length()
-        if ext.numel():
-            m.load_ref_dev(ext.data_ptr(), ext.numel(), False, True, 0)                 # :441-443
-        if self.lazy:                                                                    # MBGC_Encoder.cpp:557-562
-            m.load_separator(0)
-            self.ref_ext_sizes += frugal64(m.loaded_ref_length() - start)
-            if self.loaded is not None:
-                self.loaded.append(m.loaded_ref_length())
-        self.locks_stream += int(lock).to_bytes(8, "little")                            # :563
-        m.release_lock(lock)                                                             # MGMP.cpp:456
+        before = m.loaded_ref_length()
+        after = m.finalize_targets([e.data_ptr() if e.numel() else 0 for e in exts], [e.numel() for e in exts], locks, self.lazy)
+        for lk, a in zip(locks, after):
+            if self.lazy:
+                self.ref_ext_sizes += frugal64(int(a) - before)
+                if self.loaded is not None:
+                    self.loaded.append(int(a))
+                before = int(a)
+            self.locks_stream += int(lk).to_bytes(8, "little")
 
     def _collect_streams(self, packs, targets, T, offsets):
         """per-target stream merge in target order on rank 0 (MBGC_Encoder.cpp:542-556)."""

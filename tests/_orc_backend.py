@@ -28,6 +28,17 @@ class OracleDeviceMatcher:
     def load_ref_dev(self, ptr, n, load_rc=False, add_sep=True, sep=0):
         self.o.load_ref(_view(ptr, n).copy(), load_rc, add_sep, sep)
 
+    def finalize_targets(self, ext_ptrs, ext_lens, locks, lazy=True, add_sep=True, sep=0):
+        out = []
+        for p, n, lk in zip(ext_ptrs, ext_lens, locks):
+            if n:
+                self.o.load_ref(_view(p, n).copy(), False, add_sep, sep)
+            if lazy:
+                self.o.load_separator(sep)
+            out.append(self.o.loaded_ref_length())
+            assert self.o.release_lock(int(lk)) == 0
+        return np.array(out, dtype=np.uint64)
+
     def revcomp_dev(self, src, n, dst):
         _view(dst, n)[:] = _driver.revcomp(_view(src, n))
 
