@@ -91,10 +91,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+    # rehearsal hooks (one-GPU box): MBGC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, MBGC_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device). The driver's runs use neither.
+    if os.environ.get("MBGC_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MBGC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mbgc_amd import binding, synth
     from mbgc_amd.rounds import RoundRunner, round_schedule

@@ -46,6 +46,29 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
     atomicMax(&ht[h & mask], key);
 }
 
+// The same for several loadRef pieces in one launch. Epochs make the result independent of the order in
+// which the samples arrive, so all pieces of a round are inserted concurrently once their bytes (and the
+// separators) are in place. first[p] = index of piece p's first thread (prefix sums, first[np] = total).
+struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, pad; };
+__global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
+                                                      const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first,
+                                                      int np, int k1, int k1ord, int K, uint32_t mask) {
+    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= first[np]) return;
+    int lo = 0, hi = np;                               // largest p with first[p] <= g
+    while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (first[mid] <= g) lo = mid; else hi = mid; }
+    const InsertPiece pc = pieces[lo];
+    const uint64_t t = g - first[lo];
+    const bool tail = t >= pc.nMain;
+    const uint64_t p = tail ? pc.T + (t - pc.nMain) * (uint64_t) k1 : pc.S + t * (uint64_t) k1;
+    const uint8_t *s = ref + p;
+    uint32_t h = (uint32_t) K;
+    const int nw = K / 4;
+    for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
+    const ht_entry key = ((ht_entry) (pc.epoch + (tail ? 1u : 0u)) << 32) | (ht_entry) (uint32_t) (p >> k1ord);
+    atomicMax(&ht[h & mask], key);
+}
+
 __global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict__ ht, uint32_t *__restrict__ out, uint64_t n) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (uint32_t) ht[i];

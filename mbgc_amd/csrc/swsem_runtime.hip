@@ -75,6 +75,10 @@ struct swsem {
     bool circular = true;
     std::deque<uint64_t> locks;            // workersSwEndPositions
     uint32_t epoch = 1;
+    bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
+    std::vector<InsertPiece> pendingPieces;
+    DevBuf<InsertPiece> dPieces;
+    DevBuf<uint64_t> dPieceFirst;
     // --- per-round scratch
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
@@ -188,7 +192,11 @@ int insert_samples(swsem *h) {
     uint64_t nTail = 0;
     if (T < E + 1) nTail = (uint64_t) ((E - T) / h->k1 + 1);
     const uint64_t total = nMain + nTail;
-    if (total) {
+    if (total && h->deferInserts) {
+        InsertPiece pc;
+        pc.S = (uint64_t) S; pc.nMain = nMain; pc.T = (uint64_t) T; pc.nTail = nTail; pc.epoch = h->epoch; pc.pad = 0;
+        h->pendingPieces.push_back(pc);
+    } else if (total) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, h->stream>>>(
             h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch);
@@ -231,6 +239,30 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
         len = (uint64_t) h->pos1 == tmpEnd ? 0 : len - tmpLength;
     }
     HIPCHK(hipGetLastError());
+    return SWSEM_OK;
+}
+
+int flush_inserts(swsem *h);
+}  // namespace
+// (defined below, after run_batch's helpers)
+namespace {
+// one launch for every insertion phase collected while deferInserts was set
+int flush_inserts(swsem *h) {
+    const int np = (int) h->pendingPieces.size();
+    if (!np) return SWSEM_OK;
+    std::vector<uint64_t> first(np + 1, 0);
+    for (int i = 0; i < np; i++) first[i + 1] = first[i] + h->pendingPieces[i].nMain + h->pendingPieces[i].nTail;
+    int r;
+    if ((r = h->dPieces.reserve(np)) || (r = h->dPieceFirst.reserve(np + 1))) return r;
+    HIPCHK(hipMemcpyAsync(h->dPieces.p, h->pendingPieces.data(), np * sizeof(InsertPiece), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dPieceFirst.p, first.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    h->mark(SWSEM_K_INSERT, true);
+    k_insert_multi<<<dim3((unsigned) ((first[np] + 255) / 256)), dim3(256), 0, h->stream>>>(h->ref, h->ht, h->dPieces.p, h->dPieceFirst.p,
+                                                                                         np, h->k1, h->k1ord, h->K, h->mask);
+    h->mark(SWSEM_K_INSERT, false);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));      // the host tables above are stack/vector storage
+    h->pendingPieces.clear();
     return SWSEM_OK;
 }
 
@@ -405,6 +437,7 @@ void swsem_destroy(swsem_t *h) {
     h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
     h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
     h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release(); h->dEPack.release();
+    h->dPieces.release(); h->dPieceFirst.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -489,8 +522,11 @@ int swsem_load_separator(swsem_t *h, int sep) {
         h->samplingPos = REF_SHIFT;
     }
     if ((uint64_t) h->pos1 == h->maxRefLength) return SWSEM_OK;
-    if ((uint64_t) h->pos1 == h->swEnd)
+    if ((uint64_t) h->pos1 == h->swEnd) {
+        // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was
+        if (h->deferInserts) { int r = flush_inserts(h); if (r) return r; }
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1 - 1, (uint8_t) sep);
+    }
     else
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1++, (uint8_t) sep);
     HIPCHK(hipGetLastError());
@@ -503,14 +539,19 @@ int swsem_load_separator(swsem_t *h, int sep) {
 int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
                            int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter) {
     HIPCHK(hipSetDevice(h->device));
-    for (int i = 0; i < n; i++) {
-        int r;
-        if (ext_len[i] && (r = load_pieces(h, ext_dev[i], ext_len[i], false, addSep != 0, sep))) return r;
-        if (lazySeparator && (r = swsem_load_separator(h, sep))) return r;
-        if (loadedAfter) loadedAfter[i] = swsem_get_loaded_ref_length(h);
-        if (lockPos && (r = swsem_release_lock(h, lockPos[i]))) return r;
+    // all byte writes of the round first (copies, region separators), then every insertion phase in one
+    // launch: hashing a window needs its bytes — including a separator written by a later step — in place
+    h->deferInserts = true;
+    int r = SWSEM_OK;
+    for (int i = 0; i < n && !r; i++) {
+        if (ext_len[i]) r = load_pieces(h, ext_dev[i], ext_len[i], false, addSep != 0, sep);
+        if (!r && lazySeparator) r = swsem_load_separator(h, sep);
+        if (!r && loadedAfter) loadedAfter[i] = swsem_get_loaded_ref_length(h);
+        if (!r && lockPos) r = swsem_release_lock(h, lockPos[i]);
     }
-    return SWSEM_OK;
+    h->deferInserts = false;
+    const int r2 = flush_inserts(h);
+    return r ? r : r2;
 }
 
 int swsem_match_batch_dev(swsem_t *h, const uint8_t *q, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {

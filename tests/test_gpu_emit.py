@@ -143,13 +143,15 @@ def test_emit_batch_matches_per_contig_calls(binding):
         compare(streams, oe.streams())
 
 
-def test_round_runner_equals_driver_rounds(binding):
-    """mbgc_amd.rounds.RoundRunner (the product's round protocol, device-resident) against the reference
-    loop restated in tests/_driver.py driven on the oracle: same streams, lock and refExtSize bytes."""
+@pytest.mark.parametrize("lim,div", [(3_000_000, 0.012), (700_000, 0.012), (500_000, 0.07)])
+def test_round_runner_equals_driver_rounds(binding, lim, div):
+    """mbgc_amd.rounds.RoundRunner (the product's round protocol, device-resident, batched finalize with one
+    insertion launch per round) against the reference loop restated in tests/_driver.py driven on the
+    oracle: same streams, lock and refExtSize bytes, same hash table — also across circular wraps and
+    with dissimilar-contig retries."""
     import torch
     from mbgc_amd.rounds import RoundRunner
-    gs = small_collection(13, 90_000, 0.012, seed=5)
-    lim = 3_000_000
+    gs = small_collection(13, 90_000, div, seed=5)
     h = binding.SlidingWindowSparseEMMatcher(lim)
     o = _orc.OracleMatcher(lim)
     R = 4
