@@ -26,6 +26,10 @@ ALG_BYTES_PER_BASE = 5.5             # whole path, per input b
 # share of the probe kernel in that figure: query scan 1 B + 0.29 sequential table probes x 4 B
 ALG_BYTES_PROBE = 1.0 + 4 * 0.29
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
+# HBM bytes k_probe moves per query position, from the PMC passes in profiles/r01_pmc_hbm_traffic.json
+# (FETCH_SIZE 5.02e6 KB + WRITE_SIZE 3.16e5 KB per 80 M positions: one 64-B request per table gather,
+# 1 B of query, 4 B of candidate array)
+PROBE_TRAFFIC_PER_POS = (5022864.9 + 315628.5) * 1024 / (16 * (5_000_000 - 27))
 
 
 def cpu_baseline(sample_targets, length, emit):
@@ -179,7 +183,9 @@ def main():
                        "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": MAX_REF_LEN,
                        "hash_entries": m.hash_size(), "sharding": "file-per-GPU, all-gather of extensions"},
             "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                         "traffic": round(PROBE_TRAFFIC_PER_POS * R * (args.length - 27)),
+                         "traffic_GBs": round(PROBE_TRAFFIC_PER_POS * R * (args.length - 27) / (probe_ms * 1e-3) / 1e9, 1) if probe_ms else 0.0,
                          "alg_bytes_per_base": ALG_BYTES_PROBE, "avg_launch_ms": round(probe_ms, 4),
                          "whole_step_frac": round(ALG_BYTES_PER_BASE * value / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items()},
