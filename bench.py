@@ -153,8 +153,10 @@ def main():
     m.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
+    replayed = 0
     for s in range(warm, warm + steps):
         tot_matches += int(runner.run_round(*bufs[s]).sum())
+        replayed += m.batch_stats()["replayed_blocks"]
     barrier()
     dt = time.perf_counter() - t0
     prof = m.profile_get()
@@ -190,7 +192,7 @@ def main():
                          "whole_step_frac": round(ALG_BYTES_PER_BASE * value / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items()},
             "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof}, "dominant_kernel": dom,
-            "matches_per_step": tot_matches // steps, "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
+            "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps, "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit)
