@@ -163,6 +163,7 @@ struct Chain {
     int32_t minKeep;       // lowest keepCount of an emission since the last reset
     int32_t visited;       // hits visited since the last reset
     uint32_t cands;        // candidates fetched (diagnostics)
+    bool emitted;          // set by an emission (cleared by whoever watches for it)
 };
 
 constexpr int RING = 64;
@@ -175,9 +176,24 @@ __device__ __forceinline__ uint64_t rfl64(uint64_t x) { return ((uint64_t) rfl32
 constexpr int OVERLAP = 1024;          // warm-up positions of a speculative block chain (<= TILE)
 constexpr int SNAP = 4;                // stack elements snapshotted at a block boundary / end
 
+// A row of a block chain's stack: the match plus the scan position the chain had right after emitting it.
+// Two chains that emit the same row and have the same scan position afterwards are in the same state as
+// far as everything above that row is concerned (k_stitch re-synchronises a replay on that).
+struct __attribute__((aligned(16))) Row {
+    uint64_t posSrc, len, posDest;
+    int64_t scanAfter;
+};
+__device__ __forceinline__ void put_row(Match *dst, const Match &m, int64_t) { *dst = m; }
+__device__ __forceinline__ void put_row(Row *dst, const Match &m, int64_t scan) {
+    Row r;
+    r.posSrc = m.posSrc; r.len = m.len; r.posDest = m.posDest; r.scanAfter = scan;
+    *dst = r;
+}
+
 // A chain's match stack held in one array (global memory) with the top RING entries mirrored in LDS.
+template <class R>
 struct ArrayStack {
-    Match *st;
+    R *st;
     uint2 *ring;
     int32_t sp, ringLow;
     __device__ __forceinline__ int size() const { return sp; }
@@ -190,9 +206,9 @@ struct ArrayStack {
         }
     }
     // resMatches.resize(keep); resMatches.push_back(m)   (.cpp:299-300)
-    __device__ __forceinline__ void truncate_push(int keep, const Match &m) {
+    __device__ __forceinline__ void truncate_push(int keep, const Match &m, int64_t scanAfter) {
         sp = keep;
-        if ((threadIdx.x & (WAVE - 1)) == 0) st[sp] = m;
+        if ((threadIdx.x & (WAVE - 1)) == 0) put_row(st + sp, m, scanAfter);
         ring[sp & (RING - 1)] = make_uint2((uint32_t) m.posDest, (uint32_t) m.len);
         if (sp - (RING - 1) > ringLow) ringLow = sp - (RING - 1);
         if (ringLow > sp) ringLow = sp;
@@ -206,19 +222,19 @@ struct ArrayStack {
 // The newest segment's row count and predecessor live in registers (topKeep, topPrev); keepN[] in
 // memory is valid for every segment below it.
 struct VirtStack {
-    Match *region;            // block regions of this contig
+    Row *region;              // block regions of this contig
     uint32_t cap;             // rows per block region
     uint32_t *segStart, *keepN;
     int32_t *prev;
     int32_t segTop;           // newest non-empty segment, -1 if none
     int32_t topKeep, topPrev; // rows / predecessor of segTop
     int32_t size_;            // rows in the whole list
-    Match *own; int32_t ownN; // pushes of the block being replayed
+    Row *own; int32_t ownN;   // pushes of the block being replayed
     int32_t curSeg, curLocal, curR;   // cursor: element curLocal of segment curSeg is curR rows below the top of the segments
     __device__ __forceinline__ int size() const { return size_; }
     __device__ __forceinline__ int keep_of(int seg) const { return seg == segTop ? topKeep : (int) rfl32(keepN[seg]); }
     __device__ __forceinline__ int prev_of(int seg) const { return seg == segTop ? topPrev : (int) rfl32((uint32_t) prev[seg]); }
-    __device__ const Match *at(int idx) {
+    __device__ const Row *at(int idx) {
         const int below = size_ - ownN;              // rows held by the segments
         if (idx >= below) return own + (idx - below);
         const int r = below - 1 - idx;
@@ -231,7 +247,7 @@ struct VirtStack {
         return region + (uint64_t) curSeg * cap + rfl32(segStart[curSeg]) + curLocal;
     }
     __device__ __forceinline__ void get(int idx, int64_t &posDest, int64_t &len) {
-        const Match *m = at(idx);
+        const Row *m = at(idx);
         posDest = (int64_t) rfl64(m->posDest); len = (int64_t) rfl64(m->len);
     }
     __device__ void pop_segments(int p) {
@@ -249,12 +265,12 @@ struct VirtStack {
         }
         curSeg = -1;
     }
-    __device__ void truncate_push(int keep, const Match &m) {
+    __device__ void truncate_push(int keep, const Match &m, int64_t scanAfter) {
         int p = size_ - keep;
         const int t = p < ownN ? p : ownN;
         ownN -= t; p -= t;
         if (p > 0) pop_segments(p);
-        if ((threadIdx.x & (WAVE - 1)) == 0) own[ownN] = m;
+        if ((threadIdx.x & (WAVE - 1)) == 0) put_row(own + ownN, m, scanAfter);
         ownN++;
         size_ = keep + 1;
     }
@@ -403,11 +419,12 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
             m.posSrc = (uint64_t) ((int64_t) c - s + 1);
             m.len = (uint64_t) (K + rext + s - 1);
             m.posDest = (uint64_t) (i - s + 1);
-            stk.truncate_push(keep, m);
-            if (keep < ch.minKeep) ch.minKeep = keep;
             int64_t skip = K + rext;                 // (matchEnd - i2), k2 == 1, .cpp:308
             skip -= skip > v.skipMargin ? v.skipMargin : skip;
             ch.scan = skip ? i + skip : i + 1;       // .cpp:310-313 then the loop's i2 += k2
+            stk.truncate_push(keep, m, ch.scan);
+            if (keep < ch.minKeep) ch.minKeep = keep;
+            ch.emitted = true;
             return true;
         }
     }
@@ -452,9 +469,11 @@ __device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stac
 // Runs the chain over the candidates at query positions [p0, p1) of one contig (p1 <= positions).
 // Four 64-position batches of the candidate array are fetched per round trip; a jump that lands inside
 // the fetched window (the common case: matches of ~100 bases) costs no further load.
-template <class Stack>
+struct NoStop { __device__ __forceinline__ bool operator()() { return false; } };
+
+template <class Stack, class Stop = NoStop>
 __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
-                          int64_t p0, int64_t p1, Stack &stk, Chain &ch) {
+                          int64_t p0, int64_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     constexpr int NB = 4;
     while (true) {
@@ -478,6 +497,7 @@ __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, 
             while (m) {
                 const int l = __builtin_ctzll(m);
                 visit(v, cg, q, stk, ch, bk + l, rl32(w[k], l));
+                if (stop()) return;
                 const int64_t rel = ch.scan - bk;                     // first lane still to be visited
                 m = rel >= WAVE ? 0ull : (m & ~((1ull << rel) - 1));
             }
@@ -495,8 +515,8 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
     __shared__ uint2 ring[RING];
     const Contig cg = contigs[blockIdx.x];
     Chain ch;
-    ch.scan = 0; ch.minTouched = 0; ch.minKeep = 0; ch.visited = 0; ch.cands = 0;
-    ArrayStack stk;
+    ch.scan = 0; ch.minTouched = 0; ch.minKeep = 0; ch.visited = 0; ch.cands = 0; ch.emitted = false;
+    ArrayStack<Match> stk;
     stk.st = matches + cg.matchBase; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
     run_chain(v, cg, qbuf + cg.qoff, cand + cg.candBase, 0, npos, stk, ch);
@@ -526,10 +546,10 @@ struct __attribute__((aligned(16))) BlockRec {
     Match fTop[SNAP];      // newest rows at the end, newest first
 };
 
-__device__ __forceinline__ void snapshot_top(const Match *st, int sp, Match *out) {
+__device__ __forceinline__ void snapshot_top(const Row *st, int sp, Match *out) {
 #pragma unroll
     for (int j = 0; j < SNAP; j++) {
-        if (j < sp) out[j] = st[sp - 1 - j];
+        if (j < sp) { out[j].posSrc = st[sp - 1 - j].posSrc; out[j].len = st[sp - 1 - j].len; out[j].posDest = st[sp - 1 - j].posDest; }
         else { out[j].posSrc = 0; out[j].len = 0; out[j].posDest = 0; }
     }
 }
@@ -539,7 +559,7 @@ __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ rbContig,
                                                          const uint32_t *__restrict__ cand,
-                                                         Match *__restrict__ regions, uint32_t cap, uint32_t rb,
+                                                         Row *__restrict__ regions, uint32_t cap, uint32_t rb,
                                                          BlockRec *__restrict__ recs) {
     __shared__ uint2 ring[RING];
     const uint32_t g = blockIdx.x;
@@ -550,9 +570,9 @@ __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_
     const int64_t w1 = w0 + (int64_t) rb * TILE < npos ? w0 + (int64_t) rb * TILE : npos;
     const uint32_t *cd = cand + cg.candBase;
     Chain ch;
-    ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0;
+    ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
     const uint64_t tstart = __builtin_amdgcn_s_memtime();
-    ArrayStack stk;
+    ArrayStack<Row> stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
     if (b) run_chain(v, cg, q, cd, w0 - OVERLAP, w0, stk, ch);       // warm-up on the previous block's tail
@@ -585,7 +605,7 @@ __device__ __forceinline__ bool same_match(const Match &a, const Match &b) {
 // SNAP true rows live in LDS as 3*SNAP u64 words and are compared / rebuilt by 3*SNAP lanes at once.
 __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__restrict__ qbuf,
                                                  const Contig *__restrict__ contigs, const uint32_t *__restrict__ cand,
-                                                 Match *__restrict__ regions,
+                                                 Row *__restrict__ regions, Row *__restrict__ replayArea,
                                                  uint32_t cap, uint32_t rb, const BlockRec *__restrict__ recs,
                                                  uint32_t *__restrict__ segStart, uint32_t *__restrict__ keepN,
                                                  int32_t *__restrict__ prev, uint32_t *__restrict__ dstOff,
@@ -639,7 +659,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
                     __builtin_amdgcn_s_waitcnt(0);
                     const int n = vs.size_ < SNAP ? vs.size_ : SNAP;
                     for (int j = 0; j < n; j++) {
-                        const Match *m = vs.at(vs.size_ - 1 - j);
+                        const Row *m = vs.at(vs.size_ - 1 - j);
                         if (lane < 3) ptop[3 * j + lane] = ((const uint64_t *) m)[lane];
                     }
                     known = n;
@@ -670,16 +690,46 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
                 scanT = rScanF;
             }
         } else {
-            // replay the block from the true state; its rows replace the speculative ones in the region
+            // Replay the block from the true state. The replay writes its rows to a scratch area and
+            // watches the speculative chain's final rows: as soon as it emits a row the speculative chain
+            // also ended up with, with the same scan position right after it, the two chains are in the
+            // same state for everything above that row (a row that survived to the end of the
+            // speculative chain was never looked beneath after it was pushed), so the speculative rows
+            // above it are the true continuation and the replay stops.
             Chain ch;
-            ch.scan = scanT; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0;
-            vs.own = vs.region + (uint64_t) b * cap; vs.ownN = 0;
-            run_chain(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch);
-            const int n = vs.ownN;
+            ch.scan = scanT; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
+            Row *own = replayArea + (uint64_t) blockIdx.x * cap;
+            const Row *spec = vs.region + (uint64_t) b * cap;
+            vs.own = own; vs.ownN = 0;
+            int sp = minKeep < 0 ? 0 : minKeep;                 // speculative rows pushed while replaying the own block
+            int syncAt = -1;
+            auto stop = [&]() -> bool {
+                if (!ch.emitted) return false;
+                ch.emitted = false;
+                if (vs.ownN == 0) return false;
+                __builtin_amdgcn_s_waitcnt(0);
+                const uint64_t ePos = rfl64(own[vs.ownN - 1].posDest), eLen = rfl64(own[vs.ownN - 1].len), eSrc = rfl64(own[vs.ownN - 1].posSrc);
+                while (sp < spF && rfl64(spec[sp].posDest) < ePos) sp++;
+                if (sp < spF && rfl64(spec[sp].posDest) == ePos && rfl64(spec[sp].len) == eLen && rfl64(spec[sp].posSrc) == eSrc &&
+                    (int64_t) rfl64((uint64_t) spec[sp].scanAfter) == ch.scan) { syncAt = sp; return true; }
+                return false;
+            };
+            run_chain(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch, stop);
+            int n = vs.ownN;
             vs.size_ -= n; vs.ownN = 0; vs.own = nullptr;
             __builtin_amdgcn_s_waitcnt(0);
+            Row *dst = vs.region + (uint64_t) b * cap;
+            if (syncAt >= 0) {                                    // append the speculative continuation
+                const int tail = spF - syncAt - 1;
+                for (int k = lane; k < tail; k += WAVE) own[n + k] = spec[syncAt + 1 + k];
+                n += tail;
+                scanT = rScanF;
+                __builtin_amdgcn_s_waitcnt(0);
+            } else
+                scanT = ch.scan;
+            for (int k = lane; k < n; k += WAVE) dst[k] = own[k];
+            __builtin_amdgcn_s_waitcnt(0);
             vs.push_segment((int) b, 0, (uint32_t) n);
-            scanT = ch.scan;
             known = 0;
             replayed++;
         }
@@ -707,16 +757,16 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
 
 // copy every block's surviving rows to their place in the contig's match array
 __global__ void __launch_bounds__(WAVE) k_gather(const Contig *__restrict__ contigs, const uint32_t *__restrict__ rbContig,
-                                                 const Match *__restrict__ regions, uint32_t cap,
+                                                 const Row *__restrict__ regions, uint32_t cap,
                                                  const uint32_t *__restrict__ segStart, const uint32_t *__restrict__ keepN,
                                                  const uint32_t *__restrict__ dstOff, Match *__restrict__ matches) {
     const uint32_t g = blockIdx.x;
     const uint32_t n = keepN[g];
     if (n == 0) return;
     const Contig cg = contigs[rbContig[g]];
-    const Match *src = regions + (uint64_t) g * cap + segStart[g];
+    const Row *src = regions + (uint64_t) g * cap + segStart[g];
     Match *dst = matches + cg.matchBase + dstOff[g];
-    for (uint32_t k = threadIdx.x; k < n; k += WAVE) dst[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < n; k += WAVE) { Match m; m.posSrc = src[k].posSrc; m.len = src[k].len; m.posDest = src[k].posDest; dst[k] = m; }
 }
 
 // order-sensitive fingerprint of the whole batch, single thread: test hook only

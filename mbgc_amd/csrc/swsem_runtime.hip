@@ -83,7 +83,8 @@ struct swsem {
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
     DevBuf<uint32_t> dTileContig, dMatchCount, dRbContig, dCand;
-    DevBuf<Match> dMatches, dRegions;
+    DevBuf<Match> dMatches;
+    DevBuf<Row> dRegions, dReplay;
     DevBuf<BlockRec> dRecs;
     DevBuf<uint32_t> dSegStart, dKeepN, dDstOff;
     DevBuf<int32_t> dPrev;
@@ -328,6 +329,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
         const uint32_t cap = (uint32_t) ((h->rb * TILE + OVERLAP + h->K) / h->K + 8);
         if ((r = h->dRegions.reserve((size_t) rblocks * cap))) return r;
+        if ((r = h->dReplay.reserve((size_t) n * cap))) return r;
         if ((r = h->dRecs.reserve(rblocks))) return r;
         if ((r = h->dSegStart.reserve(rblocks))) return r;
         if ((r = h->dKeepN.reserve(rblocks))) return r;
@@ -338,7 +340,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
                                                                      h->dRegions.p, cap, h->rb, h->dRecs.p);
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
-        k_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, cap, h->rb, h->dRecs.p,
+        k_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p,
                                                        h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
                                                        h->dMatchCount.p, h->dStats.p);
         k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
@@ -432,7 +434,7 @@ void swsem_destroy(swsem_t *h) {
     if (h->lut) (void) hipFree(h->lut);
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release();
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
-    h->dRegions.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
+    h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
     h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
     h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
