@@ -291,15 +291,30 @@ struct MetaLds {
     int64_t sdiag[META_LDS];
     uint64_t ssrc[META_LDS], slp[META_LDS], snx0[META_LDS];
     uint32_t slen[META_LDS];
-    uint64_t snext[128];             // inherited nextSrcRegionLoadingPos, ring like pairedGap
 };
 
+// The chain's state between two matches. The inherited nextSrcRegionLoadingPos values of the next 65
+// matches live in two vector registers: lane k of nxA belongs to match (chunk start + k), lane k of nxB
+// to match (chunk start + 64 + k).
 struct MetaRun {
     unsigned long long claimed;
     bool curClaimed;
     int64_t gapStartIdx, gapEndIdx;
+    uint64_t nxA, nxB;
 };
 
+__device__ __forceinline__ uint64_t rl64(uint64_t x, int lane) {
+    return ((uint64_t) rl32((uint32_t) (x >> 32), lane) << 32) | rl32((uint32_t) x, lane);
+}
+// write a wave-uniform value into one lane of a vector register
+__device__ __forceinline__ uint32_t wl32(uint32_t val, int lane, uint32_t vec) {
+    return (int) (threadIdx.x & (WAVE - 1)) == lane ? val : vec;
+}
+__device__ __forceinline__ uint64_t wl64(uint64_t val, int lane, uint64_t vec) {
+    return (int) (threadIdx.x & (WAVE - 1)) == lane ? val : vec;
+}
+
+// stage matches [from, to) of the compacted list
 __device__ __forceinline__ void meta_load(const EmitView &v, const EmitContig &cg, MetaLds &L, int64_t from, int64_t to, bool lazy) {
     const EMatch *E = v.em + cg.scratchBase;
     for (int64_t t = from + threadIdx.x; t < to; t += WAVE) {
@@ -314,66 +329,105 @@ __device__ __forceinline__ void meta_load(const EmitView &v, const EmitContig &c
     __builtin_amdgcn_s_waitcnt(0);
 }
 
-// matches [j0, j1) of the chain; LDS holds matches [base, ...) covering j1 + 64
+// Matches [j0, j1) of the chain, j0 a multiple of 64; LDS holds matches [base, ...) covering j1 + 64.
+// Per chunk of 64 matches the lanes first compute everything that does not depend on the chain's state
+// (lane k works for match chunk+k: which of its next 64 matches are pairedWith it, which the lazy rule
+// rejects with its own region boundary, whether no literal follows it); the chain itself then runs on the
+// scalar unit, one match after the other, reading those per-match words with v_readlane.
 template <bool WRITE>
 __device__ void meta_run(const EmitView &v, const EmitContig &cg, MetaLds &L, MetaRun &st, int64_t base, int64_t j0, int64_t j1, int64_t n) {
-    const uint32_t lane = threadIdx.x;
+    const int lane = (int) threadIdx.x;
     const bool lazy = v.p.lazyDecompressionSupport != 0, ext = v.p.enableExtensionsWithMismatches != 0;
     const int depth = v.p.gapDepthOffsetEncoding;
-    for (int64_t j = j0; j < j1; j++) {
-        const int64_t lj = j - base;
-        if (ext && j == st.gapEndIdx) { st.gapStartIdx = -1; st.gapEndIdx = -1; }        // :222-225
-        const bool skipOffset = st.curClaimed;                                           // :229
-        const uint64_t endj = (uint64_t) ((int64_t) L.ssrc[lj] - L.sdiag[lj]) + L.slen[lj];
-        const uint64_t litLeft = (j + 1 < n ? (uint64_t) ((int64_t) L.ssrc[lj + 1] - L.sdiag[lj + 1]) : cg.n) - (uint32_t) endj;   // :242
-        const int gCnt = (int) (n - j - 1 < depth ? n - j - 1 : depth);
-        const int g = (int) lane + 1;
-        const bool rule = !lazy && st.gapStartIdx == -1 && litLeft == 0;                  // :247, applies to g == 1
-        uint64_t nextj = L.snext[j & 127];
-        bool elig = false;
-        if (g <= gCnt) {
-            const bool taken = ((st.claimed >> lane) & 1ull) || (rule && g == 1);
-            const uint64_t sj = L.ssrc[lj], sg = L.ssrc[lj + g];
-            const bool pw = L.sdiag[lj] == L.sdiag[lj + g] &&
-                            ((sj > cg.lock && sg > cg.lock) || (sj < cg.lock && sg < cg.lock));   // TextMatchers.h:46-50
-            elig = !taken && pw;
+    for (int64_t jb = j0; jb < j1; jb += WAVE) {
+        const int cnt = (int) (j1 - jb < WAVE ? j1 - jb : WAVE);
+        // ---- lane-parallel part
+        const int64_t jl = jb + lane, lk = jl - base;
+        unsigned long long pm = 0, lm = 0;
+        uint64_t own = 0;
+        bool lit0 = false;
+        if (lane < cnt) {
+            const int gCnt = (int) (n - jl - 1 < depth ? n - jl - 1 : depth);
+            const int64_t dj = L.sdiag[lk];
+            const uint64_t sj = L.ssrc[lk];
+            own = L.snx0[lk];
+            const bool above = sj > cg.lock, below = sj < cg.lock;
+            // branch-free and unrolled, so the LDS reads of several look-ahead steps are in flight together
+#pragma unroll 8
+            for (int g = 1; g <= WAVE; g++) {
+                const int64_t x = g <= gCnt ? lk + g : lk;
+                const int64_t dg = L.sdiag[x];
+                const uint64_t sg = L.ssrc[x], lg = L.slp[x];
+                const bool in = g <= gCnt;
+                const bool pw = in & (dg == dj) & ((above & (sg > cg.lock)) | (below & (sg < cg.lock)));    // TextMatchers.h:46-50
+                pm |= (unsigned long long) pw << (g - 1);
+                lm |= (unsigned long long) (in & lazy & (lg >= own)) << (g - 1);         // :258-259 with the match's own boundary
+            }
+            const uint64_t endj = (uint64_t) ((int64_t) sj - dj) + L.slen[lk];
+            const uint64_t nxt = jl + 1 < n ? (uint64_t) ((int64_t) L.ssrc[lk + 1] - L.sdiag[lk + 1]) : cg.n;
+            lit0 = nxt - (uint32_t) endj == 0;                                           // :242 (uint32 pos)
         }
-        const unsigned long long pm = __ballot(elig);
-        if (lazy && pm) {
-            if (!nextj) nextj = L.snx0[lj];                                                 // :253-257
-            elig = elig && !(L.slp[lj + g] >= nextj);                                       // :258-259
-        }
-        const unsigned long long em = lazy ? __ballot(elig) : pm;
-        uint32_t gapByte = 0;
-        if (em) {
-            const int gf = __builtin_ctzll(em) + 1;
-            const unsigned long long below = gf > 1 ? ((1ull << (gf - 1)) - 1) : 0ull;
-            const int reduce = __popcll((st.claimed | (rule ? 1ull : 0ull)) & below);
-            gapByte = (uint32_t) (gf - reduce);
-            st.claimed |= 1ull << (gf - 1);                                                 // :262
-            if (lazy) L.snext[(j + gf) & 127] = nextj;                                      // :260
-            if (ext && st.gapEndIdx <= j + gf && gf <= v.p.gapDepthMismatchesEncoding) { st.gapStartIdx = j; st.gapEndIdx = j + gf; }
-        }
-        L.snext[j & 127] = 0;
-        st.curClaimed = st.claimed & 1ull;                                                  // :272-273: advance the ring
-        st.claimed >>= 1;
-        if (WRITE) {
-            const bool gs = st.gapStartIdx == j, ge = st.gapEndIdx == j + 1, gm = st.gapStartIdx < j && j + 1 < st.gapEndIdx;
-            const bool isGap = gs || gm || ge;
-            if (lane == 0) {
-                v.meta[cg.scratchBase + j] = (skipOffset ? META_SKIPOFF : 0) | (gCnt ? META_HASGAP : 0) | (isGap ? META_ISGAP : 0) |
-                                             (gs ? META_GSTART : 0) | (gm ? META_GMID : 0) | (ge ? META_GEND : 0) | (gapByte << 8);
-                v.corr[cg.scratchBase + j] = isGap ? (uint32_t) st.gapStartIdx : (uint32_t) j;
+        const unsigned long long litZero = __ballot(lit0);
+        uint32_t metaV = 0, corrV = 0;
+        // ---- the chain (wave-uniform)
+        for (int k = 0; k < cnt; k++) {
+            const int64_t j = jb + k;
+            if (ext && j == st.gapEndIdx) { st.gapStartIdx = -1; st.gapEndIdx = -1; }    // :222-225
+            const bool skipOffset = st.curClaimed;                                       // :229
+            const int gCnt = (int) (n - j - 1 < depth ? n - j - 1 : depth);
+            const bool rule = !lazy && st.gapStartIdx == -1 && ((litZero >> k) & 1);      // :247, applies to g == 1
+            const unsigned long long taken = st.claimed | (rule ? 1ull : 0ull);
+            unsigned long long em = rl64(pm, k) & ~taken;                                 // paired and not yet claimed
+            uint64_t nextj = 0;
+            if (lazy && em) {
+                nextj = rl64(st.nxA, k);
+                const uint64_t mine = rl64(own, k);
+                if (!nextj || nextj == mine) { nextj = mine; em &= ~rl64(lm, k); }         // :253-259
+                else {                                                                     // inherited boundary: evaluate on the lanes
+                    const int g = lane + 1;
+                    const bool rej = g <= gCnt && L.slp[j - base + g] >= nextj;
+                    em &= ~__ballot(rej);
+                }
+            }
+            uint32_t gapByte = 0;
+            if (em) {
+                const int gf = __builtin_ctzll(em) + 1;
+                const unsigned long long below = gf > 1 ? ((1ull << (gf - 1)) - 1) : 0ull;
+                gapByte = (uint32_t) (gf - __popcll(taken & below));
+                st.claimed |= 1ull << (gf - 1);                                             // :262
+                if (lazy) {                                                                 // :260
+                    const int t = k + gf;
+                    if (t < WAVE) st.nxA = wl64(nextj, t, st.nxA);
+                    else st.nxB = wl64(nextj, t - WAVE, st.nxB);
+                }
+                if (ext && st.gapEndIdx <= j + gf && gf <= v.p.gapDepthMismatchesEncoding) { st.gapStartIdx = j; st.gapEndIdx = j + gf; }
+            }
+            st.curClaimed = st.claimed & 1ull;                                              // :272-273: advance the ring
+            st.claimed >>= 1;
+            if (WRITE) {
+                const bool gs = st.gapStartIdx == j, ge = st.gapEndIdx == j + 1, gm = st.gapStartIdx < j && j + 1 < st.gapEndIdx;
+                const bool isGap = gs || gm || ge;
+                const uint32_t mw = (skipOffset ? META_SKIPOFF : 0) | (gCnt ? META_HASGAP : 0) | (isGap ? META_ISGAP : 0) |
+                                    (gs ? META_GSTART : 0) | (gm ? META_GMID : 0) | (ge ? META_GEND : 0) | (gapByte << 8);
+                metaV = wl32(mw, k, metaV);
+                corrV = wl32(isGap ? (uint32_t) st.gapStartIdx : (uint32_t) j, k, corrV);
             }
         }
+        if (WRITE && lane < cnt) {
+            v.meta[cg.scratchBase + jl] = metaV;
+            v.corr[cg.scratchBase + jl] = corrV;
+        }
+        // the next chunk: its inherited values were collected in nxB
+        st.nxA = st.nxB;
+        st.nxB = 0;
     }
 }
 
-__device__ __forceinline__ void meta_store_state(MetaState *dst, const MetaRun &st, const MetaLds &L, int64_t j) {
+__device__ __forceinline__ void meta_store_state(MetaState *dst, const MetaRun &st) {
     const uint32_t lane = threadIdx.x;
-    dst->nx[lane] = L.snext[(j + lane) & 127];
+    dst->nx[lane] = st.nxA;
     if (lane == 0) {
-        dst->nx[WAVE] = L.snext[(j + WAVE) & 127];
+        dst->nx[WAVE] = st.nxB;                      // lane 0 of nxB = match j + 64
         dst->claimed = st.claimed; dst->gapStartIdx = st.gapStartIdx; dst->gapEndIdx = st.gapEndIdx;
         dst->curClaimed = st.curClaimed ? 1u : 0u; dst->pad = 0;
     }
@@ -392,15 +446,14 @@ __global__ void __launch_bounds__(WAVE) k_emit_meta_blocks(EmitView v, const Emi
     const int64_t j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
     const int64_t w = j0 >= META_WARM ? j0 - META_WARM : 0;
     const bool lazy = v.p.lazyDecompressionSupport != 0;
-    for (int i = threadIdx.x; i < 128; i += WAVE) L.snext[i] = 0;
     meta_load(v, cg, L, w, j1 + WAVE < n ? j1 + WAVE : n, lazy);
     MetaRun st;
-    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1;
+    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1; st.nxA = 0; st.nxB = 0;
     meta_run<false>(v, cg, L, st, w, w, j0, n);                     // warm-up, nothing written
     MetaState *S = states + ((size_t) blockIdx.y * maxBlocks + blockIdx.x) * 2;
-    meta_store_state(S, st, L, j0);
+    meta_store_state(S, st);
     meta_run<true>(v, cg, L, st, w, j0, j1, n);
-    meta_store_state(S + 1, st, L, j1);
+    meta_store_state(S + 1, st);
 }
 
 __global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const EmitContig *__restrict__ cgs, const MetaState *__restrict__ states,
@@ -414,31 +467,29 @@ __global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const Emi
     const bool lazy = v.p.lazyDecompressionSupport != 0;
     const int64_t nb = (n + META_BLOCK - 1) / META_BLOCK;
     MetaRun st;                                                      // true state at the start of block b
-    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1;
-    uint64_t tnx = 0, tnx64 = 0;                                     // true inherited values of matches j0+lane, j0+64
+    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1; st.nxA = 0; st.nxB = 0;
     uint32_t replayed = 0;
     for (int64_t b = 0; b < nb; b++) {
         const int64_t j0 = b * META_BLOCK, j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
         const MetaState *S = states + ((size_t) blockIdx.x * maxBlocks + b) * 2;
         bool same = true;
         if (b > 0) {
-            const bool d = S->nx[lane] != tnx || (lane == 0 && (S->nx[WAVE] != tnx64 || S->claimed != st.claimed ||
+            const uint64_t tnx64 = rl64(st.nxB, 0);
+            const bool d = S->nx[lane] != st.nxA || (lane == 0 && (S->nx[WAVE] != tnx64 || S->claimed != st.claimed ||
                            S->gapStartIdx != st.gapStartIdx || S->gapEndIdx != st.gapEndIdx ||
                            (S->curClaimed != 0) != st.curClaimed));
             same = __ballot(d) == 0;
         }
         if (same) {
             const MetaState *F = S + 1;
-            st.claimed = F->claimed; st.curClaimed = F->curClaimed != 0; st.gapStartIdx = F->gapStartIdx; st.gapEndIdx = F->gapEndIdx;
-            tnx = F->nx[lane]; tnx64 = F->nx[WAVE];
+            st.claimed = rfl64(F->claimed); st.curClaimed = rfl32(F->curClaimed) != 0;
+            st.gapStartIdx = (int64_t) rfl64((uint64_t) F->gapStartIdx); st.gapEndIdx = (int64_t) rfl64((uint64_t) F->gapEndIdx);
+            st.nxA = F->nx[lane];
+            st.nxB = lane == 0 ? F->nx[WAVE] : 0;
         } else {
             // replay the block from the true state
-            for (int i = lane; i < 128; i += WAVE) L.snext[i] = 0;
-            L.snext[(j0 + lane) & 127] = tnx;
-            if (lane == 0) L.snext[(j0 + WAVE) & 127] = tnx64;
             meta_load(v, cg, L, j0, j1 + WAVE < n ? j1 + WAVE : n, lazy);
             meta_run<true>(v, cg, L, st, j0, j0, j1, n);
-            tnx = L.snext[(j1 + lane) & 127]; tnx64 = L.snext[(j1 + WAVE) & 127];
             replayed++;
         }
     }

@@ -735,7 +735,6 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     if (p->gapDepthOffsetEncoding > 64 || p->gapDepthOffsetEncoding < 0)
         return fail(SWSEM_EINVAL, "gapDepthOffsetEncoding %d out of range (MAX_GAP_DEPTH / 2)", p->gapDepthOffsetEncoding);
     int r;
-    if (h->matchCount.size() != h->contigs.size() && (r = fetch_counts(h))) return r;
     h->ecg.assign(n, EmitContig());
     std::vector<int> which(n);
     uint64_t rows = 0, arena = 0;
@@ -745,7 +744,9 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
         which[k] = c;
         EmitContig &e = h->ecg[k];
         const Contig &cg = h->contigs[c];
-        const uint64_t nm = h->matchCount[c];
+        // rows are reserved for the most matches a contig can have, so no round trip to the host is needed
+        // between match-finding and emission
+        const uint64_t nm = cg.n / (h->minLen ? h->minLen : 1) + 2;
         e.qoff = cg.qoff; e.n = cg.n; e.matchBase = cg.matchBase;
         e.lock = lockPos ? lockPos[k] : UINT64_MAX;
         e.scratchBase = rows;

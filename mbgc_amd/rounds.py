@@ -111,10 +111,8 @@ class RoundRunner:
         ext_done = {}
         while True:
             if pending:
-                cnt = self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
-                                  [lock_of[c] for c in pending], min_len)
-                for k, c in enumerate(pending):
-                    counts[c] = cnt[k]
+                self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
+                            [lock_of[c] for c in pending], min_len)
                 if self.p is not None:
                     tgt = [first + self.rank * T + targets[c] for c in pending]
                     m.emit_batch(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
@@ -122,6 +120,9 @@ class RoundRunner:
                     un = m.emit_unmatched(len(pending))
                 else:
                     un = [int(offsets[c + 1] - offsets[c]) for c in pending]     # matcher only: always extend
+                cnt = m.batch_counts()          # after the emission launches: no host round trip in between
+                for k, c in enumerate(pending):
+                    counts[c] = cnt[k]
                 skipped_local = [c for k, c in enumerate(pending) if int(un[k]) == SKIPPED]
                 good = [(k, c) for k, c in enumerate(pending) if int(un[k]) != SKIPPED]
                 for k, c in good:
@@ -168,7 +169,6 @@ class RoundRunner:
             offs = np.zeros(len(spans) + 1, dtype=np.uint64)
             offs[1:] = np.cumsum([e - s for s, e in spans])
             self.m.match_batch_dev(self._tmp.data_ptr(), offs, min_len, locks)
-        return self.m.batch_counts()
 
     def _pack(self, ks, cs, n_emitted):
         sizes, total = self.m.emit_pack_sizes(n_emitted)
