@@ -1,0 +1,125 @@
+"""Structural fuzz: genomes related by substitutions, indels, block moves, inversions (reverse
+complements), tandem duplications, N runs and soft-masked stretches, cut into contigs of very different
+sizes — HIP path vs oracle through both target loops, bit-exact on every stream."""
+import numpy as np
+import pytest
+
+import _driver
+import _orc
+from mbgc_amd import synth
+from test_gpu_emit import HipEmitter, compare
+
+pytestmark = pytest.mark.gpu
+_COMP = {ord("A"): ord("T"), ord("C"): ord("G"), ord("G"): ord("C"), ord("T"): ord("A")}
+
+
+@pytest.fixture(scope="module")
+def binding():
+    from mbgc_amd import binding as b
+    assert b.lib().swsem_device_count() > 0
+    return b
+
+
+def mutate(rng, g, sub=0.01, n_events=12):
+    g = g.copy()
+    m = rng.random(g.size) < sub
+    g[m] = synth.ACGT[rng.integers(0, 4, int(m.sum()))]
+    for _ in range(n_events):
+        kind = rng.integers(0, 7)
+        n = g.size
+        a = int(rng.integers(0, max(1, n - 2000)))
+        ln = int(rng.integers(1, 1500))
+        if kind == 0:      # deletion
+            g = np.concatenate([g[:a], g[a + ln:]])
+        elif kind == 1:    # insertion of random sequence
+            g = np.concatenate([g[:a], synth.ACGT[rng.integers(0, 4, ln)], g[a:]])
+        elif kind == 2:    # tandem duplication
+            g = np.concatenate([g[:a + ln], g[a:a + ln], g[a + ln:]])
+        elif kind == 3:    # inversion
+            seg = g[a:a + ln][::-1].copy()
+            seg = np.array([_COMP.get(int(x), int(x)) for x in seg], dtype=np.uint8)
+            g = np.concatenate([g[:a], seg, g[a + ln:]])
+        elif kind == 4:    # block move
+            seg = g[a:a + ln].copy()
+            rest = np.concatenate([g[:a], g[a + ln:]])
+            b = int(rng.integers(0, rest.size))
+            g = np.concatenate([rest[:b], seg, rest[b:]])
+        elif kind == 5:    # N run
+            g[a:a + min(ln, 300)] = ord("N")
+        else:              # soft-masked (lower case) stretch
+            g[a:a + ln] = np.char.lower(g[a:a + ln].view("S1")).view(np.uint8) if False else (g[a:a + ln] | 0x20)
+    return g
+
+
+def cut(rng, g, k):
+    if k <= 1:
+        return [g]
+    cuts = np.sort(rng.integers(1, g.size - 1, k - 1))
+    parts = np.split(g, cuts)
+    return [p for p in parts if p.size]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fuzz_sequential(binding, seed):
+    rng = np.random.default_rng(seed)
+    base = synth.ACGT[rng.integers(0, 4, 60_000)]
+    files = [cut(rng, mutate(rng, base, 0.005 * (1 + i % 3)), int(rng.integers(1, 6))) for i in range(6)]
+    lim, _ = _driver.ref_length_limit(len(files), 60_000)
+    h = binding.SlidingWindowSparseEMMatcher(lim)
+    o = _orc.OracleMatcher(lim)
+    he, oe = HipEmitter(binding, h), _orc.OracleEmitter(o)
+    a = _driver.encode_sequential(h, he, files)
+    b = _driver.encode_sequential(o, oe, files)
+    for x, y in zip(a["matches"], b["matches"]):
+        assert np.array_equal(x, y)
+    compare(he.streams(), oe.streams())
+    assert np.array_equal(h.ht(), o.ht())
+
+
+@pytest.mark.parametrize("seed,round_size,lim", [(11, 3, 2_000_000), (12, 5, 350_000), (13, 2, 250_000)])
+def test_fuzz_rounds(binding, seed, round_size, lim):
+    rng = np.random.default_rng(seed)
+    base = synth.ACGT[rng.integers(0, 4, 50_000)]
+    gs = [cut(rng, mutate(rng, base, 0.004 * (1 + i % 4)), int(rng.integers(1, 5))) for i in range(9)]
+    h = binding.SlidingWindowSparseEMMatcher(lim)
+    o = _orc.OracleMatcher(lim)
+    a = _driver.encode_rounds(h, lambda: HipEmitter(binding, h), gs[0], gs[1:], round_size)
+    b = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), gs[0], gs[1:], round_size)
+    assert a["unmatched"] == b["unmatched"] and a["locks"] == b["locks"] and a["refExtSize"] == b["refExtSize"]
+    compare(a["streams"], b["streams"])
+    assert np.array_equal(h.ht(), o.ht())
+
+
+def test_many_tiny_contigs_in_one_batch(binding):
+    """hundreds of contigs from 1 base to a few kb in a single device-resident round"""
+    import torch
+    rng = np.random.default_rng(21)
+    base = synth.ACGT[rng.integers(0, 4, 200_000)]
+    h = binding.SlidingWindowSparseEMMatcher(4_000_000)
+    o = _orc.OracleMatcher(4_000_000)
+    for m in (h, o):
+        m.load_ref(base, load_rc=True)
+    mut = mutate(rng, base, 0.01, 20)
+    sizes = [1, 2, 27, 28, 31, 32, 33, 64] + [int(x) for x in rng.integers(1, 4000, 300)]
+    contigs, p = [], 0
+    for s in sizes:
+        contigs.append(mut[p:p + s].copy())
+        p = (p + s) % (mut.size - 5000)
+    offs = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([c.size for c in contigs])
+    buf = torch.from_numpy(np.concatenate(contigs)).to("cuda:0")
+    torch.cuda.synchronize()
+    h.match_batch_dev(buf.data_ptr(), offs, 32, None)
+    counts = h.batch_counts()
+    loaded = [h.loading_position()]
+    h.emit_batch(binding.emit_params(1), loaded=loaded, n=len(contigs))
+    for i, c in enumerate(contigs):
+        exp = o.match(c)
+        assert counts[i] == len(exp), i
+        if len(exp):
+            assert np.array_equal(h.batch_matches(i, counts[i]), exp), i
+        oe = _orc.OracleEmitter(o)
+        un = oe.process(exp, c, _orc.NO_LOCK, 128, 0, 0, loaded)
+        got_un, streams, _ = h.emit_result(i)
+        assert got_un == un, i
+        compare(streams, oe.streams())
