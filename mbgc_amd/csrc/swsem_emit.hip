@@ -34,6 +34,7 @@ struct EmitContig {
     uint64_t scratchBase;                            // per-match scratch rows (cap rows)
     uint64_t streamBase[SWSEM_NSTREAMS];             // byte offsets into the stream arena
     uint32_t cap;                                    // rows reserved (>= matches + 2)
+    uint32_t chunk0;                                 // first of the contig's ceil(cap / CH) chunks in the chunk grid
     int32_t factor;                                  // unmatchedFractionFactor
     int64_t processed, targetIdx;                    // processedTargetsCount / targetIdx
 };
@@ -60,7 +61,8 @@ struct EmitView {
     uint32_t *corr;                                  // gapStartIdx when in a gap
     uint32_t *sz;                                    // 6 u32 per gap task
     uint32_t *ofs;                                   // 6 u32 per iteration: start offsets in the six streams
-    uint32_t *chunkCnt;                              // [contig][chunk] kept-match counts / offsets, 6 sums per chunk for placement
+    uint32_t *chunkCnt;                              // [chunk] kept-match counts / offsets, 6 sums per chunk for placement
+    const uint32_t *chunkOwner;                      // [chunk] -> contig of the batch (chunks of CH rows, per contig)
     uint32_t ncontigs;
     uint64_t *packBase;                              // [contig][stream] start of the stream in the packed arena
     uint8_t *arena;                                  // streams
@@ -121,15 +123,18 @@ __device__ uint32_t block_scan(uint32_t x, uint32_t *lds, uint32_t *total) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1, MBGC_Encoder.cpp:153-205. Grid kernels: blockIdx.x = chunk of CH matches, blockIdx.y = contig.
+// pass 1, MBGC_Encoder.cpp:153-205. Grid kernels: one block per chunk of CH rows; chunkOwner maps the
+// block to its contig (gk) and gx is the chunk index inside the contig, so ragged batches launch no empty blocks.
 // ------------------------------------------------------------------------------------------------
 constexpr int CH = 256;
 
 // (a) the locally computable part of the removal test (:176-178), taking j-1 as the kept predecessor
 __global__ void __launch_bounds__(CH) k_emit_p1_flags(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
-    const EmitContig cg = cgs[blockIdx.y];
-    const int64_t n = v.matchCount[which[blockIdx.y]];
-    const int64_t j = (int64_t) blockIdx.x * CH + threadIdx.x;
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const int64_t n = v.matchCount[which[gk]];
+    const int64_t j = (int64_t) gx * CH + threadIdx.x;
     if (j >= n) return;
     const Match *M = v.matches + cg.matchBase;
     bool t = false;
@@ -143,12 +148,13 @@ __global__ void __launch_bounds__(CH) k_emit_p1_flags(EmitView v, const EmitCont
 // (b) a removed match keeps its successor (the successor is then paired with the kept predecessor), so
 // inside a run of the predicate the matches are removed alternately, starting with the first. Also
 // counts the kept matches of the chunk.
-__global__ void __launch_bounds__(CH) k_emit_p1_removed(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which,
-                                                        uint32_t maxChunks) {
+__global__ void __launch_bounds__(CH) k_emit_p1_removed(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
     __shared__ uint32_t cnt;
-    const EmitContig cg = cgs[blockIdx.y];
-    const int64_t n = v.matchCount[which[blockIdx.y]];
-    const int64_t j = (int64_t) blockIdx.x * CH + threadIdx.x;
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const int64_t n = v.matchCount[which[gk]];
+    const int64_t j = (int64_t) gx * CH + threadIdx.x;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     const uint8_t *tf = v.tflag + cg.scratchBase;
@@ -166,16 +172,15 @@ __global__ void __launch_bounds__(CH) k_emit_p1_removed(EmitView v, const EmitCo
     const unsigned long long bal = __ballot(keep);
     if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&cnt, (uint32_t) __popcll(bal));
     __syncthreads();
-    if (threadIdx.x == 0) v.chunkCnt[(size_t) blockIdx.y * maxChunks + blockIdx.x] = cnt;
+    if (threadIdx.x == 0) v.chunkCnt[(size_t) blockIdx.x] = cnt;
 }
 
 // (c) per contig: exclusive scan of the chunk counts; resets the per-contig accumulators
-__global__ void __launch_bounds__(CH) k_emit_p1_scan(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which,
-                                                     uint32_t maxChunks) {
+__global__ void __launch_bounds__(CH) k_emit_p1_scan(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
     __shared__ uint32_t lds[CH / WAVE + 2];
     const int64_t n = v.matchCount[which[blockIdx.x]];
     const uint32_t nch = (uint32_t) ((n + CH - 1) / CH);
-    uint32_t *cc = v.chunkCnt + (size_t) blockIdx.x * maxChunks;
+    uint32_t *cc = v.chunkCnt + cgs[blockIdx.x].chunk0;
     uint32_t base = 0;
     for (uint32_t c0 = 0; c0 < nch; c0 += CH) {
         const uint32_t c = c0 + threadIdx.x;
@@ -197,20 +202,21 @@ __global__ void __launch_bounds__(CH) k_emit_p1_scan(EmitView v, const EmitConti
 }
 
 // (d) compaction; an abutting successor of a removed match is extended to the left (:180-186)
-__global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which,
-                                                        uint32_t maxChunks) {
+__global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
     __shared__ uint32_t lds[CH / WAVE + 2];
-    const EmitContig cg = cgs[blockIdx.y];
-    const int64_t n = v.matchCount[which[blockIdx.y]];
-    if ((int64_t) blockIdx.x * CH >= n) return;
-    const int64_t j = (int64_t) blockIdx.x * CH + threadIdx.x;
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const int64_t n = v.matchCount[which[gk]];
+    if ((int64_t) gx * CH >= n) return;
+    const int64_t j = (int64_t) gx * CH + threadIdx.x;
     const Match *M = v.matches + cg.matchBase;
     const uint8_t *q = v.qbuf + cg.qoff, *rm = v.removed + cg.scratchBase;
     const uint32_t keep = (j < n && !rm[j]) ? 1u : 0u;
     uint32_t tot;
     const uint32_t ex = block_scan<CH>(keep, lds, &tot);
     if (!keep) return;
-    const uint32_t t = v.chunkCnt[(size_t) blockIdx.y * maxChunks + blockIdx.x] + ex;
+    const uint32_t t = v.chunkCnt[(size_t) blockIdx.x] + ex;
     EMatch e;
     e.posSrc = M[j].posSrc; e.len = M[j].len; e.posDest = M[j].posDest;
     if (j >= 1 && rm[j - 1] && M[j - 1].posDest + M[j - 1].len == M[j].posDest) {
@@ -231,9 +237,11 @@ __global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitCo
 
 // (e) unmatchedChars / totalMatched with the reference's integer types (uint32 pos, :145,:193-196)
 __global__ void __launch_bounds__(CH) k_emit_p1_sums(EmitView v, const EmitContig *__restrict__ cgs) {
-    const EmitContig cg = cgs[blockIdx.y];
-    const uint32_t nk = (uint32_t) v.out[blockIdx.y].nmatches;
-    const uint32_t t = blockIdx.x * CH + threadIdx.x;
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const uint32_t nk = (uint32_t) v.out[gk].nmatches;
+    const uint32_t t = gx * CH + threadIdx.x;
     const EMatch *E = v.em + cg.scratchBase;
     unsigned long long um = 0, tm = 0;
     if (t < nk) {
@@ -246,8 +254,8 @@ __global__ void __launch_bounds__(CH) k_emit_p1_sums(EmitView v, const EmitConti
         tm += (unsigned long long) __shfl_down((long long) tm, d);
     }
     if ((threadIdx.x & (WAVE - 1)) == 0 && (um | tm)) {
-        atomicAdd((unsigned long long *) &v.out[blockIdx.y].unmatchedChars, um);
-        atomicAdd((unsigned long long *) &v.out[blockIdx.y].totalMatched, tm);
+        atomicAdd((unsigned long long *) &v.out[gk].unmatchedChars, um);
+        atomicAdd((unsigned long long *) &v.out[gk].totalMatched, tm);
     }
 }
 
@@ -279,6 +287,7 @@ __global__ void k_emit_p1_finish(EmitView v, const EmitContig *__restrict__ cgs)
 // state and replays it from the true state otherwise — identical results by construction.
 // ------------------------------------------------------------------------------------------------
 constexpr int META_BLOCK = 256, META_WARM = 128, META_LDS = META_BLOCK + META_WARM + WAVE;
+static_assert(META_BLOCK == CH, "the pairing chain shares the chunk grid of the other emission kernels");
 
 struct MetaState {
     unsigned long long claimed;      // bit g-1: match j+g is already paired (the pairedGap ring)
@@ -433,15 +442,16 @@ __device__ __forceinline__ void meta_store_state(MetaState *dst, const MetaRun &
     }
 }
 
-// blockIdx.x = block of META_BLOCK matches, blockIdx.y = contig
-__global__ void __launch_bounds__(WAVE) k_emit_meta_blocks(EmitView v, const EmitContig *__restrict__ cgs, MetaState *__restrict__ states,
-                                                           uint32_t maxBlocks) {
+// one block per chunk of META_BLOCK (= CH) matches
+__global__ void __launch_bounds__(WAVE) k_emit_meta_blocks(EmitView v, const EmitContig *__restrict__ cgs, MetaState *__restrict__ states) {
     __shared__ MetaLds L;
-    const EmitContig cg = cgs[blockIdx.y];
-    const EmitOut o = v.out[blockIdx.y];
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const EmitOut o = v.out[gk];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
-    const int64_t j0 = (int64_t) blockIdx.x * META_BLOCK;
+    const int64_t j0 = (int64_t) gx * META_BLOCK;
     if (j0 >= n) return;
     const int64_t j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
     const int64_t w = j0 >= META_WARM ? j0 - META_WARM : 0;
@@ -450,14 +460,14 @@ __global__ void __launch_bounds__(WAVE) k_emit_meta_blocks(EmitView v, const Emi
     MetaRun st;
     st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1; st.nxA = 0; st.nxB = 0;
     meta_run<false>(v, cg, L, st, w, w, j0, n);                     // warm-up, nothing written
-    MetaState *S = states + ((size_t) blockIdx.y * maxBlocks + blockIdx.x) * 2;
+    MetaState *S = states + ((size_t) blockIdx.x) * 2;
     meta_store_state(S, st);
     meta_run<true>(v, cg, L, st, w, j0, j1, n);
     meta_store_state(S + 1, st);
 }
 
 __global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const EmitContig *__restrict__ cgs, const MetaState *__restrict__ states,
-                                                           uint32_t maxBlocks, unsigned long long *__restrict__ stats) {
+                                                           unsigned long long *__restrict__ stats) {
     __shared__ MetaLds L;
     const EmitContig cg = cgs[blockIdx.x];
     const EmitOut o = v.out[blockIdx.x];
@@ -471,7 +481,7 @@ __global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const Emi
     uint32_t replayed = 0;
     for (int64_t b = 0; b < nb; b++) {
         const int64_t j0 = b * META_BLOCK, j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
-        const MetaState *S = states + ((size_t) blockIdx.x * maxBlocks + b) * 2;
+        const MetaState *S = states + ((size_t) cg.chunk0 + b) * 2;
         bool same = true;
         if (b > 0) {
             const uint64_t tnx64 = rl64(st.nxB, 0);
@@ -681,13 +691,15 @@ __device__ GapSizes gap_sizes(const EmitView &v, const EmitContig &cg, const EMa
     return s;
 }
 
-// sizes of every gap task. blockIdx.x = chunk of 256 tasks, blockIdx.y = contig
+// sizes of every gap task, one block per chunk of 256 tasks
 __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig *__restrict__ cgs) {
-    const EmitContig cg = cgs[blockIdx.y];
-    const EmitOut o = v.out[blockIdx.y];
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const EmitOut o = v.out[gk];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
-    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t) gx * 256 + threadIdx.x;
     uint32_t cloc[2] = {0, 0};
     if (t <= n) {
         const GapSizes s = gap_sizes(v, cg, v.em + cg.scratchBase, n, t, v.qbuf + cg.qoff, cloc);
@@ -699,8 +711,8 @@ __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig
         cloc[1] += (uint32_t) __shfl_down((int) cloc[1], d);
     }
     if ((threadIdx.x & (WAVE - 1)) == 0 && (cloc[0] | cloc[1])) {
-        atomicAdd((unsigned long long *) &v.out[blockIdx.y].extMatched, (unsigned long long) cloc[0]);
-        atomicAdd((unsigned long long *) &v.out[blockIdx.y].extMismatches, (unsigned long long) cloc[1]);
+        atomicAdd((unsigned long long *) &v.out[gk].extMatched, (unsigned long long) cloc[0]);
+        atomicAdd((unsigned long long *) &v.out[gk].extMismatches, (unsigned long long) cloc[1]);
     }
 }
 
@@ -725,16 +737,18 @@ __device__ __forceinline__ IterSizes iter_sizes(const EmitView &v, const EmitCon
     return r;
 }
 
-__global__ void __launch_bounds__(CH) k_emit_place_sums(EmitView v, const EmitContig *__restrict__ cgs, uint32_t maxChunks) {
+__global__ void __launch_bounds__(CH) k_emit_place_sums(EmitView v, const EmitContig *__restrict__ cgs) {
     __shared__ uint32_t acc[6];
-    const EmitContig cg = cgs[blockIdx.y];
-    const EmitOut o = v.out[blockIdx.y];
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const EmitOut o = v.out[gk];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
-    if ((int64_t) blockIdx.x * CH > n) return;
+    if ((int64_t) gx * CH > n) return;
     if (threadIdx.x < 6) acc[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t t = (int64_t) blockIdx.x * CH + threadIdx.x;
+    const int64_t t = (int64_t) gx * CH + threadIdx.x;
     IterSizes r = {{0, 0, 0, 0, 0, 0}};
     if (t <= n) r = iter_sizes(v, cg, n, t);
 #pragma unroll
@@ -744,15 +758,15 @@ __global__ void __launch_bounds__(CH) k_emit_place_sums(EmitView v, const EmitCo
         if ((threadIdx.x & (WAVE - 1)) == 0 && x) atomicAdd(&acc[k], x);
     }
     __syncthreads();
-    if (threadIdx.x < 6) v.chunkCnt[((size_t) blockIdx.y * maxChunks + blockIdx.x) * 6 + threadIdx.x] = acc[threadIdx.x];
+    if (threadIdx.x < 6) v.chunkCnt[((size_t) blockIdx.x) * 6 + threadIdx.x] = acc[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(CH) k_emit_place_scan(EmitView v, const EmitContig *__restrict__ cgs, uint32_t maxChunks) {
+__global__ void __launch_bounds__(CH) k_emit_place_scan(EmitView v, const EmitContig *__restrict__ cgs) {
     __shared__ uint32_t lds[CH / WAVE + 2];
     const EmitOut o = v.out[blockIdx.x];
     if (o.unmatchedChars == UINT64_MAX) return;
     const uint32_t nch = (uint32_t) ((o.nmatches + 1 + CH - 1) / CH);
-    uint32_t *cc = v.chunkCnt + (size_t) blockIdx.x * maxChunks * 6;
+    uint32_t *cc = v.chunkCnt + (size_t) cgs[blockIdx.x].chunk0 * 6;
     uint32_t base[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t c0 = 0; c0 < nch; c0 += CH) {
         const uint32_t c = c0 + threadIdx.x;
@@ -774,27 +788,44 @@ __global__ void __launch_bounds__(CH) k_emit_place_scan(EmitView v, const EmitCo
 }
 
 // the six streams of all contigs back to back, (contig, stream) major: the arena is written packed
-__global__ void k_emit_packoffs(EmitView v) {
-    if (threadIdx.x | blockIdx.x) return;
+__global__ void __launch_bounds__(CH) k_emit_packoffs(EmitView v) {
+    __shared__ uint32_t lds[CH / WAVE + 2];
     uint64_t run = 0;
-    for (uint32_t k = 0; k < v.ncontigs; k++)
-        for (int s = 0; s < SWSEM_NSTREAMS; s++) {
-            v.packBase[(size_t) k * SWSEM_NSTREAMS + s] = run;
-            run += v.out[k].unmatchedChars == UINT64_MAX ? 0 : v.out[k].size[s];
+    for (uint32_t k0 = 0; k0 < v.ncontigs; k0 += CH) {
+        const uint32_t k = k0 + threadIdx.x;
+        const bool live = k < v.ncontigs && v.out[k].unmatchedChars != UINT64_MAX;
+        uint32_t mine = 0;                                           // a contig's streams stay below 4 GiB (32-bit offsets)
+        if (live) for (int s = 0; s < SWSEM_NSTREAMS; s++) mine += (uint32_t) v.out[k].size[s];
+        // 64-bit running base, 32-bit scan inside a group of CH contigs would overflow for 256 x 4 GiB: scan halves
+        uint32_t totLo, totHi;
+        const uint32_t exLo = block_scan<CH>(mine & 0xFFFFu, lds, &totLo);
+        __syncthreads();
+        const uint32_t exHi = block_scan<CH>(mine >> 16, lds, &totHi);
+        __syncthreads();
+        if (k < v.ncontigs) {
+            uint64_t at = run + exLo + ((uint64_t) exHi << 16);
+            for (int s = 0; s < SWSEM_NSTREAMS; s++) {
+                v.packBase[(size_t) k * SWSEM_NSTREAMS + s] = at;
+                at += live ? v.out[k].size[s] : 0;
+            }
         }
+        run += totLo + ((uint64_t) totHi << 16);
+    }
 }
 
-__global__ void __launch_bounds__(CH) k_emit_place_final(EmitView v, const EmitContig *__restrict__ cgs, uint32_t maxChunks) {
+__global__ void __launch_bounds__(CH) k_emit_place_final(EmitView v, const EmitContig *__restrict__ cgs) {
     __shared__ uint32_t lds[CH / WAVE + 2];
-    const EmitContig cg = cgs[blockIdx.y];
-    const EmitOut o = v.out[blockIdx.y];
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const EmitOut o = v.out[gk];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
-    if ((int64_t) blockIdx.x * CH > n) return;
-    const int64_t t = (int64_t) blockIdx.x * CH + threadIdx.x;
+    if ((int64_t) gx * CH > n) return;
+    const int64_t t = (int64_t) gx * CH + threadIdx.x;
     IterSizes r = {{0, 0, 0, 0, 0, 0}};
     if (t <= n) r = iter_sizes(v, cg, n, t);
-    const uint32_t *cb = v.chunkCnt + ((size_t) blockIdx.y * maxChunks + blockIdx.x) * 6;
+    const uint32_t *cb = v.chunkCnt + ((size_t) blockIdx.x) * 6;
     uint32_t out[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -812,18 +843,20 @@ __global__ void __launch_bounds__(CH) k_emit_place_final(EmitView v, const EmitC
 // write: one thread per iteration; the extension codes are produced by re-running the automata that
 // belong to the iteration (left codes: gap task t, right codes: first half of gap task t+1)
 __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig *__restrict__ cgs) {
-    const EmitContig cg = cgs[blockIdx.y];
-    const EmitOut o = v.out[blockIdx.y];
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const EmitOut o = v.out[gk];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
-    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t) gx * 256 + threadIdx.x;
     if (t > n) return;
     const EMatch *E = v.em + cg.scratchBase;
     const uint8_t *q = v.qbuf + cg.qoff;
     const uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
     const uint32_t *w = v.ofs + (cg.scratchBase + t) * 6;
     const bool bit40 = v.p.enable40bitReference != 0, frugal = v.p.frugal64bitLenEncoding != 0;
-    const uint64_t *pb = v.packBase + (size_t) blockIdx.y * SWSEM_NSTREAMS;
+    const uint64_t *pb = v.packBase + (size_t) gk * SWSEM_NSTREAMS;
     uint8_t *lLit = v.arena + pb[SWSEM_LIT] + w[0], *lFl = v.arena + pb[SWSEM_FLAGS] + w[1];
     uint8_t *plainDst = lLit + z[2];
     for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];

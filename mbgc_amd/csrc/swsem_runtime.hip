@@ -93,12 +93,14 @@ struct swsem {
     DevBuf<EmitContig> dECg;
     DevBuf<EmitOut> dEOut;
     DevBuf<int> dEWhich;
+    DevBuf<uint32_t> dEOwner;
     DevBuf<EMatch> dEM;
     DevBuf<uint64_t> dENext0, dELoaded, dEPack;
     DevBuf<uint8_t> dETf, dERm, dEArena;
     DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs, dEChunk;
     DevBuf<MetaState> dEStates;
     std::vector<EmitContig> ecg;
+    std::vector<uint32_t> chunkOwner;
     std::vector<EmitOut> eout;
     std::vector<uint8_t> hostStreams;
     std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
@@ -436,7 +438,7 @@ void swsem_destroy(swsem_t *h) {
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
-    h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
+    h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEOwner.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
     h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
     h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release(); h->dEPack.release();
     h->dPieces.release(); h->dPieceFirst.release();
@@ -738,6 +740,7 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     h->ecg.assign(n, EmitContig());
     std::vector<int> which(n);
     uint64_t rows = 0, arena = 0;
+    h->chunkOwner.clear();
     for (int k = 0; k < n; k++) {
         const int c = contigIdx ? contigIdx[k] : k;
         if (c < 0 || c >= (int) h->contigs.size()) return fail(SWSEM_EINVAL, "swsem_emit: no contig %d in the batch", c);
@@ -752,6 +755,8 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
         e.scratchBase = rows;
         e.cap = (uint32_t) (nm + 2);
         rows += e.cap;
+        e.chunk0 = (uint32_t) h->chunkOwner.size();
+        h->chunkOwner.insert(h->chunkOwner.end(), (e.cap + CH - 1) / CH, (uint32_t) k);
         e.factor = factor ? factor[k] : 128;
         e.processed = processed ? processed[k] : 0;
         e.targetIdx = targetIdx ? targetIdx[k] : 0;
@@ -763,6 +768,11 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
         (r = h->dEKeep.reserve(rows)) || (r = h->dEMeta.reserve(rows)) || (r = h->dECorr.reserve(rows)) ||
         (r = h->dESz.reserve(rows * 6)) || (r = h->dEOfs.reserve(rows * 6)) || (r = h->dEArena.reserve(arena)) || (r = h->dELoaded.reserve(nLoaded + 1)))
         return r;
+    const uint32_t chunks = (uint32_t) h->chunkOwner.size();
+    if ((r = h->dEOwner.reserve(chunks)) || (r = h->dEStates.reserve((size_t) chunks * 2)) || (r = h->dEChunk.reserve((size_t) chunks * 6)) ||
+        (r = h->dEPack.reserve((size_t) n * SWSEM_NSTREAMS)))
+        return r;
+    HIPCHK(hipMemcpyAsync(h->dEOwner.p, h->chunkOwner.data(), chunks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dECg.p, h->ecg.data(), n * sizeof(EmitContig), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dEWhich.p, which.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (nLoaded) HIPCHK(hipMemcpyAsync(h->dELoaded.p, refExtLoadedPos, nLoaded * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
@@ -773,32 +783,26 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     v.loaded = h->dELoaded.p; v.nLoaded = (uint32_t) nLoaded; v.p = *p;
     v.em = h->dEM.p; v.next0 = h->dENext0.p; v.tflag = h->dETf.p; v.removed = h->dERm.p; v.keepIdx = h->dEKeep.p;
     v.meta = h->dEMeta.p; v.corr = h->dECorr.p; v.sz = h->dESz.p; v.arena = h->dEArena.p; v.out = h->dEOut.p;
-    uint64_t maxRows = 0;
-    for (int k = 0; k < n; k++) maxRows = std::max<uint64_t>(maxRows, h->ecg[k].cap);
-    const uint32_t metaBlocks = (uint32_t) ((maxRows + META_BLOCK - 1) / META_BLOCK);
-    const uint32_t chunks = (uint32_t) ((maxRows + CH - 1) / CH);
-    if ((r = h->dEStates.reserve((size_t) n * metaBlocks * 2))) return r;
-    if ((r = h->dEChunk.reserve((size_t) n * chunks * 6))) return r;
-    if ((r = h->dEPack.reserve((size_t) n * SWSEM_NSTREAMS))) return r;
     v.packBase = h->dEPack.p;
     v.ofs = h->dEOfs.p;
     v.chunkCnt = h->dEChunk.p;
+    v.chunkOwner = h->dEOwner.p;
     v.ncontigs = (uint32_t) n;
-    const dim3 grid2(chunks, n);
+    const dim3 grid2(chunks);
     h->mark(SWSEM_K_EMIT, true);
     k_emit_p1_flags<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
-    k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p, chunks);
-    k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p, chunks);
-    k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p, chunks);
+    k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
+    k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
+    k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
     k_emit_p1_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p);
     k_emit_p1_finish<<<dim3((n + 63) / 64), dim3(64), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_meta_blocks<<<dim3(metaBlocks, n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p, metaBlocks);
-    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p, metaBlocks, h->dStats.p);
+    k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p);
+    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p, h->dStats.p);
     k_emit_sizes<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
-    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
-    k_emit_packoffs<<<1, 1, 0, h->stream>>>(v);
-    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, chunks);
+    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_packoffs<<<1, dim3(CH), 0, h->stream>>>(v);
+    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p);
     k_emit_write<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
     h->mark(SWSEM_K_EMIT, false);
     HIPCHK(hipGetLastError());

@@ -123,3 +123,42 @@ def test_many_tiny_contigs_in_one_batch(binding):
         got_un, streams, _ = h.emit_result(i)
         assert got_un == un, i
         compare(streams, oe.streams())
+
+
+def test_batch_beyond_65535_contigs(binding):
+    """more contigs in one round than a grid's y extent: the emission kernels index blocks through a
+    chunk-owner table, so ragged batches of any count launch one block per 256 rows and nothing else"""
+    import torch
+    rng = np.random.default_rng(33)
+    base = synth.ACGT[rng.integers(0, 4, 300_000)]
+    h = binding.SlidingWindowSparseEMMatcher(2_000_000)
+    o = _orc.OracleMatcher(2_000_000)
+    for m in (h, o):
+        m.load_ref(base)
+    mut = mutate(rng, base, 0.01, 10)
+    n = 70_000
+    sizes = rng.integers(20, 120, n)
+    sizes[::5000] = 40_000                                  # a few long ones among the crumbs
+    starts = rng.integers(0, mut.size - 40_000, n)
+    contigs = [mut[a:a + s] for a, s in zip(starts, sizes)]
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(sizes)
+    buf = torch.from_numpy(np.concatenate(contigs)).to("cuda:0")
+    torch.cuda.synchronize()
+    h.match_batch_dev(buf.data_ptr(), offs, 32, None)
+    counts = h.batch_counts()
+    loaded = [h.loading_position()]
+    h.emit_batch(binding.emit_params(1), loaded=loaded, n=n)
+    un = h.emit_unmatched(n)
+    sizes6, total = h.emit_pack_sizes(n)
+    exp_total = 0
+    for i in list(range(0, n, 97)) + list(range(0, n, 5000)) + [n - 1]:
+        exp = o.match(contigs[i])
+        assert counts[i] == len(exp), i
+        oe = _orc.OracleEmitter(o)
+        eu = oe.process(exp, contigs[i], _orc.NO_LOCK, 128, 0, 0, loaded)
+        assert un[i] == eu, i
+        got_un, streams, _ = h.emit_result(i)
+        compare(streams, oe.streams())
+        assert [len(oe.stream(k)) for k in range(6)] == [int(x) for x in sizes6[i]], i
+    assert total == int(sizes6.sum())
