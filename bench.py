@@ -161,6 +161,16 @@ def main():
     dt = time.perf_counter() - t0
     prof = m.profile_get()
     m.profile_enable(False)
+    if os.environ.get("MBGC_BENCH_BLOCK_STATS"):          # diagnostics of the last round's resolve blocks, to stderr
+        import ctypes as C
+        from mbgc_amd import binding as _b
+        buf = np.zeros(3 * 200000, dtype=np.uint64)
+        nb = C.c_uint64()
+        _b.lib().swsem_debug_block_times.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
+        _b.lib().swsem_debug_block_times(m.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), 200000, C.byref(nb))
+        t = buf[: 3 * nb.value].reshape(-1, 3).astype(np.float64)
+        print("resolve blocks %d: ticks mean %.0f max %.0f (100 MHz), visits %d (mean %.0f/block), rows %d" %
+              (nb.value, t[:, 0].mean(), t[:, 0].max(), t[:, 1].sum(), t[:, 1].mean(), t[:, 2].sum()), file=sys.stderr)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmbgc_hip.so")
+LIB_PATH = os.environ.get("MBGC_HIP_LIB", os.path.join(HERE, "libmbgc_hip.so"))   # override: A/B builds of the kernels
 NO_LOCK = 2 ** 64 - 1
 SKIPPED = 2 ** 64 - 1
 STREAM_NAMES = ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags")

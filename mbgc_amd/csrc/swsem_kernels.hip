@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_
 // unless a capped run has to be continued.
 // ------------------------------------------------------------------------------------------------
 struct Chain {
-    int64_t scan;          // next query position the sequential loop would visit
+    int32_t scan;          // next query position the sequential loop would visit (contigs stay below 2^31 bytes: the
+                           // whole automaton runs on 32-bit scalar arithmetic, 64-bit compares would go through the VALU)
     int32_t minTouched;    // lowest stack index examined since the last reset (-1: walked off the bottom)
     int32_t minKeep;       // lowest keepCount of an emission since the last reset
     int32_t visited;       // hits visited since the last reset
@@ -197,16 +198,16 @@ struct ArrayStack {
     uint2 *ring;
     int32_t sp, ringLow;
     __device__ __forceinline__ int size() const { return sp; }
-    __device__ __forceinline__ void get(int idx, int64_t &posDest, int64_t &len) {
+    __device__ __forceinline__ void get(int idx, int32_t &posDest, int32_t &len) {
         if (idx >= ringLow) {
             const uint2 e = ring[idx & (RING - 1)];
-            posDest = rfl32(e.x); len = rfl32(e.y);
+            posDest = (int32_t) rfl32(e.x); len = (int32_t) rfl32(e.y);
         } else {
-            posDest = (int64_t) rfl64(st[idx].posDest); len = (int64_t) rfl64(st[idx].len);
+            posDest = (int32_t) rfl32((uint32_t) st[idx].posDest); len = (int32_t) rfl32((uint32_t) st[idx].len);
         }
     }
     // resMatches.resize(keep); resMatches.push_back(m)   (.cpp:299-300)
-    __device__ __forceinline__ void truncate_push(int keep, const Match &m, int64_t scanAfter) {
+    __device__ __forceinline__ void truncate_push(int keep, const Match &m, int32_t scanAfter) {
         sp = keep;
         if ((threadIdx.x & (WAVE - 1)) == 0) put_row(st + sp, m, scanAfter);
         ring[sp & (RING - 1)] = make_uint2((uint32_t) m.posDest, (uint32_t) m.len);
@@ -246,9 +247,9 @@ struct VirtStack {
         }
         return region + (uint64_t) curSeg * cap + rfl32(segStart[curSeg]) + curLocal;
     }
-    __device__ __forceinline__ void get(int idx, int64_t &posDest, int64_t &len) {
+    __device__ __forceinline__ void get(int idx, int32_t &posDest, int32_t &len) {
         const Row *m = at(idx);
-        posDest = (int64_t) rfl64(m->posDest); len = (int64_t) rfl64(m->len);
+        posDest = (int32_t) rfl32((uint32_t) m->posDest); len = (int32_t) rfl32((uint32_t) m->len);
     }
     __device__ void pop_segments(int p) {
         const bool l0 = (threadIdx.x & (WAVE - 1)) == 0;
@@ -265,7 +266,7 @@ struct VirtStack {
         }
         curSeg = -1;
     }
-    __device__ void truncate_push(int keep, const Match &m, int64_t scanAfter) {
+    __device__ void truncate_push(int keep, const Match &m, int32_t scanAfter) {
         int p = size_ - keep;
         const int t = p < ownN ? p : ownN;
         ownN -= t; p -= t;
@@ -292,11 +293,11 @@ struct VirtStack {
 // Wave-cooperative exact comparison, 256 bytes per step: equal bytes of a[n..limit) vs b[n..limit)
 // given that the first n are equal. steps > 0 bounds the number of wave steps; *more tells the caller
 // the run may continue past the value returned.
-__device__ uint64_t wave_lcp_fwd(const uint8_t *a, const uint8_t *b, uint64_t n, uint64_t limit, int steps, bool &more) {
+__device__ uint32_t wave_lcp_fwd(const uint8_t *a, const uint8_t *b, uint32_t n, uint32_t limit, int steps, bool &more) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     more = false;
     while (n < limit) {
-        const uint64_t off = n + 4 * lane;
+        const uint32_t off = n + 4 * lane;
         uint32_t eq = 4;
         bool stop = false;
         if (off + 4 <= limit) {
@@ -305,14 +306,14 @@ __device__ uint64_t wave_lcp_fwd(const uint8_t *a, const uint8_t *b, uint64_t n,
         } else {
             eq = 0; stop = true;
             if (off < limit) {
-                const uint32_t avail = (uint32_t) (limit - off);
+                const uint32_t avail = limit - off;
                 while (eq < avail && a[off + eq] == b[off + eq]) eq++;
             }
         }
         const unsigned long long bal = __ballot(stop);
         if (bal) {
             const int l = __builtin_ctzll(bal);
-            return n + 4 * (uint64_t) l + rl32(eq, l);
+            return n + 4 * (uint32_t) l + rl32(eq, l);
         }
         n += 4 * WAVE;
         if (steps && --steps == 0 && n < limit) { more = true; return n; }
@@ -320,11 +321,11 @@ __device__ uint64_t wave_lcp_fwd(const uint8_t *a, const uint8_t *b, uint64_t n,
     return limit;
 }
 // the same to the left: equal bytes of a[-1-k] vs b[-1-k], k in [n, limit)
-__device__ uint64_t wave_lcp_bwd(const uint8_t *a, const uint8_t *b, uint64_t n, uint64_t limit, int steps, bool &more) {
+__device__ uint32_t wave_lcp_bwd(const uint8_t *a, const uint8_t *b, uint32_t n, uint32_t limit, int steps, bool &more) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     more = false;
     while (n < limit) {
-        const uint64_t off = n + 4 * lane;
+        const uint32_t off = n + 4 * lane;
         uint32_t eq = 4;
         bool stop = false;
         if (off + 4 <= limit) {
@@ -333,14 +334,14 @@ __device__ uint64_t wave_lcp_bwd(const uint8_t *a, const uint8_t *b, uint64_t n,
         } else {
             eq = 0; stop = true;
             if (off < limit) {
-                const uint32_t avail = (uint32_t) (limit - off);
+                const uint32_t avail = limit - off;
                 while (eq < avail && a[-(int64_t) (off + eq) - 1] == b[-(int64_t) (off + eq) - 1]) eq++;
             }
         }
         const unsigned long long bal = __ballot(stop);
         if (bal) {
             const int l = __builtin_ctzll(bal);
-            return n + 4 * (uint64_t) l + rl32(eq, l);
+            return n + 4 * (uint32_t) l + rl32(eq, l);
         }
         n += 4 * WAVE;
         if (steps && --steps == 0 && n < limit) { more = true; return n; }
@@ -351,38 +352,38 @@ __device__ uint64_t wave_lcp_bwd(const uint8_t *a, const uint8_t *b, uint64_t n,
 // Processes one visited hit. All arguments are wave-uniform. Returns true when a match was emitted.
 template <class Stack>
 __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q, Stack &stk, Chain &ch,
-                            uint64_t c, int64_t i, int64_t ell, int64_t rext, int64_t loDist, uint32_t flags) {
-    const int64_t K = v.K;
+                            uint64_t c, int32_t i, int32_t ell, int32_t rext, int32_t loDist, uint32_t flags) {
+    const int32_t K = v.K;
     uint64_t lo = 0, hi = 0;
     if (flags) window_ok(v, cg.lock, c, lo, hi);
     // true left run on demand: the automaton below only ever asks "is ell >= x", so a capped run is
     // continued the first time it could matter
-    auto need_ell = [&](int64_t x) {
+    auto need_ell = [&](int32_t x) {
         if ((flags & HIT_CAPL) && x > ell) {
             const uint64_t d = c - lo;
-            const uint64_t jmax = (uint64_t) i < d ? (uint64_t) i : d;
+            const uint32_t jmax = (uint64_t) i < d ? (uint32_t) i : (uint32_t) d;
             bool more;
-            ell = (int64_t) wave_lcp_bwd(v.ref + c, q + i, (uint64_t) ell, jmax, 0, more);
+            ell = (int32_t) wave_lcp_bwd(v.ref + c, q + i, (uint32_t) ell, jmax, 0, more);
             flags &= ~HIT_CAPL;
         }
     };
-    int64_t s = 0;                                   // (p1, p2) = (c - s, i - s)
+    int32_t s = 0;                                   // (p1, p2) = (c - s, i - s)
     int keep = stk.size();                           // resSizeWithoutOverlapped
     bool brokeOut = false;
     while (keep-- > 0) {                             // .cpp:253
-        int64_t mPos, mLen;
+        int32_t mPos, mLen;
         stk.get(keep, mPos, mLen);
-        const int64_t mEnd = mPos + mLen;
+        const int32_t mEnd = mPos + mLen;
         if (mEnd < i - s) {                          // .cpp:255
-            const int64_t g = mEnd;
+            const int32_t g = mEnd;
             need_ell((loDist < i - g + 1 ? loDist : i - g + 1) - 1);
-            int64_t t = loDist < i - g + 1 ? loDist : i - g + 1;
+            int32_t t = loDist < i - g + 1 ? loDist : i - g + 1;
             if (ell + 1 < t) t = ell + 1;
             if (t > s) s = t;                        // .cpp:257-259
             if (i - s > g - 1) { brokeOut = true; break; }   // .cpp:260-261
             s -= 1;                                  // .cpp:262
         }
-        const int64_t d = (i - s) - mPos;            // lastDelta, .cpp:264
+        const int32_t d = (i - s) - mPos;            // lastDelta, .cpp:264
         bool fail = (loDist - s < d) || (mLen > OVERLAP_MATCH_MAX_LENGTH);
         if (!fail) {
             need_ell(s + d);
@@ -396,30 +397,31 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
     ch.visited++;
     if (keep < 0) {                                  // .cpp:277-280
         need_ell((loDist < i + 1 ? loDist : i + 1) - 1);
-        int64_t t = loDist < i + 1 ? loDist : i + 1;
+        int32_t t = loDist < i + 1 ? loDist : i + 1;
         if (ell + 1 < t) t = ell + 1;
         if (t > s) s = t;
     } else {                                         // .cpp:285-289
-        int64_t mPos, mLen;
+        int32_t mPos, mLen;
         stk.get(keep, mPos, mLen);
-        const int64_t overlap = (mPos + mLen) - (i - s + 1);
+        const int32_t overlap = (mPos + mLen) - (i - s + 1);
         if (overlap > 0) s -= overlap;
     }
     ++keep;
     // right1 - p1 > minMatchLength, .cpp:298 (the K-mer itself was verified by the probe kernel)
-    if (K + rext + s > (int64_t) v.minLen || (flags & HIT_CAPR)) {
+    if (K + rext + s > (int32_t) v.minLen || (flags & HIT_CAPR)) {
         if (flags & HIT_CAPR) {
-            const uint64_t a = hi - (c + K), b = cg.n - ((uint64_t) i + K);
+            const uint64_t a = hi - (c + K);
+            const uint32_t b = (uint32_t) cg.n - (uint32_t) (i + K);
             bool more;
-            rext = (int64_t) wave_lcp_fwd(v.ref + c + K, q + i + K, (uint64_t) rext, a < b ? a : b, 0, more);
+            rext = (int32_t) wave_lcp_fwd(v.ref + c + K, q + i + K, (uint32_t) rext, a < b ? (uint32_t) a : b, 0, more);
             flags &= ~HIT_CAPR;
         }
-        if (K + rext + s > (int64_t) v.minLen) {
+        if (K + rext + s > (int32_t) v.minLen) {
             Match m;
-            m.posSrc = (uint64_t) ((int64_t) c - s + 1);
-            m.len = (uint64_t) (K + rext + s - 1);
-            m.posDest = (uint64_t) (i - s + 1);
-            int64_t skip = K + rext;                 // (matchEnd - i2), k2 == 1, .cpp:308
+            m.posSrc = c - (uint64_t) (int64_t) (s - 1);
+            m.len = (uint64_t) (uint32_t) (K + rext + s - 1);
+            m.posDest = (uint64_t) (uint32_t) (i - s + 1);
+            int32_t skip = K + rext;                 // (matchEnd - i2), k2 == 1, .cpp:308
             skip -= skip > v.skipMargin ? v.skipMargin : skip;
             ch.scan = skip ? i + skip : i + 1;       // .cpp:310-313 then the loop's i2 += k2
             stk.truncate_push(keep, m, ch.scan);
@@ -434,36 +436,58 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
 
 // A visited candidate: verify the K-mer (memcmp(curr1, curr2, K), .cpp:298 — a failed candidate changes
 // no state in the reference either) and take the first step of the right run (.cpp:227-246) and of the
-// left run. The first step is one byte per lane (64 bytes per side = one sector each for the reference
-// and the query: runs between 1 %-divergent genomes average ~50 bytes, wider steps only move unused
-// bytes); the loads of all three comparisons are issued before any of them is consumed, so a visit
-// costs one memory round trip. Longer runs continue 256 bytes per step (wave_lcp_fwd / wave_lcp_bwd).
+// left run. All of it is ONE dword load per lane from the reference and one from the query: the wave
+// reads the 256 bytes starting LEFTW bytes before the candidate, so lanes [0, LEFTW/4) hold the left
+// run, the next K/4 lanes the K-mer and the rest the first 256 - LEFTW - K bytes of the right run. (The
+// chains keep every CU's vector-memory pipeline busy — a wave-wide load occupies it for 16 cycles
+// whatever its width — so a visit is priced in load instructions, not in bytes.) A lane whose dword
+// crosses a limit of its run is not loaded and ends the run there; if the run really reaches it the last
+// < 4 bytes are compared one by one. Longer runs continue 256 bytes per step (wave_lcp_fwd / _bwd).
+constexpr int LEFTW = 64;
+
 template <class Stack>
-__device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stack &stk, Chain &ch, int64_t i, uint32_t val) {
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
+__device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stack &stk, Chain &ch, int32_t i, uint32_t val) {
+    const int32_t lane = (int32_t) (threadIdx.x & (WAVE - 1));
     ch.cands++;
     const uint64_t c = (uint64_t) val << v.k1ord;                     // htDecodePos, .h:133
     uint64_t lo, hi;
     window_ok(v, cg.lock, c, lo, hi);
-    const int64_t K = v.K;
+    const int32_t K = v.K;
     const uint8_t *r0 = v.ref + c, *q0 = q + i;
-    const uint64_t ra = hi - (c + K), rb = cg.n - ((uint64_t) i + K);
-    const uint64_t limR = ra < rb ? ra : rb;
+    const uint64_t ra = hi - (c + K);
+    const uint32_t rb = (uint32_t) cg.n - (uint32_t) (i + K);
+    const int32_t limR = (int32_t) (ra < rb ? (uint32_t) ra : rb);
     const uint64_t d = c - lo;
-    const uint64_t limL = (uint64_t) i < d ? (uint64_t) i : d;
-    const bool inR = lane < limR, inL = lane < limL, isK = (int) lane < (int) (K / 4);
-    uint32_t xk = 0;
-    uint8_t ar = 0, br = 0, al = 0, bl = 0;
-    if (isK) xk = ld_u32(r0 + 4 * lane) ^ ld_u32(q0 + 4 * lane);
-    if (inR) { ar = r0[K + lane]; br = q0[K + lane]; }
-    if (inL) { al = r0[-(int64_t) lane - 1]; bl = q0[-(int64_t) lane - 1]; }
-    if (__ballot(xk != 0)) { ch.scan = i + 1; return; }
-    const unsigned long long sr = __ballot(!inR || ar != br), sl = __ballot(!inL || al != bl);
-    // the first stopping lane is the first mismatch or the first byte past the limit
-    const uint64_t rext = sr ? (uint64_t) __builtin_ctzll(sr) : (uint64_t) WAVE;
-    const uint64_t ell = sl ? (uint64_t) __builtin_ctzll(sl) : (uint64_t) WAVE;
-    process_hit(v, cg, q, stk, ch, c, i, (int64_t) ell, (int64_t) rext, (int64_t) (d > 0xFFFFFFFFull ? 0xFFFFFFFFull : d),
-                (sl ? 0u : HIT_CAPL) | (sr ? 0u : HIT_CAPR));
+    const int32_t limL = (uint64_t) i < d ? i : (int32_t) d;
+    constexpr int LL = LEFTW / 4;                                     // lanes of the left run
+    const int32_t rel = 4 * lane - LEFTW;                             // first byte of the lane's dword, relative to the candidate
+    const bool full = lane < LL ? -rel <= limL : rel + 4 <= K + limR; // the dword lies inside its run's limit
+    uint32_t x = 0;
+    if (full) x = ld_u32(r0 + rel) ^ ld_u32(q0 + rel);
+    const unsigned long long stopAll = __ballot(!full || x != 0);
+    const unsigned long long fwd = stopAll >> LL;                     // bit t: lane LL + t
+    if (fwd & ((1ull << (K / 4)) - 1)) { ch.scan = i + 1; return; }   // K-mer differs (its lanes are always inside the limits)
+    const unsigned long long fullAll = __ballot(full);
+    int32_t rext = 4 * (WAVE - LL) - K;
+    const bool capR = fwd == 0;
+    if (!capR) {
+        const int l = LL + __builtin_ctzll(fwd);
+        rext = 4 * (l - LL) - K;
+        if ((fullAll >> l) & 1) rext += __builtin_ctz(rl32(x, l)) >> 3;
+        else while (rext < limR && r0[K + rext] == q0[K + rext]) rext++;      // the lane that holds the limit
+    }
+    const uint32_t bwd = (uint32_t) stopAll & ((1u << LL) - 1);
+    int32_t ell = LEFTW;
+    const bool capL = bwd == 0;
+    if (!capL) {
+        const int l = 31 - __builtin_clz(bwd);                        // the stopping lane nearest to the candidate
+        ell = 4 * (LL - 1 - l);
+        if ((fullAll >> l) & 1) ell += __builtin_clz(rl32(x, l)) >> 3;
+        else while (ell < limL && r0[-ell - 1] == q0[-ell - 1]) ell++;
+    }
+    // loDist only ever competes with distances inside the contig (< 2^31)
+    process_hit(v, cg, q, stk, ch, c, i, ell, rext, (int32_t) (d > 0x7FFFFFFFull ? 0x7FFFFFFFull : d),
+                (capL ? HIT_CAPL : 0u) | (capR ? HIT_CAPR : 0u));
 }
 
 // Runs the chain over the candidates at query positions [p0, p1) of one contig (p1 <= positions).
@@ -473,32 +497,32 @@ struct NoStop { __device__ __forceinline__ bool operator()() { return false; } }
 
 template <class Stack, class Stop = NoStop>
 __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
-                          int64_t p0, int64_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
+                          int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     constexpr int NB = 4;
     while (true) {
-        const int64_t s = ch.scan > p0 ? ch.scan : p0;
+        const int32_t s = ch.scan > p0 ? ch.scan : p0;
         if (s >= p1) break;
-        const int64_t base = s & ~(int64_t) (WAVE - 1);
+        const int32_t base = s & ~(WAVE - 1);
         uint32_t w[NB];
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            const int64_t pos = base + k * WAVE + lane;
+            const int32_t pos = base + k * WAVE + (int32_t) lane;
             w[k] = (pos >= s && pos < p1) ? cand[pos] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            const int64_t bk = base + k * WAVE;
+            const int32_t bk = base + k * WAVE;
             if (bk >= p1) break;
             if (ch.scan >= bk + WAVE) continue;                       // jumped over this batch
             unsigned long long m = __ballot(w[k] != 0);
-            const int64_t rel0 = ch.scan - bk;
+            const int32_t rel0 = ch.scan - bk;
             if (rel0 > 0) m &= ~((1ull << rel0) - 1);
             while (m) {
                 const int l = __builtin_ctzll(m);
                 visit(v, cg, q, stk, ch, bk + l, rl32(w[k], l));
                 if (stop()) return;
-                const int64_t rel = ch.scan - bk;                     // first lane still to be visited
+                const int32_t rel = ch.scan - bk;                     // first lane still to be visited
                 m = rel >= WAVE ? 0ull : (m & ~((1ull << rel) - 1));
             }
             if (ch.scan < bk + WAVE) ch.scan = bk + WAVE < p1 ? bk + WAVE : p1;
@@ -518,7 +542,7 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
     ch.scan = 0; ch.minTouched = 0; ch.minKeep = 0; ch.visited = 0; ch.cands = 0; ch.emitted = false;
     ArrayStack<Match> stk;
     stk.st = matches + cg.matchBase; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
-    const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
+    const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
     run_chain(v, cg, qbuf + cg.qoff, cand + cg.candBase, 0, npos, stk, ch);
     if (threadIdx.x == 0) matchCount[blockIdx.x] = (uint32_t) stk.sp;
 }
@@ -565,9 +589,9 @@ __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_
     const uint32_t g = blockIdx.x;
     const Contig cg = contigs[rbContig[g]];
     const uint32_t b = g - cg.rb0;
-    const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
-    const int64_t w0 = (int64_t) b * rb * TILE;
-    const int64_t w1 = w0 + (int64_t) rb * TILE < npos ? w0 + (int64_t) rb * TILE : npos;
+    const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
+    const int32_t w0 = (int32_t) (b * rb * TILE);
+    const int32_t w1 = w0 + (int32_t) (rb * TILE) < npos ? w0 + (int32_t) (rb * TILE) : npos;
     const uint32_t *cd = cand + cg.candBase;
     Chain ch;
     ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
@@ -620,14 +644,14 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     vs.segTop = -1; vs.topKeep = 0; vs.topPrev = -1; vs.size_ = 0; vs.own = nullptr; vs.ownN = 0; vs.curSeg = -1; vs.curLocal = 0; vs.curR = 0;
     for (uint32_t b = lane; b < cg.nrb; b += WAVE) { vs.keepN[b] = 0; vs.segStart[b] = 0; }
     __builtin_amdgcn_s_waitcnt(0);
-    int64_t scanT = 0;                 // true scan position
+    int32_t scanT = 0;                 // true scan position
     constexpr int TW = 3 * SNAP;       // u64 words of the newest-rows window
     __shared__ uint64_t ptop[TW];      // newest true rows, newest first, {posSrc, len, posDest} each
     int known = 0;                     // rows of ptop that are valid
     uint32_t replayed = 0;
     const BlockRec *rc = recs + cg.rb0;
-    const int64_t span = (int64_t) rb * TILE;
-    const int64_t npos = cg.n >= (uint64_t) v.K ? (int64_t) (cg.n - v.K + 1) : 0;
+    const int32_t span = (int32_t) (rb * TILE);
+    const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
     constexpr int STAGE = 16;          // block records fetched per coalesced burst
     __shared__ uint4 srec[STAGE * sizeof(BlockRec) / 16];
     for (uint32_t b = 0; b < cg.nrb; b++) {
@@ -637,10 +661,10 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
             for (uint32_t i = lane; i < nrec * (sizeof(BlockRec) / 16); i += WAVE) srec[i] = src[i];
             __builtin_amdgcn_s_waitcnt(0);
         }
-        const int64_t w0 = (int64_t) b * span;
+        const int32_t w0 = (int32_t) b * span;
         if (scanT >= w0 + span) continue;                       // the sequential loop jumped over this block
         const BlockRec *r = (const BlockRec *) (srec + (b % STAGE) * (sizeof(BlockRec) / 16));
-        const int64_t rScanB = (int64_t) rfl64((uint64_t) r->scanB), rScanF = (int64_t) rfl64((uint64_t) r->scanF);
+        const int32_t rScanB = (int32_t) rfl32((uint32_t) r->scanB), rScanF = (int32_t) rfl32((uint32_t) r->scanF);
         const int spB = (int) rfl32((uint32_t) r->spB), spF = (int) rfl32((uint32_t) r->spF);
         const int minTouched = (int) rfl32((uint32_t) r->minTouched), minKeep = (int) rfl32((uint32_t) r->minKeep);
         const uint64_t *bw = (const uint64_t *) r->bTop, *fw = (const uint64_t *) r->fTop;
@@ -711,7 +735,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
                 const uint64_t ePos = rfl64(own[vs.ownN - 1].posDest), eLen = rfl64(own[vs.ownN - 1].len), eSrc = rfl64(own[vs.ownN - 1].posSrc);
                 while (sp < spF && rfl64(spec[sp].posDest) < ePos) sp++;
                 if (sp < spF && rfl64(spec[sp].posDest) == ePos && rfl64(spec[sp].len) == eLen && rfl64(spec[sp].posSrc) == eSrc &&
-                    (int64_t) rfl64((uint64_t) spec[sp].scanAfter) == ch.scan) { syncAt = sp; return true; }
+                    (int32_t) rfl32((uint32_t) spec[sp].scanAfter) == ch.scan) { syncAt = sp; return true; }
                 return false;
             };
             run_chain(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch, stop);

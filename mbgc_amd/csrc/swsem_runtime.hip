@@ -284,7 +284,8 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         Contig &cg = h->contigs[c];
         cg.qoff = offsets[c];
         cg.n = offsets[c + 1] - offsets[c];
-        if (cg.n >= (1ull << 32)) return fail(SWSEM_EINVAL, "contig %d longer than 4 GiB", c);
+        // query positions are 32-bit signed in the resolve automaton (and uint32 in processMatches, MBGC_Encoder.cpp:145)
+        if (cg.n >= (1ull << 31) - (1ull << 20)) return fail(SWSEM_EINVAL, "contig %d longer than 2^31 - 2^20 bytes", c);
         cg.lock = lockPos ? lockPos[c] : UINT64_MAX;
         const uint64_t npos = cg.n >= (uint64_t) h->K ? cg.n - h->K + 1 : 0;
         cg.tile0 = tiles;
