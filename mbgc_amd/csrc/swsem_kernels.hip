@@ -28,6 +28,35 @@ __global__ void __launch_bounds__(256) k_load_rc(const uint8_t *__restrict__ src
 
 __global__ void k_set_byte(uint8_t *p, uint8_t v) { *p = v; }
 
+// The byte writes of a whole finalize call (swsem_finalize_targets): every extension copied to its place
+// in the reference buffer by one launch (block = 4096 bytes of one piece, 16 bytes per thread, any
+// alignment), then the separator bytes in program order by one thread.
+struct CopyPiece { uint64_t dst; const uint8_t *src; uint64_t len; };
+struct BytePiece { uint64_t off, val; };
+__global__ void __launch_bounds__(256) k_copy_multi(uint8_t *__restrict__ ref, const CopyPiece *__restrict__ pieces,
+                                                    const uint64_t *__restrict__ first, int np) {
+    int lo = 0, hi = np - 1;                                        // piece p with first[p] <= blockIdx.x < first[p+1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const CopyPiece pc = pieces[lo];
+    const uint64_t o = ((uint64_t) blockIdx.x - first[lo]) * 4096 + 16 * (uint64_t) threadIdx.x;
+    if (o >= pc.len) return;
+    uint8_t *d = ref + pc.dst + o;
+    const uint8_t *s = pc.src + o;
+    if (o + 16 <= pc.len) {
+        uint4 t;
+        memcpy(&t, s, 16);
+        memcpy(d, &t, 16);
+    } else
+        for (uint64_t k = 0; k < pc.len - o; k++) d[k] = s[k];
+}
+__global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restrict__ b, int n) {
+    for (int i = 0; i < n; i++) ref[b[i].off] = (uint8_t) b[i].val;
+}
+
+
 // processIgnoreCollisionsRef, .cpp:146-171. Thread t < nMain inserts the main-loop sample at
 // S + t*k1 with epoch `epoch`; thread nMain + u inserts the tail sample T + u*k1 with epoch + 1
 // (the tail runs after the main loop on the CPU, so it wins collisions against it).

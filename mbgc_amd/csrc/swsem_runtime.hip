@@ -77,8 +77,9 @@ struct swsem {
     uint32_t epoch = 1;
     bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
     std::vector<InsertPiece> pendingPieces;
-    DevBuf<InsertPiece> dPieces;
-    DevBuf<uint64_t> dPieceFirst;
+    std::vector<CopyPiece> pendingCopies;    // ... and its byte writes: device-to-device copies,
+    std::vector<BytePiece> pendingBytes;     // then single bytes (separators), each list in program order
+    DevBuf<uint64_t> dTables;                // one upload: insert pieces, their prefix, copy pieces, their prefix, bytes
     // --- per-round scratch
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
@@ -101,6 +102,8 @@ struct swsem {
     DevBuf<MetaState> dEStates;
     std::vector<EmitContig> ecg;
     std::vector<uint32_t> chunkOwner;
+    std::vector<int> ewhich;
+    std::vector<uint64_t> eloaded;
     std::vector<EmitOut> eout;
     std::vector<uint8_t> hostStreams;
     std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
@@ -229,12 +232,17 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
                 const uint64_t thr = (tmpLength + 3) / 4;
                 const unsigned blocks = (unsigned) std::min<uint64_t>((thr + 255) / 256, 8192);
                 k_load_rc<<<dim3(blocks), dim3(256), 0, h->stream>>>(text + len - tmpLength, h->ref + h->pos1, tmpLength, h->lut);
+            } else if (h->deferInserts) {
+                CopyPiece cp; cp.dst = (uint64_t) h->pos1; cp.src = text; cp.len = tmpLength;
+                h->pendingCopies.push_back(cp);
             } else
                 HIPCHK(hipMemcpyAsync(h->ref + h->pos1, text, tmpLength, hipMemcpyDeviceToDevice, h->stream));
             h->mark(SWSEM_K_LOAD, false);
         }
-        if (addSep && (uint64_t) h->pos1 + tmpLength == h->swEnd)
-            k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->swEnd - 1, (uint8_t) sep);
+        if (addSep && (uint64_t) h->pos1 + tmpLength == h->swEnd) {
+            if (h->deferInserts) { BytePiece bp; bp.off = h->swEnd - 1; bp.val = (uint64_t) (uint8_t) sep; h->pendingBytes.push_back(bp); }
+            else k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->swEnd - 1, (uint8_t) sep);
+        }
         h->pos1 += (int64_t) tmpLength;
         int r = insert_samples(h);
         if (r) return r;
@@ -249,23 +257,43 @@ int flush_inserts(swsem *h);
 }  // namespace
 // (defined below, after run_batch's helpers)
 namespace {
-// one launch for every insertion phase collected while deferInserts was set
+// everything collected while deferInserts was set: all copies in one launch, the separator bytes in one
+// (in program order; no copy of a round lands on a byte written by an earlier separator of the same
+// round), then every insertion phase in one launch. The tables travel in a single upload.
 int flush_inserts(swsem *h) {
-    const int np = (int) h->pendingPieces.size();
-    if (!np) return SWSEM_OK;
-    std::vector<uint64_t> first(np + 1, 0);
-    for (int i = 0; i < np; i++) first[i + 1] = first[i] + h->pendingPieces[i].nMain + h->pendingPieces[i].nTail;
+    const size_t np = h->pendingPieces.size(), nc = h->pendingCopies.size(), nb = h->pendingBytes.size();
+    if (!np && !nc && !nb) return SWSEM_OK;
+    constexpr uint64_t CHUNK = 256 * 16;                 // bytes per copy block
+    const size_t wPieces = np * (sizeof(InsertPiece) / 8), wCopies = nc * (sizeof(CopyPiece) / 8), wBytes = nb * (sizeof(BytePiece) / 8);
+    std::vector<uint64_t> tab(wPieces + (np + 1) + wCopies + (nc + 1) + wBytes);
+    uint64_t *tPieces = tab.data(), *tFirst = tPieces + wPieces, *tCopies = tFirst + np + 1, *tCFirst = tCopies + wCopies, *tBytes = tCFirst + nc + 1;
+    if (np) memcpy(tPieces, h->pendingPieces.data(), np * sizeof(InsertPiece));
+    tFirst[0] = 0;
+    for (size_t i = 0; i < np; i++) tFirst[i + 1] = tFirst[i] + h->pendingPieces[i].nMain + h->pendingPieces[i].nTail;
+    if (nc) memcpy(tCopies, h->pendingCopies.data(), nc * sizeof(CopyPiece));
+    tCFirst[0] = 0;
+    for (size_t i = 0; i < nc; i++) tCFirst[i + 1] = tCFirst[i] + (h->pendingCopies[i].len + CHUNK - 1) / CHUNK;
+    if (nb) memcpy(tBytes, h->pendingBytes.data(), nb * sizeof(BytePiece));
     int r;
-    if ((r = h->dPieces.reserve(np)) || (r = h->dPieceFirst.reserve(np + 1))) return r;
-    HIPCHK(hipMemcpyAsync(h->dPieces.p, h->pendingPieces.data(), np * sizeof(InsertPiece), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->dPieceFirst.p, first.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-    h->mark(SWSEM_K_INSERT, true);
-    k_insert_multi<<<dim3((unsigned) ((first[np] + 255) / 256)), dim3(256), 0, h->stream>>>(h->ref, h->ht, h->dPieces.p, h->dPieceFirst.p,
-                                                                                         np, h->k1, h->k1ord, h->K, h->mask);
-    h->mark(SWSEM_K_INSERT, false);
+    if ((r = h->dTables.reserve(tab.size()))) return r;
+    HIPCHK(hipMemcpyAsync(h->dTables.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, h->stream));
+    const uint64_t *d = h->dTables.p;
+    if (nc) {
+        h->mark(SWSEM_K_LOAD, true);
+        k_copy_multi<<<dim3((unsigned) tCFirst[nc]), dim3(256), 0, h->stream>>>(h->ref, (const CopyPiece *) (d + (tCopies - tab.data())),
+                                                                              d + (tCFirst - tab.data()), (int) nc);
+        h->mark(SWSEM_K_LOAD, false);
+    }
+    if (nb) k_set_bytes<<<1, 1, 0, h->stream>>>(h->ref, (const BytePiece *) (d + (tBytes - tab.data())), (int) nb);
+    if (np) {
+        h->mark(SWSEM_K_INSERT, true);
+        k_insert_multi<<<dim3((unsigned) ((tFirst[np] + 255) / 256)), dim3(256), 0, h->stream>>>(
+            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask);
+        h->mark(SWSEM_K_INSERT, false);
+    }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));      // the host tables above are stack/vector storage
-    h->pendingPieces.clear();
+    HIPCHK(hipStreamSynchronize(h->stream));      // the host table above is vector storage
+    h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear();
     return SWSEM_OK;
 }
 
@@ -442,7 +470,7 @@ void swsem_destroy(swsem_t *h) {
     h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEOwner.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
     h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
     h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release(); h->dEPack.release();
-    h->dPieces.release(); h->dPieceFirst.release();
+    h->dTables.release();
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -531,8 +559,10 @@ int swsem_load_separator(swsem_t *h, int sep) {
         // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was
         if (h->deferInserts) { int r = flush_inserts(h); if (r) return r; }
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1 - 1, (uint8_t) sep);
-    }
-    else
+    } else if (h->deferInserts) {
+        BytePiece bp; bp.off = (uint64_t) h->pos1++; bp.val = (uint64_t) (uint8_t) sep;
+        h->pendingBytes.push_back(bp);
+    } else
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1++, (uint8_t) sep);
     HIPCHK(hipGetLastError());
     return SWSEM_OK;
@@ -739,7 +769,8 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
         return fail(SWSEM_EINVAL, "gapDepthOffsetEncoding %d out of range (MAX_GAP_DEPTH / 2)", p->gapDepthOffsetEncoding);
     int r;
     h->ecg.assign(n, EmitContig());
-    std::vector<int> which(n);
+    std::vector<int> &which = h->ewhich;       // uploaded asynchronously: must outlive this call
+    which.assign(n, 0);
     uint64_t rows = 0, arena = 0;
     h->chunkOwner.clear();
     for (int k = 0; k < n; k++) {
@@ -776,8 +807,9 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     HIPCHK(hipMemcpyAsync(h->dEOwner.p, h->chunkOwner.data(), chunks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dECg.p, h->ecg.data(), n * sizeof(EmitContig), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dEWhich.p, which.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    if (nLoaded) HIPCHK(hipMemcpyAsync(h->dELoaded.p, refExtLoadedPos, nLoaded * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
+    if (nLoaded) HIPCHK(hipMemcpyAsync(h->dELoaded.p, h->eloaded.data(), nLoaded * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    // no synchronisation here: the kernels below queue up behind match-finding while it is still running
     EmitView v;
     v.ref = h->ref; v.qbuf = h->qdev; v.matches = h->dMatches.p; v.matchCount = h->dMatchCount.p;
     v.pos1 = (uint64_t) h->pos1; v.refLength = h->refLength(); v.maxRefLength = h->maxRefLength;

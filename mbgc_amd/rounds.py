@@ -254,7 +254,10 @@ class RoundRunner:
             s0, s1 = int(pk["starts"][k * 6]), int(pk["starts"][k * 6 + 6])
             chunks.append(pk["buf"][s0:s1])
             meta.extend([c] + [int(x) for x in pk["sizes"][k]])
-        local = torch.cat(chunks) if chunks else torch.empty(0, dtype=torch.uint8, device=self.device)
+        if len(packs) == 1 and len(items) == len(packs[0]["starts"]) // 6 and all(k == j for j, (_, _, k) in enumerate(items)):
+            local = packs[0]["buf"][: int(packs[0]["starts"][-1])]     # one emission, nothing dropped: already packed in order
+        else:
+            local = torch.cat(chunks) if chunks else torch.empty(0, dtype=torch.uint8, device=self.device)
         all_bytes = self._allgather_bytes(local) if self.world > 1 else [local]
         all_meta = self._allgather_ints(meta + [-1]) if self.world > 1 else [meta + [-1]]
         self.stream_bytes += sum(int(b.numel()) for b in all_bytes)
