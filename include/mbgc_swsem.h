@@ -73,7 +73,9 @@ int swsem_load_separator(swsem_t *h, int sep);                    /* loadSeparat
 /* finalizeParallelProcessingOfTarget for n targets in target order (MGMP.cpp:440-457 + MBGC_Encoder.cpp:557-562):
  * per target loadRef(ext, len, false, addSep, sep), then — lazy mode — loadSeparator(sep), then
  * releaseWorkerMatchingLockPos(lockPos[i]) (lockPos may be NULL). loadedAfter[i] receives
- * getLoadedRefLength() after target i. One call per round instead of 3 n. */
+ * getLoadedRefLength() after target i. One call per round instead of 3 n. The copies are queued on the
+ * handle's stream and the call returns: the ext_dev buffers must stay valid until swsem_synchronize() or any
+ * later call that hands results back to the host (swsem_batch_counts, swsem_emit_batch, swsem_match ...). */
 int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
                            int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter);
 /* PgHelpers::upperReverseComplement(src, n, dst) on device buffers, utils/helper.cpp:405-410 — what

@@ -80,6 +80,10 @@ struct swsem {
     std::vector<CopyPiece> pendingCopies;    // ... and its byte writes: device-to-device copies,
     std::vector<BytePiece> pendingBytes;     // then single bytes (separators), each list in program order
     DevBuf<uint64_t> dTables;                // one upload: insert pieces, their prefix, copy pieces, their prefix, bytes
+    struct HostTab {                         // pinned staging for that upload; reused once its copy has completed
+        uint64_t *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false;
+    } hostTables[2];
+    int hostTableSel = 0;
     // --- per-round scratch
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
@@ -105,6 +109,7 @@ struct swsem {
     std::vector<int> ewhich;
     std::vector<uint64_t> eloaded;
     std::vector<EmitOut> eout;
+    uint8_t *pin = nullptr; size_t pinCap = 0, pinExtraAt = 0;
     std::vector<uint8_t> hostStreams;
     std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
@@ -265,7 +270,18 @@ int flush_inserts(swsem *h) {
     if (!np && !nc && !nb) return SWSEM_OK;
     constexpr uint64_t CHUNK = 256 * 16;                 // bytes per copy block
     const size_t wPieces = np * (sizeof(InsertPiece) / 8), wCopies = nc * (sizeof(CopyPiece) / 8), wBytes = nb * (sizeof(BytePiece) / 8);
-    std::vector<uint64_t> tab(wPieces + (np + 1) + wCopies + (nc + 1) + wBytes);
+    // host table: a member (two alternating ones), so the upload needs no wait before returning
+    swsem::HostTab &ht = h->hostTables[h->hostTableSel ^= 1];
+    const size_t words = wPieces + (np + 1) + wCopies + (nc + 1) + wBytes;
+    if (ht.pending) { HIPCHK(hipEventSynchronize(ht.ev)); ht.pending = false; }
+    if (ht.cap < words) {
+        if (ht.p) HIPCHK(hipHostFree(ht.p));
+        ht.p = nullptr; ht.cap = 0;
+        if (hipHostMalloc((void **) &ht.p, (words + 64) * 8, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", (words + 64) * 8);
+        ht.cap = words + 64;
+    }
+    if (!ht.ev) HIPCHK(hipEventCreateWithFlags(&ht.ev, hipEventDisableTiming));
+    struct { uint64_t *p; uint64_t *data() { return p; } size_t n; size_t size() const { return n; } } tab = {ht.p, words};
     uint64_t *tPieces = tab.data(), *tFirst = tPieces + wPieces, *tCopies = tFirst + np + 1, *tCFirst = tCopies + wCopies, *tBytes = tCFirst + nc + 1;
     if (np) memcpy(tPieces, h->pendingPieces.data(), np * sizeof(InsertPiece));
     tFirst[0] = 0;
@@ -277,6 +293,8 @@ int flush_inserts(swsem *h) {
     int r;
     if ((r = h->dTables.reserve(tab.size()))) return r;
     HIPCHK(hipMemcpyAsync(h->dTables.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(ht.ev, h->stream));
+    ht.pending = true;
     const uint64_t *d = h->dTables.p;
     if (nc) {
         h->mark(SWSEM_K_LOAD, true);
@@ -292,7 +310,6 @@ int flush_inserts(swsem *h) {
         h->mark(SWSEM_K_INSERT, false);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));      // the host table above is vector storage
     h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear();
     return SWSEM_OK;
 }
@@ -385,19 +402,48 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     return SWSEM_OK;
 }
 
-int fetch_counts(swsem *h) {
-    const int n = (int) h->contigs.size();
-    h->matchCount.resize(n);
-    HIPCHK(hipMemcpyAsync(h->matchCount.data(), h->dMatchCount.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    unsigned long long st[8];
-    HIPCHK(hipMemcpyAsync(st, h->dStats.p, sizeof st, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->stats[1] = st[1]; h->stats[2] = st[2]; h->stats[5] = st[3];
-    uint64_t tot = 0;
-    for (int c = 0; c < n; c++) tot += h->matchCount[c];
-    h->stats[3] = tot;
+// pinned landing zone for everything a batch hands back to the host: {stats[8] | match counts | emit results}:
+// the copies queue up back to back and one wait serves them all
+int pin_reserve(swsem *h, size_t bytes) {
+    if (h->pinCap >= bytes) return SWSEM_OK;
+    if (h->pin) HIPCHK(hipHostFree(h->pin));
+    h->pin = nullptr; h->pinCap = 0;
+    if (hipHostMalloc((void **) &h->pin, bytes + 4096, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", bytes + 4096);
+    h->pinCap = bytes + 4096;
     return SWSEM_OK;
 }
+
+// queues the copies of the match counts and statistics (no wait)
+int queue_counts(swsem *h, size_t extraBytes) {
+    const size_t n = h->contigs.size();
+    const size_t countsAt = 64, extraAt = (countsAt + n * sizeof(uint32_t) + 63) & ~(size_t) 63;
+    int r = pin_reserve(h, extraAt + extraBytes);
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(h->pin, h->dStats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pin + countsAt, h->dMatchCount.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    h->pinExtraAt = extraAt;
+    return SWSEM_OK;
+}
+
+// after the wait: pinned block -> host state
+void take_counts(swsem *h) {
+    const size_t n = h->contigs.size();
+    const unsigned long long *st = (const unsigned long long *) h->pin;
+    h->matchCount.assign((const uint32_t *) (h->pin + 64), (const uint32_t *) (h->pin + 64) + n);
+    h->stats[1] = st[1]; h->stats[2] = st[2]; h->stats[5] = st[3];
+    uint64_t tot = 0;
+    for (size_t c = 0; c < n; c++) tot += h->matchCount[c];
+    h->stats[3] = tot;
+}
+
+int fetch_counts(swsem *h) {
+    int r = queue_counts(h, 0);
+    if (r) return r;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    take_counts(h);
+    return SWSEM_OK;
+}
+
 
 }  // namespace
 
@@ -471,6 +517,8 @@ void swsem_destroy(swsem_t *h) {
     h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
     h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release(); h->dEPack.release();
     h->dTables.release();
+    if (h->pin) { hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
+    for (auto &t : h->hostTables) { if (t.p) hipHostFree(t.p); if (t.ev) hipEventDestroy(t.ev); t = swsem::HostTab(); }
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -596,8 +644,7 @@ int swsem_match_batch_dev(swsem_t *h, const uint8_t *q, const uint64_t *offsets,
 
 int swsem_batch_counts(swsem_t *h, uint64_t *nm) {
     if (!h->batchValid) return fail(SWSEM_EINVAL, "no batch results");
-    int r = fetch_counts(h);
-    if (r) return r;
+    if (h->matchCount.size() != h->contigs.size()) { int r = fetch_counts(h); if (r) return r; }
     for (size_t c = 0; c < h->contigs.size(); c++) nm[c] = h->matchCount[c];
     return SWSEM_OK;
 }
@@ -839,9 +886,13 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     k_emit_write<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
     h->mark(SWSEM_K_EMIT, false);
     HIPCHK(hipGetLastError());
-    h->eout.resize(n);
-    HIPCHK(hipMemcpyAsync(h->eout.data(), h->dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream));
+    // results, match counts and statistics land in one pinned block behind one wait
+    const bool needCounts = h->matchCount.size() != h->contigs.size();
+    if ((r = queue_counts(h, n * sizeof(EmitOut)))) return r;
+    HIPCHK(hipMemcpyAsync(h->pin + h->pinExtraAt, h->dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (needCounts) take_counts(h);
+    h->eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
     uint64_t tot = 0;
     h->hostStreamOff.assign((size_t) n * SWSEM_NSTREAMS, 0);
     for (int k = 0; k < n; k++)

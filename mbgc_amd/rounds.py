@@ -60,6 +60,7 @@ class RoundRunner:
         self.locks_stream = bytearray()              # :563
         self.ref_ext_sizes = bytearray()             # :559-560
         self.stream_bytes = 0
+        self._keep = []                              # temporaries handed to finalize_targets: alive until the next host wait
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -121,6 +122,7 @@ class RoundRunner:
                 else:
                     un = [int(offsets[c + 1] - offsets[c]) for c in pending]     # matcher only: always extend
                 cnt = m.batch_counts()          # after the emission launches: no host round trip in between
+                self._keep.clear()              # the waits above cover every copy queued by earlier finalize calls
                 for k, c in enumerate(pending):
                     counts[c] = cnt[k]
                 skipped_local = [c for k, c in enumerate(pending) if int(un[k]) == SKIPPED]
@@ -191,58 +193,71 @@ class RoundRunner:
             return
         m = self.m
         # extension string of every local target in range: contig, then its reverse complement (:389-398)
-        my = [t for t in range(lo, hi) if t // T == self.rank] if self.world > 1 else list(range(lo, hi))
-        pieces, lens = [], []
+        my = [t for t in range(lo, hi) if t // T == self.rank] if self.world > 1 else range(lo, hi)
+        by_target = {}
+        for c, lt in enumerate(targets):
+            by_target.setdefault(lt, []).append(c)
+        base_ptr = qbuf.data_ptr()
+        pieces = []                                 # per target: (device pointer, bytes, tensor keeping them alive or None)
         for t in my:
-            lt = t - self.rank * T
             parts = []
-            for c in range(len(targets)):
-                if targets[c] != lt:
-                    continue
+            for c in by_target.get(t - self.rank * T, ()):
                 s, e = int(offsets[c]), int(offsets[c + 1])
                 n, un = e - s, unmatched[c]
                 if self.policy.proper_for_ext(n, un):
-                    parts.append(qbuf[s:e])
+                    parts.append((base_ptr + s, n, None, s))
                 if self.p is not None and self.policy.proper_for_rc_ext(n, un):
                     rc = torch.empty(n, dtype=torch.uint8, device=self.device)
-                    m.revcomp_dev(qbuf.data_ptr() + s, n, rc.data_ptr())
-                    parts.append(rc)
-            ext = torch.cat(parts) if len(parts) > 1 else (parts[0] if parts else qbuf[0:0])
-            pieces.append(ext)
-            lens.append(ext.numel())
+                    m.revcomp_dev(base_ptr + s, n, rc.data_ptr())
+                    parts.append((rc.data_ptr(), n, rc, -1))
+            if len(parts) == 1:
+                pieces.append(parts[0])
+            elif not parts:
+                pieces.append((0, 0, None, -1))
+            else:                                   # several strings of one target are loaded as one text
+                ext = torch.cat([x[2] if x[2] is not None else qbuf[x[3]: x[3] + x[1]] for x in parts])
+                pieces.append((ext.data_ptr(), ext.numel(), ext, -1))
+        # finalize_targets returns with its copies queued: their sources must outlive this function
+        self._keep.extend(x[2] for x in pieces if x[2] is not None)
         if self.world == 1:
-            self._finalize_many(pieces, [locks[t] for t in my])
+            self._finalize_many([x[0] for x in pieces], [x[1] for x in pieces], [locks[t] for t in my])
             return
-        local = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=self.device)
+        tens = [x[2] if x[2] is not None else qbuf[x[3]: x[3] + x[1]] for x in pieces if x[1]]
+        local = torch.cat(tens) if tens else torch.empty(0, dtype=torch.uint8, device=self.device)
         all_ext = self._allgather_bytes(local)
-        all_lens = self._allgather_ints(lens + [-1])           # -1 terminator keeps the tensor non-empty
+        self._keep.extend(all_ext)
+        all_lens = self._allgather_ints([x[1] for x in pieces] + [-1])           # -1 terminator keeps the tensor non-empty
         cur = [0] * self.world
         idx = [0] * self.world
-        exts = []
+        ptrs, lens = [], []
         for t in range(lo, hi):                                # global target order = rank-major in the round
             r = t // T
             ln = all_lens[r][idx[r]]
-            exts.append(all_ext[r][cur[r]: cur[r] + ln])
+            ptrs.append(all_ext[r].data_ptr() + cur[r] if ln else 0)
+            lens.append(ln)
             cur[r] += ln
             idx[r] += 1
-        self._finalize_many(exts, [locks[t] for t in range(lo, hi)])
+        self._finalize_many(ptrs, lens, [locks[t] for t in range(lo, hi)])
 
-    def _finalize_many(self, exts, locks):
+    def _finalize_many(self, ptrs, lens, locks):
         """finalizeParallelProcessingOfTarget for consecutive targets in one call into the library:
         loadRef(ext), lazy-mode separator, lock release (MGMP.cpp:440-457, MBGC_Encoder.cpp:557-563)"""
         m = self.m
         before = m.loaded_ref_length()
-        after = m.finalize_targets([e.data_ptr() if e.numel() else 0 for e in exts], [e.numel() for e in exts], locks, self.lazy)
-        for lk, a in zip(locks, after):
+        after = m.finalize_targets(ptrs, lens, locks, self.lazy)
+        for lk, a in zip(locks, after.tolist()):
             if self.lazy:
-                self.ref_ext_sizes += frugal64(int(a) - before)
+                self.ref_ext_sizes += frugal64(a - before)
                 if self.loaded is not None:
-                    self.loaded.append(int(a))
-                before = int(a)
+                    self.loaded.append(a)
+                before = a
             self.locks_stream += int(lk).to_bytes(8, "little")
 
     def _collect_streams(self, packs, targets, T, offsets):
         """per-target stream merge in target order on rank 0 (MBGC_Encoder.cpp:542-556)."""
+        if self.world == 1 and not self.keep_streams:
+            self.stream_bytes += sum(int(pk["sizes"][pk["ks"]].sum()) for pk in packs if pk["ks"])
+            return
         # order this rank's emitted contigs by contig index, pack their six streams into one tensor
         items = []
         for pk in packs:
