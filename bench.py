@@ -147,6 +147,7 @@ def main():
     for s in range(warm):
         runner.keep_streams = bool(args.check and s == 0)
         runner.run_round(*bufs[s])
+        runner.flush()
         if args.check and s == 0 and rank == 0 and world == 1:
             check_against_oracle(runner, base, sched[0][0], args.length, emit)
         runner.keep_streams = False
@@ -157,6 +158,7 @@ def main():
     for s in range(warm, warm + steps):
         tot_matches += int(runner.run_round(*bufs[s]).sum())
         replayed += m.batch_stats()["replayed_blocks"]
+    runner.flush()                                     # the last round's emission (its second phase runs beside the next round)
     barrier()
     dt = time.perf_counter() - t0
     prof = m.profile_get()

@@ -140,11 +140,24 @@ int swsem_emit(swsem_t *h, const swsem_emit_params_t *p, int contig, uint64_t lo
 int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
                      const int *unmatchedFractionFactor, const int64_t *processedTargetsCount, const int64_t *targetIdx,
                      const uint64_t *refExtLoadedPos, uint64_t nLoaded);
+/* swsem_emit_batch in two steps, for callers that overlap. _begin returns as soon as the part the caller's
+ * control flow depends on is known — processMatches' return value per contig incl. the dissimilarity verdict
+ * (swsem_emit_unmatched), i.e. what MGMP.cpp:382-399 decides the retry and the reference extension on — with
+ * the byte-level work (pairing, mismatch extensions, stream bytes) queued on a second stream. Between _begin
+ * and _end the caller may finalize the round (swsem_finalize_targets) and start the next one
+ * (swsem_match_batch_dev): the reference's workers run processMatches next to the finalizer in the same way
+ * (MGMP.cpp:520-555). The query buffer of the emitted batch must stay untouched until _end. Once the
+ * reference buffer has wrapped, loads wait for the running emission (they would overwrite text it reads).
+ * _end (also implied by swsem_emit_result / swsem_emit_pack_dev / the next _begin) waits for the streams. */
+int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+                           const int *unmatchedFractionFactor, const int64_t *processedTargetsCount, const int64_t *targetIdx,
+                           const uint64_t *refExtLoadedPos, uint64_t nLoaded);
+int swsem_emit_batch_end(swsem_t *h);
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out);
 /* Keep the streams in HBM (no host copy inside swsem_emit_batch; swsem_emit_result then copies on demand)
  * and pack them, (result, stream) major, into one device buffer — the unit the multi-GPU path gathers to
  * the rank that feeds the host-side PPMd/LZMA backend. sizes[n*6] and *total are host outputs; a NULL
- * dst_dev only reports sizes. */
+ * dst_dev only reports sizes. The copy has completed when the call returns (any stream may consume it). */
 void swsem_emit_set_host_copy(swsem_t *h, int on);
 int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched /* [n of the last swsem_emit_batch] */);
 int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total);

@@ -21,7 +21,7 @@ swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circula
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
-swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
+swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_end swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_copy""".split()
 
 
@@ -99,6 +99,8 @@ def lib():
         L.swsem_emit.argtypes = [vp, C.POINTER(EmitParams), ci, u64, ci, C.c_int64, C.c_int64, vp, u64,
                                  C.POINTER(Streams)]
         L.swsem_emit_batch.argtypes = [vp, C.POINTER(EmitParams), ci, vp, vp, vp, vp, vp, vp, u64]
+        L.swsem_emit_batch_begin.argtypes = L.swsem_emit_batch.argtypes
+        L.swsem_emit_batch_end.argtypes = [vp]
         L.swsem_emit_result.argtypes = [vp, ci, C.POINTER(Streams)]
         L.swsem_emit_set_host_copy.argtypes = [vp, ci]
         L.swsem_emit_set_host_copy.restype = None
@@ -239,7 +241,8 @@ class SlidingWindowSparseEMMatcher:
             streams[name] = bytes(np.ctypeslib.as_array(st.data[i], shape=(n,))) if n else b""
         return st.unmatchedChars, streams, st
 
-    def emit_batch(self, params, contigs=None, locks=None, factors=None, processed=None, target_idx=None, loaded=None, n=None):
+    def emit_batch(self, params, contigs=None, locks=None, factors=None, processed=None, target_idx=None, loaded=None, n=None,
+                   _entry="swsem_emit_batch"):
         """processMatches for several contigs of the last batch at once; fetch with emit_result(k)."""
         def arr(x, dt):
             return None if x is None else np.ascontiguousarray(x, dtype=dt)
@@ -248,8 +251,15 @@ class SlidingWindowSparseEMMatcher:
         ld = np.ascontiguousarray(loaded if loaded is not None else [0], dtype=np.uint64)
         cnt = n if n is not None else (ci.size if ci is not None else self._batch_n)
         ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-        _chk(lib().swsem_emit_batch(self.h, C.byref(params), cnt, ptr(ci), ptr(lk), ptr(fa), ptr(pr), ptr(ti), ptr(ld), ld.size))
+        _chk(getattr(lib(), _entry)(self.h, C.byref(params), cnt, ptr(ci), ptr(lk), ptr(fa), ptr(pr), ptr(ti), ptr(ld), ld.size))
         return cnt
+
+    def emit_batch_begin(self, *a, **k):
+        """emit_batch up to processMatches' return values (emit_unmatched); the stream bytes follow on a second
+        HIP stream while the caller finalizes the round and starts the next one. emit_batch_end() waits."""
+        return self.emit_batch(*a, _entry="swsem_emit_batch_begin", **k)
+
+    def emit_batch_end(self): _chk(lib().swsem_emit_batch_end(self.h))
 
     def emit_set_host_copy(self, on): lib().swsem_emit_set_host_copy(self.h, int(on))
 

@@ -110,6 +110,15 @@ struct swsem {
     std::vector<uint64_t> eloaded;
     std::vector<EmitOut> eout;
     uint8_t *pin = nullptr; size_t pinCap = 0, pinExtraAt = 0;
+    // emission in two phases: pass 1 (what the extension policy needs) on `stream`, the rest on `stream2` behind evP1,
+    // so that the caller can queue the round's finalize and the next round's match-finding next to it
+    hipStream_t stream2 = nullptr;
+    hipEvent_t evP1 = nullptr, evDone = nullptr;
+    bool emitOutstanding = false, refGuarded = false;
+    uint64_t emitPos1 = 0;                   // loading position the running emission started at
+    int emitN = 0;
+    uint8_t *pinE = nullptr; size_t pinECap = 0;
+    DevBuf<unsigned long long> dEStat;
     std::vector<uint8_t> hostStreams;
     std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
@@ -138,15 +147,16 @@ struct swsem {
         v.mask = mask; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
         return v;
     }
-    void mark(int fam, bool begin) {
+    void mark(int fam, bool begin, hipStream_t on = nullptr) {
         if (!prof) return;
+        if (!on) on = stream;
         if (begin) {
             ProfEvent e; e.fam = fam;
             (void) hipEventCreate(&e.a); (void) hipEventCreate(&e.b);
-            (void) hipEventRecord(e.a, stream);
+            (void) hipEventRecord(e.a, on);
             events.push_back(e);
         } else
-            (void) hipEventRecord(events.back().b, stream);
+            (void) hipEventRecord(events.back().b, on);
     }
     void drain_events() {
         for (auto &e : events) {
@@ -219,6 +229,19 @@ int insert_samples(swsem *h) {
     return SWSEM_OK;
 }
 
+// An emission whose second phase is still running reads reference bytes next to its matches, all of them
+// below the loading position it started at. While the buffer has never wrapped, a load that only appends
+// (first byte written >= that position) cannot touch them, so finalize may run beside the emission; a
+// write below it (the separator that replaces the last loaded byte when the loader reaches the window's
+// end) or any write after a wrap (old text is overwritten) waits for the emission instead.
+int ref_write_guard(swsem *h, uint64_t firstByte) {
+    if (h->emitOutstanding && (h->laps > 0 || firstByte < h->emitPos1) && !h->refGuarded) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->evDone, 0));
+        h->refGuarded = true;
+    }
+    return SWSEM_OK;
+}
+
 // private loadRef, .cpp:402-437, on a device-resident text
 int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSep, int sep) {
     while (len != 0) {
@@ -227,6 +250,8 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
             h->pos1 = REF_SHIFT;
             h->samplingPos = REF_SHIFT;
         }
+        int g = ref_write_guard(h, (uint64_t) h->pos1 < h->swEnd ? (uint64_t) h->pos1 : h->swEnd - 1);
+        if (g) return g;
         const uint64_t tmpEnd = h->swEnd;
         uint64_t tmpLength = len;
         const uint64_t tmpMax = tmpEnd < (uint64_t) h->pos1 ? h->maxRefLength : tmpEnd;
@@ -268,6 +293,13 @@ namespace {
 int flush_inserts(swsem *h) {
     const size_t np = h->pendingPieces.size(), nc = h->pendingCopies.size(), nb = h->pendingBytes.size();
     if (!np && !nc && !nb) return SWSEM_OK;
+    {
+        uint64_t lowest = UINT64_MAX;
+        for (auto &c : h->pendingCopies) lowest = std::min(lowest, c.dst);
+        for (auto &b : h->pendingBytes) lowest = std::min(lowest, b.off);
+        int g = ref_write_guard(h, lowest);
+        if (g) return g;
+    }
     constexpr uint64_t CHUNK = 256 * 16;                 // bytes per copy block
     const size_t wPieces = np * (sizeof(InsertPiece) / 8), wCopies = nc * (sizeof(CopyPiece) / 8), wBytes = nb * (sizeof(BytePiece) / 8);
     // host table: a member (two alternating ones), so the upload needs no wait before returning
@@ -479,6 +511,9 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     h->samplingPos = (uint64_t) k1;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     h->ownStream = true;
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evDone, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rb = (uint32_t) x; }
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
@@ -510,7 +545,7 @@ void swsem_destroy(swsem_t *h) {
     if (h->ht) (void) hipFree(h->ht);
     if (h->lut) (void) hipFree(h->lut);
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release();
-    h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
+    h->dMatchCount.release(); h->dMatches.release(); h->dStats.release(); h->dEStat.release();
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
     h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEOwner.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
@@ -519,6 +554,10 @@ void swsem_destroy(swsem_t *h) {
     h->dTables.release();
     if (h->pin) { hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
     for (auto &t : h->hostTables) { if (t.p) hipHostFree(t.p); if (t.ev) hipEventDestroy(t.ev); t = swsem::HostTab(); }
+    if (h->stream2) { (void) hipStreamSynchronize(h->stream2); (void) hipStreamDestroy(h->stream2); }
+    if (h->evP1) (void) hipEventDestroy(h->evP1);
+    if (h->evDone) (void) hipEventDestroy(h->evDone);
+    if (h->pinE) (void) hipHostFree(h->pinE);
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -603,6 +642,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
         h->samplingPos = REF_SHIFT;
     }
     if ((uint64_t) h->pos1 == h->maxRefLength) return SWSEM_OK;
+    { int g = ref_write_guard(h, (uint64_t) h->pos1 == h->swEnd ? (uint64_t) h->pos1 - 1 : (uint64_t) h->pos1); if (g) return g; }
     if ((uint64_t) h->pos1 == h->swEnd) {
         // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was
         if (h->deferInserts) { int r = flush_inserts(h); if (r) return r; }
@@ -672,8 +712,9 @@ int swsem_match(swsem_t *h, const uint8_t *query, uint64_t len, uint32_t minLen,
                 const swsem_match_t **matches, uint64_t *nmatches) {
     HIPCHK(hipSetDevice(h->device));
     *matches = nullptr; *nmatches = 0;
-    int r = h->stage.reserve(len + 64);
+    int r = swsem_emit_batch_end(h);                   // an emission still running reads the staged query
     if (r) return r;
+    if ((r = h->stage.reserve(len + 64))) return r;
     if (len) HIPCHK(hipMemcpyAsync(h->stage.p, query, len, hipMemcpyHostToDevice, h->stream));
     const uint64_t offs[2] = {0, len};
     if ((r = run_batch(h, h->stage.p, offs, 1, minLen, &lockPos))) return r;
@@ -805,10 +846,11 @@ void swsem_emit_params_default(swsem_emit_params_t *p, int mode) {
 
 // processMatches for `n` contigs of the last batch in one pass (the reference runs it per contig on the
 // worker thread that matched it, MGMP.cpp:381). Results stay on the handle until the next emit call.
-int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
-                     const int *factor, const int64_t *processed, const int64_t *targetIdx,
-                     const uint64_t *refExtLoadedPos, uint64_t nLoaded) {
+int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+                           const int *factor, const int64_t *processed, const int64_t *targetIdx,
+                           const uint64_t *refExtLoadedPos, uint64_t nLoaded) {
     HIPCHK(hipSetDevice(h->device));
+    { int e = swsem_emit_batch_end(h); if (e) return e; }          // the scratch of an earlier emission is about to be reused
     if (!h->batchValid) return fail(SWSEM_EINVAL, "swsem_emit: no match results on the handle");
     if (n <= 0) return fail(SWSEM_EINVAL, "swsem_emit: empty request");
     if (p->lazyDecompressionSupport && nLoaded == 0) return fail(SWSEM_EINVAL, "swsem_emit: lazy mode needs refExtLoadedPosArr");
@@ -848,7 +890,7 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
         (r = h->dESz.reserve(rows * 6)) || (r = h->dEOfs.reserve(rows * 6)) || (r = h->dEArena.reserve(arena)) || (r = h->dELoaded.reserve(nLoaded + 1)))
         return r;
     const uint32_t chunks = (uint32_t) h->chunkOwner.size();
-    if ((r = h->dEOwner.reserve(chunks)) || (r = h->dEStates.reserve((size_t) chunks * 2)) || (r = h->dEChunk.reserve((size_t) chunks * 6)) ||
+    if ((r = h->dEStat.reserve(8)) || (r = h->dEOwner.reserve(chunks)) || (r = h->dEStates.reserve((size_t) chunks * 2)) || (r = h->dEChunk.reserve((size_t) chunks * 6)) ||
         (r = h->dEPack.reserve((size_t) n * SWSEM_NSTREAMS)))
         return r;
     HIPCHK(hipMemcpyAsync(h->dEOwner.p, h->chunkOwner.data(), chunks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
@@ -876,23 +918,50 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
     k_emit_p1_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p);
     k_emit_p1_finish<<<dim3((n + 63) / 64), dim3(64), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p);
-    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, h->dECg.p, h->dEStates.p, h->dStats.p);
-    k_emit_sizes<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_packoffs<<<1, dim3(CH), 0, h->stream>>>(v);
-    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_write<<<grid2, dim3(256), 0, h->stream>>>(v, h->dECg.p);
     h->mark(SWSEM_K_EMIT, false);
     HIPCHK(hipGetLastError());
-    // results, match counts and statistics land in one pinned block behind one wait
+    // pass-1 results (unmatchedChars, the dissimilarity verdict), match counts and statistics: one pinned block, one wait
     const bool needCounts = h->matchCount.size() != h->contigs.size();
     if ((r = queue_counts(h, n * sizeof(EmitOut)))) return r;
     HIPCHK(hipMemcpyAsync(h->pin + h->pinExtraAt, h->dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->evP1, h->stream));
+    // the rest runs on the second stream behind pass 1
+    if (h->pinECap < n * sizeof(EmitOut)) {
+        if (h->pinE) HIPCHK(hipHostFree(h->pinE));
+        h->pinE = nullptr; h->pinECap = 0;
+        if (hipHostMalloc((void **) &h->pinE, n * sizeof(EmitOut) + 4096, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
+        h->pinECap = n * sizeof(EmitOut) + 4096;
+    }
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
+    h->mark(SWSEM_K_EMIT, true, h->stream2);
+    k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, h->dECg.p, h->dEStates.p);
+    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, h->dECg.p, h->dEStates.p, h->dEStat.p);
+    k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, h->dECg.p);
+    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream2>>>(v, h->dECg.p);
+    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream2>>>(v, h->dECg.p);
+    k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
+    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, h->dECg.p);
+    k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, h->dECg.p);
+    h->mark(SWSEM_K_EMIT, false, h->stream2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->pinE, h->dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream2));
+    HIPCHK(hipEventRecord(h->evDone, h->stream2));
+    h->emitOutstanding = true; h->refGuarded = false; h->emitN = n; h->emitPos1 = (uint64_t) h->pos1;
+    h->packedBytes = 0; h->hostStreamsValid = false;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (needCounts) take_counts(h);
     h->eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
+    return SWSEM_OK;
+}
+
+// waits for the second phase of the last swsem_emit_batch_begin; afterwards its streams can be fetched
+int swsem_emit_batch_end(swsem_t *h) {
+    if (!h->emitOutstanding) return SWSEM_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->evDone));
+    h->emitOutstanding = false;
+    const int n = h->emitN;
+    h->eout.assign((const EmitOut *) h->pinE, (const EmitOut *) h->pinE + n);
     uint64_t tot = 0;
     h->hostStreamOff.assign((size_t) n * SWSEM_NSTREAMS, 0);
     for (int k = 0; k < n; k++)
@@ -905,11 +974,18 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
     h->hostStreams.resize(tot + 1);
     h->hostStreamsValid = false;
     if (h->emitHostCopy) {
-        if (tot) HIPCHK(hipMemcpyAsync(h->hostStreams.data(), h->dEArena.p, tot, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if (tot) HIPCHK(hipMemcpyAsync(h->hostStreams.data(), h->dEArena.p, tot, hipMemcpyDeviceToHost, h->stream2));
+        HIPCHK(hipStreamSynchronize(h->stream2));
         h->hostStreamsValid = true;
     }
     return SWSEM_OK;
+}
+
+int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+                     const int *factor, const int64_t *processed, const int64_t *targetIdx,
+                     const uint64_t *refExtLoadedPos, uint64_t nLoaded) {
+    int r = swsem_emit_batch_begin(h, p, n, contigIdx, lockPos, factor, processed, targetIdx, refExtLoadedPos, nLoaded);
+    return r ? r : swsem_emit_batch_end(h);
 }
 
 void swsem_emit_set_host_copy(swsem_t *h, int on) { h->emitHostCopy = on != 0; }
@@ -924,22 +1000,27 @@ int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched) {
 // major — so handing it on is one device-to-device copy.
 int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total) {
     HIPCHK(hipSetDevice(h->device));
+    { int e = swsem_emit_batch_end(h); if (e) return e; }
     if (sizes)
         for (size_t k = 0; k < h->eout.size(); k++)
             for (int st = 0; st < SWSEM_NSTREAMS; st++) sizes[k * SWSEM_NSTREAMS + st] = h->eout[k].size[st];
     if (dst_dev && h->packedBytes) {
         if (h->packedBytes > cap) return fail(SWSEM_EINVAL, "swsem_emit_pack_dev: buffer too small");
-        HIPCHK(hipMemcpyAsync(dst_dev, h->dEArena.p, h->packedBytes, hipMemcpyDeviceToDevice, h->stream));
+        // on the emission's own stream, and waited for: the consumer may be on any stream, and the main stream
+        // may already hold the next round's match-finding
+        HIPCHK(hipMemcpyAsync(dst_dev, h->dEArena.p, h->packedBytes, hipMemcpyDeviceToDevice, h->stream2));
+        HIPCHK(hipStreamSynchronize(h->stream2));
     }
     if (total) *total = h->packedBytes;
     return SWSEM_OK;
 }
 
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
+    { int e = swsem_emit_batch_end(h); if (e) return e; }
     if (k < 0 || k >= (int) h->eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
     if (!h->hostStreamsValid) {
-        if (h->packedBytes) HIPCHK(hipMemcpyAsync(h->hostStreams.data(), h->dEArena.p, h->packedBytes, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->packedBytes) HIPCHK(hipMemcpyAsync(h->hostStreams.data(), h->dEArena.p, h->packedBytes, hipMemcpyDeviceToHost, h->stream2));
+        HIPCHK(hipStreamSynchronize(h->stream2));
         h->hostStreamsValid = true;
     }
     const EmitOut &o = h->eout[k];

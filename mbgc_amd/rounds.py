@@ -61,6 +61,7 @@ class RoundRunner:
         self.ref_ext_sizes = bytearray()             # :559-560
         self.stream_bytes = 0
         self._keep = []                              # temporaries handed to finalize_targets: alive until the next host wait
+        self._deferred = None                        # emission whose streams have not been collected yet
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -114,10 +115,12 @@ class RoundRunner:
             if pending:
                 self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
                             [lock_of[c] for c in pending], min_len)
+                # the previous round's streams: its emission's second phase ran beside the launches above
+                self.flush()
                 if self.p is not None:
                     tgt = [first + self.rank * T + targets[c] for c in pending]
-                    m.emit_batch(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
-                                 [self.targets_done + finalized] * len(pending), tgt, self.loaded, n=len(pending))
+                    m.emit_batch_begin(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
+                                       [self.targets_done + finalized] * len(pending), tgt, self.loaded, n=len(pending))
                     un = m.emit_unmatched(len(pending))
                 else:
                     un = [int(offsets[c + 1] - offsets[c]) for c in pending]     # matcher only: always extend
@@ -129,15 +132,18 @@ class RoundRunner:
                 good = [(k, c) for k, c in enumerate(pending) if int(un[k]) != SKIPPED]
                 for k, c in good:
                     unmatched[c] = int(un[k])
-                if self.p is not None and good:
-                    packs.append(self._pack([k for k, _ in good], [c for _, c in good], len(pending)))
+                last = ([k for k, _ in good], [c for _, c in good], len(pending)) if self.p is not None and good else None
             else:
                 skipped_local = []
+                last = None
             # the first target (global order) holding a dissimilar contig cuts the round (MGMP.cpp:382-388:
             # "discard, wait until the earlier targets are loaded, retry")
             first_skip_local = min([self.rank * T + targets[c] for c in skipped_local], default=ntot)
             first_skip = min(x[0] for x in self._allgather_ints([first_skip_local])) if self.world > 1 else first_skip_local
             upto = first_skip                       # targets [finalized, upto) are complete on every rank
+            if last is not None and first_skip < ntot:
+                packs.append(self._pack(*last))     # a retry follows: it reuses the emission's buffers, take the streams now
+                last = None
             # everything the sequential schedule would do AFTER the skipping contig is redone against the
             # extended reference: the rest of that target and all later targets of the round
             cut = min([c for c in skipped_local if self.rank * T + targets[c] == first_skip], default=ncont)
@@ -153,9 +159,21 @@ class RoundRunner:
                 unmatched[c] = None
             packs = [self._drop(pk, pending) for pk in packs]
         if self.p is not None:
-            self._collect_streams(packs, targets, T, offsets)
+            # the streams of the last emission are taken later (flush): until then its second phase runs
+            # beside the finalize queued above and the next round's match-finding
+            self._deferred = (packs, last, targets, T, offsets, qbuf)      # qbuf: read by the emission until then
         self.targets_done += ntot
         return counts
+
+    def flush(self):
+        """waits for the emission still in flight (if any) and merges its streams; call after the last round"""
+        d, self._deferred = self._deferred, None
+        if d is None:
+            return
+        packs, last, targets, T, offsets, _ = d
+        if last is not None:
+            packs.append(self._pack(*last))
+        self._collect_streams(packs, targets, T, offsets)
 
     def _match(self, qbuf, spans, locks, min_len):
         """match contigs given as byte spans of qbuf. match_batch_dev takes offsets of back-to-back

@@ -70,6 +70,12 @@ class OracleDeviceMatcher:
             self._em.append((un, em))
         return n
 
+    def emit_batch_begin(self, *a, **k):
+        return self.emit_batch(*a, **k)
+
+    def emit_batch_end(self):
+        pass
+
     def emit_unmatched(self, n):
         return np.array([u for u, _ in self._em[:n]], dtype=np.uint64)
 

@@ -169,6 +169,7 @@ def test_round_runner_equals_driver_rounds(binding, lim, div):
         offs[1:] = np.cumsum([c.size for c in chunk])
         torch.cuda.synchronize()
         runner.run_round(buf, offs)
+    runner.flush()
     for k in b["streams"]:
         assert bytes(runner.streams[k]) == b["streams"][k], k
     assert bytes(runner.locks_stream) == b["locks"] and bytes(runner.ref_ext_sizes) == b["refExtSize"]

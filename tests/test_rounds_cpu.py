@@ -52,6 +52,7 @@ def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None):
         offs = np.zeros(len(contigs) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum([c.size for c in contigs])
         runner.run_round(buf, offs, tg)
+    runner.flush()
     return runner, m
 
 
