@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict
 // all gathers of a thread in flight together) and the entry — zeroed when empty or rejected by the
 // sliding-window test — is stored per position with coalesced dword stores.
 // ------------------------------------------------------------------------------------------------
+template <bool HASH_ONLY>
 __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ tileContig,
@@ -153,6 +154,16 @@ __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_
         }
         hsh[k] = h & v.mask;
     }
+    uint32_t *out = cand + cg.candBase + ts;
+    if (HASH_ONLY) {                                                  // lazy mode: the chains gather on demand
+#pragma unroll
+        for (int k = 0; k < POS_PER_THREAD; k++) {
+            const uint32_t j = k * PROBE_THREADS + threadIdx.x;
+            out[j] = hsh[k];
+        }
+        if (threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long) npos);
+        return;
+    }
     // all gathers of this thread are issued before the first one is consumed
     uint32_t ent[POS_PER_THREAD];
 #pragma unroll
@@ -160,7 +171,6 @@ __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_
         const uint32_t j = k * PROBE_THREADS + threadIdx.x;
         ent[k] = j < npos ? (uint32_t) v.ht[hsh[k]] : 0u;
     }
-    uint32_t *out = cand + cg.candBase + ts;
     uint32_t nz = 0;
 #pragma unroll
     for (int k = 0; k < POS_PER_THREAD; k++) {
@@ -524,6 +534,48 @@ __device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stac
 // the fetched window (the common case: matches of ~100 bases) costs no further load.
 struct NoStop { __device__ __forceinline__ bool operator()() { return false; } };
 
+// Lazy form of the same loop: `hashes` holds the bucket index of every query position (k_probe<true>) and
+// the hash table is consulted only for the WL positions from the scan position on — the loop visits a
+// few positions after every match and jumps ~100 ahead, so most buckets never need to be fetched.
+#ifndef SWSEM_WL
+#define SWSEM_WL 32
+#endif
+constexpr int WL = SWSEM_WL;
+template <class Stack, class Stop = NoStop>
+__device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ hashes,
+                               int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
+    const int32_t lane = (int32_t) (threadIdx.x & (WAVE - 1));
+    int32_t wb = -0x40000000;                                         // window [wb, wb + WL)
+    uint32_t w = 0;
+    unsigned long long m = 0;
+    const uint32_t *htw = (const uint32_t *) v.ht;                    // low dword of an entry = the stored position
+    while (true) {
+        const int32_t s = ch.scan > p0 ? ch.scan : p0;
+        if (s >= p1) break;
+        ch.scan = s;
+        if (s < wb || s >= wb + WL) {
+            wb = s;
+            const int32_t pos = s + lane;
+            uint32_t e = 0;
+            if (lane < WL && pos < p1) {
+                e = htw[2 * (uint64_t) hashes[pos]];
+                if (e != 0) {
+                    uint64_t lo, hi;
+                    if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;
+                }
+            }
+            w = e;
+            m = __ballot(w != 0);
+        }
+        const unsigned long long mk = m & ~((1ull << (s - wb)) - 1);
+        if (!mk) { ch.scan = wb + WL < p1 ? wb + WL : p1; continue; }
+        const int l = __builtin_ctzll(mk);
+        visit(v, cg, q, stk, ch, wb + l, rl32(w, l));
+        if (stop()) return;
+    }
+}
+
+
 template <class Stack, class Stop = NoStop>
 __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
                           int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
@@ -559,8 +611,16 @@ __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, 
     }
 }
 
+template <bool LAZY, class Stack, class Stop = NoStop>
+__device__ __forceinline__ void chain_run(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
+                                          int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
+    if constexpr (LAZY) run_chain_lazy(v, cg, q, cand, p0, p1, stk, ch, stop);
+    else run_chain(v, cg, q, cand, p0, p1, stk, ch, stop);
+}
+
 // Sequential resolution (one wave replays a whole contig): the simple form, kept as the cross-check
 // of the block-parallel path (SWSEM_RESOLVE=seq).
+template <bool LAZY>
 __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *__restrict__ qbuf,
                                                       const Contig *__restrict__ contigs,
                                                       const uint32_t *__restrict__ cand,
@@ -572,7 +632,7 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
     ArrayStack<Match> stk;
     stk.st = matches + cg.matchBase; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
-    run_chain(v, cg, qbuf + cg.qoff, cand + cg.candBase, 0, npos, stk, ch);
+    chain_run<LAZY>(v, cg, qbuf + cg.qoff, cand + cg.candBase, 0, npos, stk, ch);
     if (threadIdx.x == 0) matchCount[blockIdx.x] = (uint32_t) stk.sp;
 }
 
@@ -608,6 +668,7 @@ __device__ __forceinline__ void snapshot_top(const Row *st, int sp, Match *out) 
 }
 
 // resolve block rbIdx of a contig = tiles [rbIdx*rb, (rbIdx+1)*rb) of it
+template <bool LAZY>
 __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ rbContig,
@@ -628,14 +689,14 @@ __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_
     ArrayStack<Row> stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
-    if (b) run_chain(v, cg, q, cd, w0 - OVERLAP, w0, stk, ch);       // warm-up on the previous block's tail
+    if (b) chain_run<LAZY>(v, cg, q, cd, w0 - OVERLAP, w0, stk, ch);   // warm-up on the previous block's tail
     BlockRec r;
     r.scanB = ch.scan > w0 ? ch.scan : w0;
     r.spB = stk.sp;
     __builtin_amdgcn_s_waitcnt(0);            // the wave's own stack rows are read back below
     snapshot_top(stk.st, stk.sp, r.bTop);
     ch.minTouched = 0x7fffffff; ch.minKeep = stk.sp; ch.visited = 0;
-    run_chain(v, cg, q, cd, w0, w1, stk, ch);
+    chain_run<LAZY>(v, cg, q, cd, w0, w1, stk, ch);
     r.scanF = ch.scan;
     r.spF = stk.sp;
     r.minTouched = ch.visited ? ch.minTouched : 0x7fffffff;
@@ -656,6 +717,7 @@ __device__ __forceinline__ bool same_match(const Match &a, const Match &b) {
 // contig's match count. The walk is a dependent chain executed by a single wave, so everything in it
 // is either scalar (readfirstlane'd record fields) or one lane-parallel LDS operation: the newest
 // SNAP true rows live in LDS as 3*SNAP u64 words and are compared / rebuilt by 3*SNAP lanes at once.
+template <bool LAZY>
 __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__restrict__ qbuf,
                                                  const Contig *__restrict__ contigs, const uint32_t *__restrict__ cand,
                                                  Row *__restrict__ regions, Row *__restrict__ replayArea,
@@ -767,7 +829,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
                     (int32_t) rfl32((uint32_t) spec[sp].scanAfter) == ch.scan) { syncAt = sp; return true; }
                 return false;
             };
-            run_chain(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch, stop);
+            chain_run<LAZY>(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch, stop);
             int n = vs.ownN;
             vs.size_ -= n; vs.ownN = 0; vs.own = nullptr;
             __builtin_amdgcn_s_waitcnt(0);

@@ -75,6 +75,7 @@ struct swsem {
     bool circular = true;
     std::deque<uint64_t> locks;            // workersSwEndPositions
     uint32_t epoch = 1;
+    bool lazyProbe = true;                 // chains gather the hash table on demand (SWSEM_PROBE=lazy) instead of a dense probe pass
     bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
     std::vector<InsertPiece> pendingPieces;
     std::vector<CopyPiece> pendingCopies;    // ... and its byte writes: device-to-device copies,
@@ -398,12 +399,14 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     const RefView v = h->view();
     if (tiles) {
         h->mark(SWSEM_K_PROBE, true);
-        k_probe<<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
+        if (h->lazyProbe) k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
+        else k_probe<false><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
         h->mark(SWSEM_K_PROBE, false);
     }
     if (h->seqResolve || tiles == 0) {
         h->mark(SWSEM_K_RESOLVE, true);
-        k_resolve_seq<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
+        if (h->lazyProbe) k_resolve_seq<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
+        else k_resolve_seq<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
         h->mark(SWSEM_K_RESOLVE, false);
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
@@ -416,13 +419,18 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if ((r = h->dDstOff.reserve(rblocks))) return r;
         if ((r = h->dPrev.reserve(rblocks))) return r;
         h->mark(SWSEM_K_RESOLVE, true);
-        k_resolve_blocks<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p,
-                                                                     h->dRegions.p, cap, h->rb, h->dRecs.p);
+        if (h->lazyProbe) k_resolve_blocks<true><<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p,
+                                                                                           h->dRegions.p, cap, h->rb, h->dRecs.p);
+        else k_resolve_blocks<false><<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p,
+                                                                                 h->dRegions.p, cap, h->rb, h->dRecs.p);
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
-        k_stitch<<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p,
-                                                       h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
-                                                       h->dMatchCount.p, h->dStats.p);
+        if (h->lazyProbe) k_stitch<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p,
+                                                                             h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
+                                                                             h->dMatchCount.p, h->dStats.p);
+        else k_stitch<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p,
+                                                                   h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
+                                                                   h->dMatchCount.p, h->dStats.p);
         k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
                                                             h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
         h->mark(SWSEM_K_STITCH, false);
@@ -515,6 +523,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
         hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evDone, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
+    if (const char *e = getenv("SWSEM_PROBE")) h->lazyProbe = strcmp(e, "dense") != 0;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rb = (uint32_t) x; }
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
         hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
