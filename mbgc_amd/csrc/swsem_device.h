@@ -42,6 +42,8 @@ struct RefView {
     const ht_entry *ht;
     uint64_t pos1, refLength, maxRefLength;
     uint32_t mask;
+    int fpBits;               // low bits of a table entry that hold the K-mer's fingerprint
+    int fpCheck;              // fingerprints may be used to reject entries (see ht_value)
     int K, k1ord, skipMargin;
     uint32_t minLen;
 };
@@ -63,6 +65,25 @@ __device__ __forceinline__ uint4 ld_u128(const uint8_t *p) {
 // maRushPrime1HashSimplified<K>, utils/Hashes.h:28-40, one step (pure u32 arithmetic is exact)
 __device__ __forceinline__ uint32_t hash_step(uint32_t h, uint32_t k, uint32_t j) {
     return (h ^ (k + j)) * 171717u;
+}
+
+// Table entry: (epoch << (32 + F)) | (position >> k1ord) << F | fingerprint, F = fpBits. atomicMax on it
+// gives the reference's last-writer-wins (later load phases carry larger epochs, later positions of one
+// phase larger values). The fingerprint is the top F bits of the K-mer's 32-bit hash — the bucket index
+// is its low bits — so an entry left by a different K-mer is told apart without touching the reference
+// (the reference finds out with memcmp, .cpp:298, and moves on without any other effect). That is exact
+// as long as the bytes an entry was hashed from are still the bytes at its position, i.e. until the
+// buffer wraps (or a separator replaces an already hashed byte): from then on a stale entry may point
+// at new text that does equal the query, the reference would match it, and the filter is switched off
+// (fpCheck = 0; entries keep their layout).
+__device__ __forceinline__ ht_entry ht_key(uint32_t epoch, uint32_t value, uint32_t hash, int fpBits) {
+    return ((ht_entry) epoch << (32 + fpBits)) | ((ht_entry) value << fpBits) | (ht_entry) (fpBits ? hash >> (32 - fpBits) : 0u);
+}
+// stored position of an entry, or 0 when the bucket is empty or holds another K-mer's fingerprint
+__device__ __forceinline__ uint32_t ht_value(const RefView &v, ht_entry e, uint32_t hash) {
+    const uint32_t fp = (uint32_t) e & ((1u << v.fpBits) - 1u);
+    if (v.fpCheck && fp != (hash >> (32 - v.fpBits))) return 0u;
+    return (uint32_t) (e >> v.fpBits);
 }
 
 // window test of SlidingWindowSparseEMMatcher.cpp:212-222. Returns false when the entry is rejected.

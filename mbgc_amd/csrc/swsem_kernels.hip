@@ -62,7 +62,7 @@ __global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restri
 // (the tail runs after the main loop on the CPU, so it wins collisions against it).
 __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                 uint64_t S, uint64_t nMain, uint64_t T, uint64_t nTail, int k1,
-                                                int k1ord, int K, uint32_t mask, uint32_t epoch) {
+                                                int k1ord, int K, uint32_t mask, uint32_t epoch, int fpBits) {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nMain + nTail) return;
     const bool tail = t >= nMain;
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
     uint32_t h = (uint32_t) K;
     const int nw = K / 4;
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
-    const ht_entry key = ((ht_entry) (epoch + (tail ? 1u : 0u)) << 32) | (ht_entry) (uint32_t) (p >> k1ord);
+    const ht_entry key = ht_key(epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
     atomicMax(&ht[h & mask], key);
 }
 
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
 struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, pad; };
 __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                       const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first,
-                                                      int np, int k1, int k1ord, int K, uint32_t mask) {
+                                                      int np, int k1, int k1ord, int K, uint32_t mask, int fpBits) {
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= first[np]) return;
     int lo = 0, hi = np;                               // largest p with first[p] <= g
@@ -94,13 +94,13 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
     uint32_t h = (uint32_t) K;
     const int nw = K / 4;
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
-    const ht_entry key = ((ht_entry) (pc.epoch + (tail ? 1u : 0u)) << 32) | (ht_entry) (uint32_t) (p >> k1ord);
+    const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
     atomicMax(&ht[h & mask], key);
 }
 
-__global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict__ ht, uint32_t *__restrict__ out, uint64_t n) {
+__global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict__ ht, uint32_t *__restrict__ out, uint64_t n, int fpBits) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint32_t) ht[i];
+    if (i < n) out[i] = (uint32_t) (ht[i] >> fpBits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_
                 lo = hi;
             }
         }
-        hsh[k] = h & v.mask;
+        hsh[k] = h;                                                   // bucket = h & mask, fingerprint = its top bits
     }
     uint32_t *out = cand + cg.candBase + ts;
     if (HASH_ONLY) {                                                  // lazy mode: the chains gather on demand
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_
 #pragma unroll
     for (int k = 0; k < POS_PER_THREAD; k++) {
         const uint32_t j = k * PROBE_THREADS + threadIdx.x;
-        ent[k] = j < npos ? (uint32_t) v.ht[hsh[k]] : 0u;
+        ent[k] = j < npos ? ht_value(v, v.ht[hsh[k] & v.mask], hsh[k]) : 0u;
     }
     uint32_t nz = 0;
 #pragma unroll
@@ -548,7 +548,6 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
     int32_t wb = -0x40000000;                                         // window [wb, wb + WL)
     uint32_t w = 0;
     unsigned long long m = 0;
-    const uint32_t *htw = (const uint32_t *) v.ht;                    // low dword of an entry = the stored position
     while (true) {
         const int32_t s = ch.scan > p0 ? ch.scan : p0;
         if (s >= p1) break;
@@ -558,7 +557,8 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
             const int32_t pos = s + lane;
             uint32_t e = 0;
             if (lane < WL && pos < p1) {
-                e = htw[2 * (uint64_t) hashes[pos]];
+                const uint32_t hv = hashes[pos];
+                e = ht_value(v, v.ht[hv & v.mask], hv);
                 if (e != 0) {
                     uint64_t lo, hi;
                     if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;

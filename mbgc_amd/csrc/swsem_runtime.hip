@@ -75,6 +75,8 @@ struct swsem {
     bool circular = true;
     std::deque<uint64_t> locks;            // workersSwEndPositions
     uint32_t epoch = 1;
+    bool pristine = true;                  // no byte of the buffer has been rewritten after it was hashed (no wrap yet)
+    int fpBits = 0;                        // fingerprint bits of a table entry: what the bucket index leaves of the 32-bit hash, at most 8
     bool lazyProbe = true;                 // chains gather the hash table on demand (SWSEM_PROBE=lazy) instead of a dense probe pass
     bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
     std::vector<InsertPiece> pendingPieces;
@@ -145,7 +147,7 @@ struct swsem {
     RefView view() const {
         RefView v;
         v.ref = ref; v.ht = ht; v.pos1 = (uint64_t) pos1; v.refLength = refLength(); v.maxRefLength = maxRefLength;
-        v.mask = mask; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
+        v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? 1 : 0; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
         return v;
     }
     void mark(int fam, bool begin, hipStream_t on = nullptr) {
@@ -190,6 +192,7 @@ void init_params(swsem *h) {
         h->hash_size = ((uint32_t) 1) << (i++);
     } while (i <= 31 && h->hash_size < h->maxRefLength / (uint64_t) h->k1);
     h->mask = h->hash_size - 1;
+    h->fpBits = std::min(8, 32 - (int) __builtin_ctz(h->hash_size));
 }
 
 void build_lut(uint8_t *lut) {
@@ -221,11 +224,12 @@ int insert_samples(swsem *h) {
     } else if (total) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch);
+            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch, h->fpBits);
         h->mark(SWSEM_K_INSERT, false);
         HIPCHK(hipGetLastError());
     }
     h->epoch += 2;
+    if (h->epoch >= (1u << (32 - h->fpBits)) - 2) return fail(SWSEM_EINVAL, "too many load phases for the table's epoch field");
     h->samplingPos = (uint64_t) (T + (int64_t) nTail * h->k1);
     return SWSEM_OK;
 }
@@ -248,6 +252,7 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
     while (len != 0) {
         if ((uint64_t) h->pos1 == h->maxRefLength && h->swEnd != h->maxRefLength) {
             h->laps++;
+            h->pristine = false;
             h->pos1 = REF_SHIFT;
             h->samplingPos = REF_SHIFT;
         }
@@ -339,7 +344,7 @@ int flush_inserts(swsem *h) {
     if (np) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert_multi<<<dim3((unsigned) ((tFirst[np] + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask);
+            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits);
         h->mark(SWSEM_K_INSERT, false);
     }
     HIPCHK(hipGetLastError());
@@ -589,7 +594,7 @@ uint64_t swsem_get_loaded_ref_length(const swsem_t *h) {
     return (uint64_t) h->laps * (h->maxRefLength - REF_SHIFT) + ((uint64_t) h->pos1 - REF_SHIFT);
 }
 uint64_t swsem_get_max_ref_length(const swsem_t *h) { return h->maxRefLength; }
-void swsem_set_position(swsem_t *h, uint64_t p, int laps) { h->pos1 = (int64_t) p; h->laps = laps; }
+void swsem_set_position(swsem_t *h, uint64_t p, int laps) { h->pos1 = (int64_t) p; h->laps = laps; h->pristine = false; }
 int swsem_get_K(const swsem_t *h) { return h->K; }
 uint32_t swsem_get_hash_size(const swsem_t *h) { return h->hash_size; }
 
@@ -647,6 +652,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
     HIPCHK(hipSetDevice(h->device));
     if ((uint64_t) h->pos1 == h->maxRefLength && h->swEnd != h->maxRefLength) {
         h->laps++;
+        h->pristine = false;
         h->pos1 = REF_SHIFT;
         h->samplingPos = REF_SHIFT;
     }
@@ -654,6 +660,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
     { int g = ref_write_guard(h, (uint64_t) h->pos1 == h->swEnd ? (uint64_t) h->pos1 - 1 : (uint64_t) h->pos1); if (g) return g; }
     if ((uint64_t) h->pos1 == h->swEnd) {
         // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was
+        h->pristine = false;
         if (h->deferInserts) { int r = flush_inserts(h); if (r) return r; }
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1 - 1, (uint8_t) sep);
     } else if (h->deferInserts) {
@@ -785,7 +792,7 @@ int swsem_debug_copy_ht(swsem_t *h, uint32_t *out) {
     DevBuf<uint32_t> tmp;
     int r = tmp.reserve(h->hash_size);
     if (r) return r;
-    k_ht_low_words<<<dim3((h->hash_size + 255) / 256), dim3(256), 0, h->stream>>>(h->ht, tmp.p, h->hash_size);
+    k_ht_low_words<<<dim3((h->hash_size + 255) / 256), dim3(256), 0, h->stream>>>(h->ht, tmp.p, h->hash_size, h->fpBits);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, tmp.p, (size_t) h->hash_size * 4, hipMemcpyDeviceToHost));
     tmp.release();
@@ -802,6 +809,13 @@ int swsem_debug_block_times(swsem_t *h, uint64_t *out, uint64_t cap, uint64_t *n
     HIPCHK(hipStreamSynchronize(h->stream));
     if (nb) HIPCHK(hipMemcpy(tmp.data(), h->dRecs.p, nb * sizeof(BlockRec), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < nb; i++) { out[3 * i] = tmp[i].cycles; out[3 * i + 1] = tmp[i].visits; out[3 * i + 2] = tmp[i].emits; }
+    return SWSEM_OK;
+}
+
+// diagnostics: one raw 64-bit table entry
+int swsem_debug_ht_entry(swsem_t *h, uint64_t bucket, uint64_t *out) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->ht + bucket, 8, hipMemcpyDeviceToHost));
     return SWSEM_OK;
 }
 
