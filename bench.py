@@ -23,13 +23,23 @@ sys.path.insert(0, ROOT)
 GENOME_LEN = 5_000_000
 MAX_REF_LEN = 1_280_000_000          # 128 files -> referenceFactor 128 -> 128 * 5e6 * 2 (MGMP.cpp:130-158)
 ALG_BYTES_PER_BASE = 5.5             # whole path, per input base
-# share of the probe kernel in that figure: query scan 1 B + 0.29 sequential table probes x 4 B
-ALG_BYTES_PROBE = 1.0 + 4 * 0.29
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
-# HBM bytes k_probe moves per query position, from the PMC passes in profiles/r01_pmc_hbm_traffic.json
-# (FETCH_SIZE 5.02e6 KB + WRITE_SIZE 3.16e5 KB per 80 M positions: one 64-B request per table gather,
-# 1 B of query, 4 B of candidate array)
-PROBE_TRAFFIC_PER_POS = (5022864.9 + 315628.5) * 1024 / (16 * (5_000_000 - 27))
+# SURVEY.md §8(d) splits that figure by term; per kernel family (bytes per input base of a launch):
+#   probe   k_probe<true>: the query scan, 1 B
+#   resolve k_resolve_blocks: the table probes the sequential loop performs (0.29 x 4 B), the reference
+#           bytes it compares (0.918 B) and the match rows it writes (24 B x 766 k rows / 80 M bases)
+#   load    extension copy, read + write (2 B);  insert  one 4-B table entry per 16 bases
+#   emit    the six streams (0.14 B)
+ALG_BYTES = {"probe": 1.0, "resolve": 4 * 0.29 + 0.918 + 0.23, "stitch": 0.23, "load": 2.0, "insert": 0.25, "emit": 0.14}
+# HBM bytes per input base each family really moves, from the PMC passes in profiles/r01_pmc_hbm_traffic.json
+# (FETCH_SIZE + WRITE_SIZE of its largest launches = rounds of 16 x 5 Mbp, / 80 M bases)
+TRAFFIC = {"probe": (41035.8 + 313186.5) * 1024 / 80e6, "resolve": (2881920.2 + 57730.2) * 1024 / 80e6,
+           "stitch": (641.2 + 88.2 + 12967.4 + 18365.8) * 1024 / 80e6, "load": (39696.8 + 78735.5) * 1024 / 80e6,
+           "insert": (40359.1 + 156256.9) * 1024 / 80e6,
+           "emit": (9639.8 + 893.6 + 17843.1 + 12633.3 + 24417.4 + 1560.2 + 90062.2 + 21189.8 + 21408.5 + 210015.7 +
+                    844.4 + 1149.9 + 33364.4 + 756.1 + 8890.0 + 17190.2 + 127.9 + 16375.0 + 96054.1) * 1024 / 80e6}
+KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query)", "resolve": "k_resolve_blocks<true>", "stitch": "k_stitch + k_gather",
+             "load": "k_copy_multi", "insert": "k_insert_multi", "emit": "k_emit_* (14 launches)"}
 
 
 def cpu_baseline(sample_targets, length, emit):
@@ -181,10 +191,13 @@ def main():
     bases_step = R * world * args.length
     value = bases_step * steps / dt / 1e9
     if rank == 0:
-        dom = max(("probe", "resolve", "stitch", "emit", "insert", "load"), key=lambda k: prof[k][0])
+        # the dominant kernel: the families that are a single kernel per launch (emission is 14 small kernels,
+        # the second half of which runs beside other work on a second stream and is timed as elapsed time)
+        dom = max(("probe", "resolve", "stitch", "insert", "load"), key=lambda k: prof[k][0])
         per_launch_ms = {k: (prof[k][0] / prof[k][1] if prof[k][1] else 0.0) for k in prof}
-        probe_ms = per_launch_ms["probe"]
-        ach = ALG_BYTES_PROBE * R * args.length / (probe_ms * 1e-3) / 1e9 if probe_ms else 0.0
+        dom_ms = per_launch_ms[dom]
+        launch_bases = R * args.length                     # bases one launch of a family processes (this rank's round)
+        ach = ALG_BYTES[dom] * launch_bases / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         out = {
             "metric": "input Gbases/s (compress hot path, -m1: match-finding + stream emission)" if emit else
                       "input Gbases/s (compress path, SlidingWindowSparseEMMatcher only)",
@@ -196,12 +209,12 @@ def main():
                                    (" + processMatches (six streams, gathered to rank 0)" if emit else "", R),
                        "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": MAX_REF_LEN,
                        "hash_entries": m.hash_size(), "sharding": "file-per-GPU, all-gather of extensions"},
-            "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "traffic": round(PROBE_TRAFFIC_PER_POS * R * (args.length - 27)),
-                         "traffic_GBs": round(PROBE_TRAFFIC_PER_POS * R * (args.length - 27) / (probe_ms * 1e-3) / 1e9, 1) if probe_ms else 0.0,
-                         "alg_bytes_per_base": ALG_BYTES_PROBE, "avg_launch_ms": round(probe_ms, 4),
-                         "whole_step_frac": round(ALG_BYTES_PER_BASE * value / HBM_PEAK_GBS, 5)},
+                         "traffic": round(TRAFFIC[dom] * launch_bases),
+                         "traffic_GBs": round(TRAFFIC[dom] * launch_bases / (dom_ms * 1e-3) / 1e9, 1) if dom_ms else 0.0,
+                         "alg_bytes_per_base": round(ALG_BYTES[dom], 3), "avg_launch_ms": round(dom_ms, 4),
+                         "whole_step_frac": round(ALG_BYTES_PER_BASE * value / world / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items()},
             "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof}, "dominant_kernel": dom,
             "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps, "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),

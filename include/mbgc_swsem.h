@@ -171,10 +171,12 @@ int swsem_dev_copy(swsem_t *h, void *dst_dev, const void *src_dev, uint64_t byte
 /* ---- test / measurement hooks (not part of the reference surface) */
 int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out);      /* getRef() bytes, .h:104 */
 int swsem_debug_copy_ht(swsem_t *h, uint32_t *out /* [hash_size] 32-bit image as on the CPU */);
-enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2, SWSEM_K_EXTEND = 3, SWSEM_K_RESOLVE = 4,
+enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2, SWSEM_K_EMIT2 = 3, SWSEM_K_RESOLVE = 4,
        SWSEM_K_STITCH = 5, SWSEM_K_EMIT = 6, SWSEM_K_COUNT = 7 };
-/* When enabled every kernel launch is bracketed by HIP events on the handle's stream; the accumulated
- * device time (ms) and launch count per kernel family are read back with swsem_profile_get. */
+/* When enabled every kernel family's launches are bracketed by HIP events on the stream they run on; the
+ * accumulated device time (ms) and bracket count per family are read back with swsem_profile_get.
+ * EMIT = pass 1 of processMatches (main stream), EMIT2 = its second phase (second stream; the bracket also
+ * covers whatever the main stream runs beside it, so it is an elapsed time, not a sum of kernel times). */
 int swsem_debug_block_times(swsem_t *h, uint64_t *out /* [cap][3]: ticks, candidates visited, stack rows */, uint64_t cap, uint64_t *nblocks);
 int swsem_profile_enable(swsem_t *h, int on);
 int swsem_profile_get(swsem_t *h, double ms[SWSEM_K_COUNT], uint64_t launches[SWSEM_K_COUNT]);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MBGC_HIP_LIB", os.path.join(HERE, "libmbgc_hip.so")) 
 NO_LOCK = 2 ** 64 - 1
 SKIPPED = 2 ** 64 - 1
 STREAM_NAMES = ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags")
-KERNEL_FAMILIES = ("load", "insert", "probe", "extend", "resolve", "stitch", "emit")
+KERNEL_FAMILIES = ("load", "insert", "probe", "emit2", "resolve", "stitch", "emit")
 
 EXPORTS = """swsem_last_error swsem_device_count swsem_create swsem_destroy swsem_set_stream swsem_synchronize
 swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circular_buffer swsem_get_ref_length

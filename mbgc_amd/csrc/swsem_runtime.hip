@@ -956,7 +956,7 @@ int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         h->pinECap = n * sizeof(EmitOut) + 4096;
     }
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
-    h->mark(SWSEM_K_EMIT, true, h->stream2);
+    h->mark(SWSEM_K_EMIT2, true, h->stream2);
     k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, h->dECg.p, h->dEStates.p);
     k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, h->dECg.p, h->dEStates.p, h->dEStat.p);
     k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, h->dECg.p);
@@ -965,7 +965,7 @@ int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
     k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, h->dECg.p);
     k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, h->dECg.p);
-    h->mark(SWSEM_K_EMIT, false, h->stream2);
+    h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h->pinE, h->dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream2));
     HIPCHK(hipEventRecord(h->evDone, h->stream2));
