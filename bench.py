@@ -156,7 +156,7 @@ def main():
 
     for s in range(warm):
         runner.keep_streams = bool(args.check and s == 0)
-        runner.run_round(*bufs[s])
+        runner.run_round(*bufs[s], next_batch=bufs[s + 1] if s + 1 < len(bufs) else None)
         runner.flush()
         if args.check and s == 0 and rank == 0 and world == 1:
             check_against_oracle(runner, base, sched[0][0], args.length, emit)
@@ -166,7 +166,8 @@ def main():
     t0 = time.perf_counter()
     replayed = 0
     for s in range(warm, warm + steps):
-        tot_matches += int(runner.run_round(*bufs[s]).sum())
+        # every timed step also hashes a following round's queries (the last one a round that is not matched here)
+        tot_matches += int(runner.run_round(*bufs[s], next_batch=bufs[(s + 1) % len(bufs)]).sum())
         replayed += m.batch_stats()["replayed_blocks"]
     runner.flush()                                     # the last round's emission (its second phase runs beside the next round)
     barrier()

@@ -95,6 +95,12 @@ int swsem_match(swsem_t *h, const uint8_t *query, uint64_t len, uint32_t minMatc
  * and can be fetched per contig. */
 int swsem_match_batch_dev(swsem_t *h, const uint8_t *queries_dev, const uint64_t *offsets, int n,
                           uint32_t minMatchLength, const uint64_t *lockPos);
+/* Optional look-ahead: the K-mer hashes of the query scan (.cpp:200-201) depend on the query alone, so the
+ * batch that will be matched NEXT can be announced while the current one is still being matched; they are
+ * computed on a third stream and adopted by the swsem_match_batch_dev call with the same (queries_dev,
+ * offsets, n). The buffer must hold its final bytes when announced. Purely an overlap: results are those of
+ * swsem_match_batch_dev alone. */
+int swsem_hash_batch_dev(swsem_t *h, const uint8_t *queries_dev, const uint64_t *offsets, int n);
 int swsem_batch_counts(swsem_t *h, uint64_t *nmatches /* [n] */);
 int swsem_batch_matches(swsem_t *h, int contig, swsem_match_t *out, uint64_t cap);
 /* order-sensitive fingerprint of all match rows of the batch, computed on the device copy */

@@ -91,6 +91,19 @@ struct swsem {
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
     DevBuf<uint32_t> dTileContig, dMatchCount, dRbContig, dCand;
+    // K-mer hashes of a batch announced ahead (swsem_hash_batch_dev): computed on a third stream into the other
+    // hash buffer while the current batch is still being matched; swsem_match_batch_dev on the same buffers adopts them
+    DevBuf<uint32_t> dCandNext, dPrepTileContig;
+    DevBuf<Contig> dPrepContigs;
+    DevBuf<unsigned long long> dPrepStats;
+    hipStream_t stream3 = nullptr;
+    hipEvent_t evHash = nullptr, evMatched = nullptr, evMatchedPrev = nullptr;   // hashes ready / chains of the last batch (the one before) done
+    bool prepValid = false;
+    int matchedRecorded = 0;
+    const uint8_t *prepQ = nullptr;
+    std::vector<uint64_t> prepOffsets;
+    std::vector<Contig> prepContigs;
+    std::vector<uint32_t> prepTileContig, tileContigHost, rbContigHost;
     DevBuf<Match> dMatches;
     DevBuf<Row> dRegions, dReplay;
     DevBuf<BlockRec> dRecs;
@@ -113,6 +126,9 @@ struct swsem {
     std::vector<uint64_t> eloaded;
     std::vector<EmitOut> eout;
     uint8_t *pin = nullptr; size_t pinCap = 0, pinExtraAt = 0;
+    // small host tables travel through a pinned ring: an asynchronous copy from pageable memory is staged by the
+    // runtime and can block the calling thread for milliseconds when its staging pool is busy
+    uint8_t *ring = nullptr; size_t ringCap = 0, ringAt = 0;
     // emission in two phases: pass 1 (what the extension policy needs) on `stream`, the rest on `stream2` behind evP1,
     // so that the caller can queue the round's finalize and the next round's match-finding next to it
     hipStream_t stream2 = nullptr;
@@ -139,7 +155,7 @@ struct swsem {
     uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
     // --- profiling
     bool prof = false;
-    std::vector<ProfEvent> events;
+    std::deque<ProfEvent> events;
     double profMs[SWSEM_K_COUNT] = {0};
     uint64_t profN[SWSEM_K_COUNT] = {0};
 
@@ -150,12 +166,27 @@ struct swsem {
         v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? 1 : 0; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
         return v;
     }
+    // event pairs are recycled: creating events by the hundred makes the runtime grow its signal pool now and
+    // then, which can stall the calling thread in the middle of a measurement
+    std::vector<ProfEvent> idle;
+    void account(const ProfEvent &e) {
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, e.a, e.b);
+        profMs[e.fam] += ms; profN[e.fam]++;
+        idle.push_back(e);
+    }
     void mark(int fam, bool begin, hipStream_t on = nullptr) {
         if (!prof) return;
         if (!on) on = stream;
         if (begin) {
-            ProfEvent e; e.fam = fam;
-            (void) hipEventCreate(&e.a); (void) hipEventCreate(&e.b);
+            while (events.size() > 1 && hipEventQuery(events.front().b) == hipSuccess) {   // harvest what has finished
+                account(events.front());
+                events.pop_front();
+            }
+            ProfEvent e;
+            if (!idle.empty()) { e = idle.back(); idle.pop_back(); }
+            else { (void) hipEventCreate(&e.a); (void) hipEventCreate(&e.b); }
+            e.fam = fam;
             (void) hipEventRecord(e.a, on);
             events.push_back(e);
         } else
@@ -164,10 +195,7 @@ struct swsem {
     void drain_events() {
         for (auto &e : events) {
             (void) hipEventSynchronize(e.b);
-            float ms = 0;
-            (void) hipEventElapsedTime(&ms, e.a, e.b);
-            profMs[e.fam] += ms; profN[e.fam]++;
-            (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b);
+            account(e);
         }
         events.clear();
     }
@@ -315,8 +343,10 @@ int flush_inserts(swsem *h) {
     if (ht.cap < words) {
         if (ht.p) HIPCHK(hipHostFree(ht.p));
         ht.p = nullptr; ht.cap = 0;
-        if (hipHostMalloc((void **) &ht.p, (words + 64) * 8, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", (words + 64) * 8);
-        ht.cap = words + 64;
+        // generous: (re)allocating pinned memory synchronises the whole device, it must not recur in steady state
+        const size_t want = std::max<size_t>(2 * words, 1 << 16);
+        if (hipHostMalloc((void **) &ht.p, want * 8, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want * 8);
+        ht.cap = want;
     }
     if (!ht.ev) HIPCHK(hipEventCreateWithFlags(&ht.ev, hipEventDisableTiming));
     struct { uint64_t *p; uint64_t *data() { return p; } size_t n; size_t size() const { return n; } } tab = {ht.p, words};
@@ -352,6 +382,73 @@ int flush_inserts(swsem *h) {
     return SWSEM_OK;
 }
 
+// copies `bytes` of host data to the device through the pinned ring, asynchronously on `st`
+int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (!bytes) return SWSEM_OK;
+    const size_t need = (bytes + 255) & ~(size_t) 255;
+    if (need * 4 > h->ringCap) {                       // (re)allocation: rare, and the only place that waits
+        HIPCHK(hipDeviceSynchronize());
+        if (h->ring) HIPCHK(hipHostFree(h->ring));
+        h->ring = nullptr; h->ringCap = 0; h->ringAt = 0;
+        const size_t want = std::max<size_t>(need * 8, 8u << 20);
+        if (hipHostMalloc((void **) &h->ring, want, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want);
+        h->ringCap = want;
+    }
+    if (h->ringAt + need > h->ringCap) {               // wrap: everything staged a lap ago has long been copied, but make sure
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream2));
+        HIPCHK(hipStreamSynchronize(h->stream3));
+        h->ringAt = 0;
+    }
+    uint8_t *slot = h->ring + h->ringAt;
+    h->ringAt += need;
+    memcpy(slot, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st));
+    return SWSEM_OK;
+}
+
+// K-mer hashes of a future batch, beside whatever the main stream is doing (the hashes depend on the query only)
+int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n) {
+    h->prepValid = false;
+    if (n <= 0 || !h->lazyProbe) return SWSEM_OK;
+    h->prepContigs.assign(n, Contig());
+    h->prepTileContig.clear();
+    uint32_t tiles = 0;
+    for (int c = 0; c < n; c++) {
+        Contig &cg = h->prepContigs[c];
+        cg.qoff = offsets[c];
+        cg.n = offsets[c + 1] - offsets[c];
+        if (cg.n >= (1ull << 31) - (1ull << 20)) return SWSEM_OK;          // swsem_match_batch_dev reports it
+        const uint64_t npos = cg.n >= (uint64_t) h->K ? cg.n - h->K + 1 : 0;
+        cg.tile0 = tiles;
+        cg.ntiles = (uint32_t) ((npos + TILE - 1) / TILE);
+        cg.candBase = (uint64_t) tiles * TILE;
+        h->prepTileContig.insert(h->prepTileContig.end(), cg.ntiles, (uint32_t) c);
+        tiles += cg.ntiles;
+    }
+    if (!tiles) return SWSEM_OK;
+    int r;
+    if ((r = h->dPrepContigs.reserve(n)) || (r = h->dPrepTileContig.reserve(tiles)) || (r = h->dPrepStats.reserve(8)) ||
+        (r = h->dCandNext.reserve((size_t) tiles * TILE)))
+        return r;
+    // the buffer about to be overwritten held the hashes of the batch before the current one: its chains are long done,
+    // but say so to the third stream
+    if (h->matchedRecorded >= 2) HIPCHK(hipStreamWaitEvent(h->stream3, h->evMatchedPrev, 0));
+    if ((r = upload(h, h->dPrepContigs.p, h->prepContigs.data(), n * sizeof(Contig), h->stream3)) ||
+        (r = upload(h, h->dPrepTileContig.p, h->prepTileContig.data(), tiles * sizeof(uint32_t), h->stream3)))
+        return r;
+    const RefView v = h->view();
+    h->mark(SWSEM_K_PROBE, true, h->stream3);
+    k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream3>>>(v, qdev, h->dPrepContigs.p, h->dPrepTileContig.p, h->dCandNext.p, h->dPrepStats.p);
+    h->mark(SWSEM_K_PROBE, false, h->stream3);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->evHash, h->stream3));
+    h->prepQ = qdev;
+    h->prepOffsets.assign(offsets, offsets + n + 1);
+    h->prepValid = true;
+    return SWSEM_OK;
+}
+
 int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {
     if (n <= 0) return fail(SWSEM_EINVAL, "empty batch");
     if (minLen < (uint32_t) h->K)   // SlidingWindowSparseEMMatcher.cpp:480-483
@@ -360,7 +457,8 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     h->matchCount.clear();
     h->minLen = minLen;
     h->contigs.assign(n, Contig());
-    std::vector<uint32_t> tileContig, rbContig;
+    std::vector<uint32_t> &tileContig = h->tileContigHost, &rbContig = h->rbContigHost;   // uploaded asynchronously
+    tileContig.clear(); rbContig.clear();
     uint64_t matchRows = 0, bases = 0;
     uint32_t tiles = 0, rblocks = 0;
     for (int c = 0; c < n; c++) {
@@ -392,17 +490,23 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if ((r = h->dTileContig.reserve(std::max<uint32_t>(tiles, 1)))) return r;
     if ((r = h->dCand.reserve((size_t) std::max<uint32_t>(tiles, 1) * TILE))) return r;
     if ((r = h->dMatches.reserve(matchRows))) return r;
-    HIPCHK(hipMemcpyAsync(h->dContigs.p, h->contigs.data(), n * sizeof(Contig), hipMemcpyHostToDevice, h->stream));
+    if ((r = upload(h, h->dContigs.p, h->contigs.data(), n * sizeof(Contig), h->stream))) return r;
     if ((r = h->dRbContig.reserve(std::max<uint32_t>(rblocks, 1)))) return r;
     if (tiles) {
-        HIPCHK(hipMemcpyAsync(h->dTileContig.p, tileContig.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->dRbContig.p, rbContig.data(), rblocks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        if ((r = upload(h, h->dTileContig.p, tileContig.data(), tiles * sizeof(uint32_t), h->stream)) ||
+            (r = upload(h, h->dRbContig.p, rbContig.data(), rblocks * sizeof(uint32_t), h->stream)))
+            return r;
     }
     HIPCHK(hipMemsetAsync(h->dStats.p, 0, 8 * sizeof(unsigned long long), h->stream));
-    // the host vectors above must outlive the async copies
-    HIPCHK(hipStreamSynchronize(h->stream));
     const RefView v = h->view();
-    if (tiles) {
+    // hashes announced ahead for exactly these buffers: adopt them
+    const bool adopted = h->prepValid && h->lazyProbe && h->prepQ == qdev && h->prepOffsets.size() == (size_t) n + 1 &&
+                         std::equal(h->prepOffsets.begin(), h->prepOffsets.end(), offsets);
+    h->prepValid = false;
+    if (adopted && tiles) {
+        std::swap(h->dCand, h->dCandNext);
+        HIPCHK(hipStreamWaitEvent(h->stream, h->evHash, 0));
+    } else if (tiles) {
         h->mark(SWSEM_K_PROBE, true);
         if (h->lazyProbe) k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
         else k_probe<false><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
@@ -441,6 +545,9 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         h->mark(SWSEM_K_STITCH, false);
     }
     HIPCHK(hipGetLastError());
+    std::swap(h->evMatched, h->evMatchedPrev);
+    HIPCHK(hipEventRecord(h->evMatched, h->stream));
+    if (h->matchedRecorded < 2) h->matchedRecorded++;
     h->qdev = qdev;
     h->stats[0] = bases;
     h->batchValid = true;
@@ -453,8 +560,9 @@ int pin_reserve(swsem *h, size_t bytes) {
     if (h->pinCap >= bytes) return SWSEM_OK;
     if (h->pin) HIPCHK(hipHostFree(h->pin));
     h->pin = nullptr; h->pinCap = 0;
-    if (hipHostMalloc((void **) &h->pin, bytes + 4096, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", bytes + 4096);
-    h->pinCap = bytes + 4096;
+    const size_t want = std::max<size_t>(2 * bytes, 1 << 20);          // see flush_inserts: no regrowth in steady state
+    if (hipHostMalloc((void **) &h->pin, want, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want);
+    h->pinCap = want;
     return SWSEM_OK;
 }
 
@@ -526,7 +634,11 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     h->ownStream = true;
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evDone, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
+        hipEventCreateWithFlags(&h->evDone, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evHash, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evMatched, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evMatchedPrev, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
     if (const char *e = getenv("SWSEM_PROBE")) h->lazyProbe = strcmp(e, "dense") != 0;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rb = (uint32_t) x; }
@@ -558,7 +670,7 @@ void swsem_destroy(swsem_t *h) {
     if (h->ref) (void) hipFree(h->ref);
     if (h->ht) (void) hipFree(h->ht);
     if (h->lut) (void) hipFree(h->lut);
-    h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release();
+    h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release(); h->dCandNext.release(); h->dPrepTileContig.release(); h->dPrepContigs.release(); h->dPrepStats.release();
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release(); h->dEStat.release();
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
@@ -567,8 +679,16 @@ void swsem_destroy(swsem_t *h) {
     h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release(); h->dEPack.release();
     h->dTables.release();
     if (h->pin) { hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
+    if (h->ring) { hipHostFree(h->ring); h->ring = nullptr; h->ringCap = 0; }
     for (auto &t : h->hostTables) { if (t.p) hipHostFree(t.p); if (t.ev) hipEventDestroy(t.ev); t = swsem::HostTab(); }
     if (h->stream2) { (void) hipStreamSynchronize(h->stream2); (void) hipStreamDestroy(h->stream2); }
+    h->drain_events();
+    for (auto &e : h->idle) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+    h->idle.clear();
+    if (h->stream3) { (void) hipStreamSynchronize(h->stream3); (void) hipStreamDestroy(h->stream3); }
+    if (h->evHash) (void) hipEventDestroy(h->evHash);
+    if (h->evMatched) (void) hipEventDestroy(h->evMatched);
+    if (h->evMatchedPrev) (void) hipEventDestroy(h->evMatchedPrev);
     if (h->evP1) (void) hipEventDestroy(h->evP1);
     if (h->evDone) (void) hipEventDestroy(h->evDone);
     if (h->pinE) (void) hipHostFree(h->pinE);
@@ -691,6 +811,11 @@ int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, con
     h->deferInserts = false;
     const int r2 = flush_inserts(h);
     return r ? r : r2;
+}
+
+int swsem_hash_batch_dev(swsem_t *h, const uint8_t *q, const uint64_t *offsets, int n) {
+    HIPCHK(hipSetDevice(h->device));
+    return prepare_hashes(h, q, offsets, n);
 }
 
 int swsem_match_batch_dev(swsem_t *h, const uint8_t *q, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {
@@ -916,11 +1041,10 @@ int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     if ((r = h->dEStat.reserve(8)) || (r = h->dEOwner.reserve(chunks)) || (r = h->dEStates.reserve((size_t) chunks * 2)) || (r = h->dEChunk.reserve((size_t) chunks * 6)) ||
         (r = h->dEPack.reserve((size_t) n * SWSEM_NSTREAMS)))
         return r;
-    HIPCHK(hipMemcpyAsync(h->dEOwner.p, h->chunkOwner.data(), chunks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->dECg.p, h->ecg.data(), n * sizeof(EmitContig), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->dEWhich.p, which.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if ((r = upload(h, h->dEOwner.p, h->chunkOwner.data(), chunks * sizeof(uint32_t), h->stream))) return r;
+    if ((r = upload(h, h->dECg.p, h->ecg.data(), n * sizeof(EmitContig), h->stream)) || (r = upload(h, h->dEWhich.p, which.data(), n * sizeof(int), h->stream))) return r;
     h->eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
-    if (nLoaded) HIPCHK(hipMemcpyAsync(h->dELoaded.p, h->eloaded.data(), nLoaded * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    if ((r = upload(h, h->dELoaded.p, h->eloaded.data(), nLoaded * sizeof(uint64_t), h->stream))) return r;
     // no synchronisation here: the kernels below queue up behind match-finding while it is still running
     EmitView v;
     v.ref = h->ref; v.qbuf = h->qdev; v.matches = h->dMatches.p; v.matchCount = h->dMatchCount.p;
@@ -952,8 +1076,9 @@ int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     if (h->pinECap < n * sizeof(EmitOut)) {
         if (h->pinE) HIPCHK(hipHostFree(h->pinE));
         h->pinE = nullptr; h->pinECap = 0;
-        if (hipHostMalloc((void **) &h->pinE, n * sizeof(EmitOut) + 4096, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
-        h->pinECap = n * sizeof(EmitOut) + 4096;
+        const size_t want = std::max<size_t>(2 * n * sizeof(EmitOut), 1 << 20);
+        if (hipHostMalloc((void **) &h->pinE, want, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
+        h->pinECap = want;
     }
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
     h->mark(SWSEM_K_EMIT2, true, h->stream2);

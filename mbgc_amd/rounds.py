@@ -62,6 +62,7 @@ class RoundRunner:
         self.stream_bytes = 0
         self._keep = []                              # temporaries handed to finalize_targets: alive until the next host wait
         self._deferred = None                        # emission whose streams have not been collected yet
+        self._pack_buf = None
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -92,11 +93,13 @@ class RoundRunner:
         return [p.view(torch.int64).tolist() for p in parts]
 
     # ---- one round ----------------------------------------------------------------------------
-    def run_round(self, qbuf, offsets, targets=None, min_len=32):
+    def run_round(self, qbuf, offsets, targets=None, min_len=32, next_batch=None):
         """qbuf: uint8 device tensor holding this rank's contigs of the round back to back, contig c at
         [offsets[c], offsets[c+1]). targets[c] = index (0..T-1) of the local target contig c belongs to
         (default: one contig per target). Every rank passes the same number of targets T; globally the
-        round's targets are ordered rank-major. Returns this rank's match counts per contig."""
+        round's targets are ordered rank-major. Returns this rank's match counts per contig.
+        next_batch = (qbuf, offsets) of the round that follows, if its bytes are already in HBM: its K-mer
+        hashes are then computed beside this round's match-finding (they depend on the query only)."""
         m = self.m
         ncont = len(offsets) - 1
         targets = list(range(ncont)) if targets is None else list(targets)
@@ -115,6 +118,9 @@ class RoundRunner:
             if pending:
                 self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
                             [lock_of[c] for c in pending], min_len)
+                if next_batch is not None and hasattr(m, "hash_batch_dev"):
+                    m.hash_batch_dev(next_batch[0].data_ptr(), next_batch[1])
+                    next_batch = None
                 # the previous round's streams: its emission's second phase ran beside the launches above
                 self.flush()
                 if self.p is not None:
@@ -172,7 +178,7 @@ class RoundRunner:
             return
         packs, last, targets, T, offsets, _ = d
         if last is not None:
-            packs.append(self._pack(*last))
+            packs.append(self._pack(*last, reuse=(self.world == 1 and not packs)))
         self._collect_streams(packs, targets, T, offsets)
 
     def _match(self, qbuf, spans, locks, min_len):
@@ -190,9 +196,17 @@ class RoundRunner:
             offs[1:] = np.cumsum([e - s for s, e in spans])
             self.m.match_batch_dev(self._tmp.data_ptr(), offs, min_len, locks)
 
-    def _pack(self, ks, cs, n_emitted):
+    def _pack(self, ks, cs, n_emitted, reuse=False):
         sizes, total = self.m.emit_pack_sizes(n_emitted)
-        buf = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        if reuse:
+            # one grow-only buffer for the common case (one emission per round, consumed before the next one is
+            # packed): allocating per round goes through the caching allocator, whose occasional hipMalloc stalls
+            # the whole device for milliseconds
+            if self._pack_buf is None or self._pack_buf.numel() < max(total, 1):
+                self._pack_buf = torch.empty(max(int(total * 1.5), 1 << 20), dtype=torch.uint8, device=self.device)
+            buf = self._pack_buf
+        else:
+            buf = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
         self.m.emit_pack_dev(buf.data_ptr(), buf.numel())
         starts = np.zeros(n_emitted * 6 + 1, dtype=np.int64)
         starts[1:] = np.cumsum(sizes.reshape(-1))
