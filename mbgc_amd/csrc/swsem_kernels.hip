@@ -52,6 +52,17 @@ __global__ void __launch_bounds__(256) k_copy_multi(uint8_t *__restrict__ ref, c
     } else
         for (uint64_t k = 0; k < pc.len - o; k++) d[k] = s[k];
 }
+// host tables staged in pinned memory -> device (a plain kernel: the runtime's own host-to-device copies can
+// block the calling thread for milliseconds on a side stream)
+__global__ void __launch_bounds__(256) k_upload(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t n) {
+    const uint64_t o = 16 * ((uint64_t) blockIdx.x * 256 + threadIdx.x);
+    if (o + 16 <= n) {
+        uint4 t;
+        memcpy(&t, src + o, 16);
+        memcpy(dst + o, &t, 16);
+    } else
+        for (uint64_t k = o; k < n; k++) dst[k] = src[k];
+}
 __global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restrict__ b, int n) {
     for (int i = 0; i < n; i++) ref[b[i].off] = (uint8_t) b[i].val;
 }

@@ -403,14 +403,18 @@ int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
     uint8_t *slot = h->ring + h->ringAt;
     h->ringAt += need;
     memcpy(slot, src, bytes);
-    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st));
+    // pinned host memory is mapped into the device's address space: a kernel does the copy
+    k_upload<<<dim3((unsigned) ((bytes + 4095) / 4096)), dim3(256), 0, st>>>((uint8_t *) dst, slot, bytes);
+    HIPCHK(hipGetLastError());
     return SWSEM_OK;
 }
 
 // K-mer hashes of a future batch, beside whatever the main stream is doing (the hashes depend on the query only)
 int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n) {
     h->prepValid = false;
+    hipStream_t hs = h->stream3;
     if (n <= 0 || !h->lazyProbe) return SWSEM_OK;
+    (void) hipStreamQuery(hs);             // lets the runtime retire what this stream has completed (it is never waited on by the host)
     h->prepContigs.assign(n, Contig());
     h->prepTileContig.clear();
     uint32_t tiles = 0;
@@ -433,16 +437,16 @@ int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n
         return r;
     // the buffer about to be overwritten held the hashes of the batch before the current one: its chains are long done,
     // but say so to the third stream
-    if (h->matchedRecorded >= 2) HIPCHK(hipStreamWaitEvent(h->stream3, h->evMatchedPrev, 0));
-    if ((r = upload(h, h->dPrepContigs.p, h->prepContigs.data(), n * sizeof(Contig), h->stream3)) ||
-        (r = upload(h, h->dPrepTileContig.p, h->prepTileContig.data(), tiles * sizeof(uint32_t), h->stream3)))
+    if (h->matchedRecorded >= 2) HIPCHK(hipStreamWaitEvent(hs, h->evMatchedPrev, 0));
+    if ((r = upload(h, h->dPrepContigs.p, h->prepContigs.data(), n * sizeof(Contig), hs)) ||
+        (r = upload(h, h->dPrepTileContig.p, h->prepTileContig.data(), tiles * sizeof(uint32_t), hs)))
         return r;
     const RefView v = h->view();
-    h->mark(SWSEM_K_PROBE, true, h->stream3);
-    k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream3>>>(v, qdev, h->dPrepContigs.p, h->dPrepTileContig.p, h->dCandNext.p, h->dPrepStats.p);
-    h->mark(SWSEM_K_PROBE, false, h->stream3);
+    h->mark(SWSEM_K_PROBE, true, hs);
+    k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, hs>>>(v, qdev, h->dPrepContigs.p, h->dPrepTileContig.p, h->dCandNext.p, h->dPrepStats.p);
+    h->mark(SWSEM_K_PROBE, false, hs);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->evHash, h->stream3));
+    HIPCHK(hipEventRecord(h->evHash, hs));
     h->prepQ = qdev;
     h->prepOffsets.assign(offsets, offsets + n + 1);
     h->prepValid = true;
