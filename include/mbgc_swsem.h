@@ -154,11 +154,16 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
  * (swsem_match_batch_dev): the reference's workers run processMatches next to the finalizer in the same way
  * (MGMP.cpp:520-555). The query buffer of the emitted batch must stay untouched until _end. Once the
  * reference buffer has wrapped, loads wait for the running emission (they would overwrite text it reads).
- * _end (also implied by swsem_emit_result / swsem_emit_pack_dev / the next _begin) waits for the streams. */
+ * _end (also implied by swsem_emit_result / swsem_emit_pack_dev) waits for the streams. */
 int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
                            const int *unmatchedFractionFactor, const int64_t *processedTargetsCount, const int64_t *targetIdx,
                            const uint64_t *refExtLoadedPos, uint64_t nLoaded);
 int swsem_emit_batch_end(swsem_t *h);
+/* Two emissions can be in flight: _begin only waits for the one before the previous (whose buffers it takes
+ * over). swsem_emit_result / swsem_emit_pack_dev read the latest emission, or — after swsem_emit_select(h, 1) —
+ * the one before it, which lets a caller begin round r+1 before it collects the streams of round r.
+ * swsem_emit_batch_end waits for both. */
+int swsem_emit_select(swsem_t *h, int previous);
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out);
 /* Keep the streams in HBM (no host copy inside swsem_emit_batch; swsem_emit_result then copies on demand)
  * and pack them, (result, stream) major, into one device buffer — the unit the multi-GPU path gathers to

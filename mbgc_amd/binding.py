@@ -21,7 +21,7 @@ swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circula
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_hash_batch_dev swsem_batch_counts swsem_batch_matches
-swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_end swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
+swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_copy""".split()
 
 
@@ -102,6 +102,7 @@ def lib():
         L.swsem_emit_batch.argtypes = [vp, C.POINTER(EmitParams), ci, vp, vp, vp, vp, vp, vp, u64]
         L.swsem_emit_batch_begin.argtypes = L.swsem_emit_batch.argtypes
         L.swsem_emit_batch_end.argtypes = [vp]
+        L.swsem_emit_select.argtypes = [vp, ci]
         L.swsem_emit_result.argtypes = [vp, ci, C.POINTER(Streams)]
         L.swsem_emit_set_host_copy.argtypes = [vp, ci]
         L.swsem_emit_set_host_copy.restype = None
@@ -266,6 +267,7 @@ class SlidingWindowSparseEMMatcher:
         return self.emit_batch(*a, _entry="swsem_emit_batch_begin", **k)
 
     def emit_batch_end(self): _chk(lib().swsem_emit_batch_end(self.h))
+    def emit_select(self, previous): _chk(lib().swsem_emit_select(self.h, int(previous)))
 
     def emit_set_host_copy(self, on): lib().swsem_emit_set_host_copy(self.h, int(on))
 

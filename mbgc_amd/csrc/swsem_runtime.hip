@@ -110,21 +110,46 @@ struct swsem {
     DevBuf<uint32_t> dSegStart, dKeepN, dDstOff;
     DevBuf<int32_t> dPrev;
     DevBuf<unsigned long long> dStats;
-    // --- emission scratch
-    DevBuf<EmitContig> dECg;
-    DevBuf<EmitOut> dEOut;
-    DevBuf<int> dEWhich;
-    DevBuf<uint32_t> dEOwner;
-    DevBuf<EMatch> dEM;
-    DevBuf<uint64_t> dENext0, dELoaded, dEPack;
-    DevBuf<uint8_t> dETf, dERm, dEArena;
-    DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs, dEChunk;
-    DevBuf<MetaState> dEStates;
-    std::vector<EmitContig> ecg;
-    std::vector<uint32_t> chunkOwner;
-    std::vector<int> ewhich;
-    std::vector<uint64_t> eloaded;
-    std::vector<EmitOut> eout;
+    // --- emission: two slots, so that the second phase of one batch can still be running while the next is begun
+    struct EmitSlot {
+        DevBuf<EmitContig> dECg;
+        DevBuf<EmitOut> dEOut;
+        DevBuf<int> dEWhich;
+        DevBuf<uint32_t> dEOwner;
+        DevBuf<EMatch> dEM;
+        DevBuf<uint64_t> dENext0, dELoaded, dEPack;
+        DevBuf<uint8_t> dETf, dERm, dEArena;
+        DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs, dEChunk;
+        DevBuf<MetaState> dEStates;
+        DevBuf<unsigned long long> dEStat;
+        std::vector<EmitContig> ecg;
+        std::vector<uint32_t> chunkOwner;
+        std::vector<int> ewhich;
+        std::vector<uint64_t> eloaded;
+        std::vector<EmitOut> eout;
+        hipEvent_t evDone = nullptr;
+        bool outstanding = false, refGuarded = false;
+        uint64_t emitPos1 = 0;               // loading position the emission started at
+        int emitN = 0;
+        uint8_t *pinE = nullptr; size_t pinECap = 0;
+        std::vector<uint8_t> hostStreams;
+        std::vector<uint64_t> hostStreamOff; // [k * NSTREAMS + s] offset into hostStreams
+        bool hostStreamsValid = false;
+        uint64_t packedBytes = 0;
+        void release() {
+            dECg.release(); dEOut.release(); dEWhich.release(); dEOwner.release(); dEM.release(); dENext0.release(); dELoaded.release();
+            dEPack.release(); dETf.release(); dERm.release(); dEArena.release(); dEKeep.release(); dEMeta.release(); dECorr.release();
+            dESz.release(); dEOfs.release(); dEChunk.release(); dEStates.release(); dEStat.release();
+            if (pinE) { (void) hipHostFree(pinE); pinE = nullptr; pinECap = 0; }
+            if (evDone) { (void) hipEventDestroy(evDone); evDone = nullptr; }
+        }
+    } slot[2];
+    int latest = 0;                          // slot of the last swsem_emit_batch_begin
+    // largest request seen so far: a slot is always sized for it, so the second slot does not regrow (= hipFree +
+    // hipMalloc, a device-wide stall) the first time it meets a full-size batch
+    uint64_t capN = 0, capRows = 0, capArena = 0, capLoaded = 0, capChunks = 0;
+    int selected = -1;                       // slot the result calls read (-1: the latest), swsem_emit_select
+    EmitSlot &sel() { return slot[selected < 0 ? latest : selected]; }
     uint8_t *pin = nullptr; size_t pinCap = 0, pinExtraAt = 0;
     // small host tables travel through a pinned ring: an asynchronous copy from pageable memory is staged by the
     // runtime and can block the calling thread for milliseconds when its staging pool is busy
@@ -132,17 +157,8 @@ struct swsem {
     // emission in two phases: pass 1 (what the extension policy needs) on `stream`, the rest on `stream2` behind evP1,
     // so that the caller can queue the round's finalize and the next round's match-finding next to it
     hipStream_t stream2 = nullptr;
-    hipEvent_t evP1 = nullptr, evDone = nullptr;
-    bool emitOutstanding = false, refGuarded = false;
-    uint64_t emitPos1 = 0;                   // loading position the running emission started at
-    int emitN = 0;
-    uint8_t *pinE = nullptr; size_t pinECap = 0;
-    DevBuf<unsigned long long> dEStat;
-    std::vector<uint8_t> hostStreams;
-    std::vector<uint64_t> hostStreamOff;   // [k * NSTREAMS + s] offset into hostStreams
+    hipEvent_t evP1 = nullptr;
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
-    bool hostStreamsValid = false;
-    uint64_t packedBytes = 0;
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 4;                       // probe tiles per resolve block (SWSEM_RB)
     std::vector<Contig> contigs;
@@ -268,10 +284,11 @@ int insert_samples(swsem *h) {
 // write below it (the separator that replaces the last loaded byte when the loader reaches the window's
 // end) or any write after a wrap (old text is overwritten) waits for the emission instead.
 int ref_write_guard(swsem *h, uint64_t firstByte) {
-    if (h->emitOutstanding && (h->laps > 0 || firstByte < h->emitPos1) && !h->refGuarded) {
-        HIPCHK(hipStreamWaitEvent(h->stream, h->evDone, 0));
-        h->refGuarded = true;
-    }
+    for (auto &E : h->slot)
+        if (E.outstanding && (h->laps > 0 || firstByte < E.emitPos1) && !E.refGuarded) {
+            HIPCHK(hipStreamWaitEvent(h->stream, E.evDone, 0));
+            E.refGuarded = true;
+        }
     return SWSEM_OK;
 }
 
@@ -359,7 +376,7 @@ int flush_inserts(swsem *h) {
     for (size_t i = 0; i < nc; i++) tCFirst[i + 1] = tCFirst[i] + (h->pendingCopies[i].len + CHUNK - 1) / CHUNK;
     if (nb) memcpy(tBytes, h->pendingBytes.data(), nb * sizeof(BytePiece));
     int r;
-    if ((r = h->dTables.reserve(tab.size()))) return r;
+    if ((r = h->dTables.reserve(std::max<size_t>(2 * tab.size(), 1 << 16)))) return r;   // regrowing = hipFree = a device-wide wait
     HIPCHK(hipMemcpyAsync(h->dTables.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipEventRecord(ht.ev, h->stream));
     ht.pending = true;
@@ -602,6 +619,34 @@ int fetch_counts(swsem *h) {
 }
 
 
+// waits for the second phase of the emission in slot si, if one is running, and takes its results
+int end_slot(swsem *h, int si) {
+    swsem::EmitSlot &E = h->slot[si];
+    if (!E.outstanding) return SWSEM_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(E.evDone));
+    E.outstanding = false;
+    const int n = E.emitN;
+    E.eout.assign((const EmitOut *) E.pinE, (const EmitOut *) E.pinE + n);
+    uint64_t tot = 0;
+    E.hostStreamOff.assign((size_t) n * SWSEM_NSTREAMS, 0);
+    for (int k = 0; k < n; k++)
+        for (int st = 0; st < SWSEM_NSTREAMS; st++) {
+            if (E.eout[k].unmatchedChars == UINT64_MAX) E.eout[k].size[st] = 0;
+            E.hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st] = tot;       // == packBase on the device
+            tot += E.eout[k].size[st];
+        }
+    E.packedBytes = tot;
+    E.hostStreamsValid = false;
+    if (h->emitHostCopy) {
+        E.hostStreams.resize(tot + 1);
+        if (tot) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, tot, hipMemcpyDeviceToHost, h->stream3));
+        HIPCHK(hipStreamSynchronize(h->stream3));
+        E.hostStreamsValid = true;
+    }
+    return SWSEM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -638,7 +683,8 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     h->ownStream = true;
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->slot[0].evDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->slot[1].evDone, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evHash, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evMatched, hipEventDisableTiming) != hipSuccess ||
@@ -670,17 +716,17 @@ void swsem_destroy(swsem_t *h) {
     if (!h) return;
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
+    if (h->stream2) (void) hipStreamSynchronize(h->stream2);
+    if (h->stream3) (void) hipStreamSynchronize(h->stream3);
     h->drain_events();
     if (h->ref) (void) hipFree(h->ref);
     if (h->ht) (void) hipFree(h->ht);
     if (h->lut) (void) hipFree(h->lut);
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release(); h->dCandNext.release(); h->dPrepTileContig.release(); h->dPrepContigs.release(); h->dPrepStats.release();
-    h->dMatchCount.release(); h->dMatches.release(); h->dStats.release(); h->dEStat.release();
+    h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
-    h->dECg.release(); h->dEOut.release(); h->dEWhich.release(); h->dEOwner.release(); h->dEM.release(); h->dENext0.release(); h->dELoaded.release();
-    h->dETf.release(); h->dERm.release(); h->dEArena.release(); h->dEKeep.release(); h->dEMeta.release(); h->dECorr.release();
-    h->dESz.release(); h->dEOfs.release(); h->dEStates.release(); h->dEChunk.release(); h->dEPack.release();
+    for (auto &E : h->slot) E.release();
     h->dTables.release();
     if (h->pin) { hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
     if (h->ring) { hipHostFree(h->ring); h->ring = nullptr; h->ringCap = 0; }
@@ -694,8 +740,6 @@ void swsem_destroy(swsem_t *h) {
     if (h->evMatched) (void) hipEventDestroy(h->evMatched);
     if (h->evMatchedPrev) (void) hipEventDestroy(h->evMatchedPrev);
     if (h->evP1) (void) hipEventDestroy(h->evP1);
-    if (h->evDone) (void) hipEventDestroy(h->evDone);
-    if (h->pinE) (void) hipHostFree(h->pinE);
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1002,23 +1046,25 @@ int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, cons
                            const int *factor, const int64_t *processed, const int64_t *targetIdx,
                            const uint64_t *refExtLoadedPos, uint64_t nLoaded) {
     HIPCHK(hipSetDevice(h->device));
-    { int e = swsem_emit_batch_end(h); if (e) return e; }          // the scratch of an earlier emission is about to be reused
+    const int si = h->latest ^ 1;                                     // the slot not used by the previous emission
+    { int e = end_slot(h, si); if (e) return e; }                    // its scratch is about to be reused
+    swsem::EmitSlot &E = h->slot[si];
     if (!h->batchValid) return fail(SWSEM_EINVAL, "swsem_emit: no match results on the handle");
     if (n <= 0) return fail(SWSEM_EINVAL, "swsem_emit: empty request");
     if (p->lazyDecompressionSupport && nLoaded == 0) return fail(SWSEM_EINVAL, "swsem_emit: lazy mode needs refExtLoadedPosArr");
     if (p->gapDepthOffsetEncoding > 64 || p->gapDepthOffsetEncoding < 0)
         return fail(SWSEM_EINVAL, "gapDepthOffsetEncoding %d out of range (MAX_GAP_DEPTH / 2)", p->gapDepthOffsetEncoding);
     int r;
-    h->ecg.assign(n, EmitContig());
-    std::vector<int> &which = h->ewhich;       // uploaded asynchronously: must outlive this call
+    E.ecg.assign(n, EmitContig());
+    std::vector<int> &which = E.ewhich;       // uploaded asynchronously: must outlive this call
     which.assign(n, 0);
     uint64_t rows = 0, arena = 0;
-    h->chunkOwner.clear();
+    E.chunkOwner.clear();
     for (int k = 0; k < n; k++) {
         const int c = contigIdx ? contigIdx[k] : k;
         if (c < 0 || c >= (int) h->contigs.size()) return fail(SWSEM_EINVAL, "swsem_emit: no contig %d in the batch", c);
         which[k] = c;
-        EmitContig &e = h->ecg[k];
+        EmitContig &e = E.ecg[k];
         const Contig &cg = h->contigs[c];
         // rows are reserved for the most matches a contig can have, so no round trip to the host is needed
         // between match-finding and emission
@@ -1028,108 +1074,99 @@ int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         e.scratchBase = rows;
         e.cap = (uint32_t) (nm + 2);
         rows += e.cap;
-        e.chunk0 = (uint32_t) h->chunkOwner.size();
-        h->chunkOwner.insert(h->chunkOwner.end(), (e.cap + CH - 1) / CH, (uint32_t) k);
+        e.chunk0 = (uint32_t) E.chunkOwner.size();
+        E.chunkOwner.insert(E.chunkOwner.end(), (e.cap + CH - 1) / CH, (uint32_t) k);
         e.factor = factor ? factor[k] : 128;
         e.processed = processed ? processed[k] : 0;
         e.targetIdx = targetIdx ? targetIdx[k] : 0;
         const uint64_t szs[SWSEM_NSTREAMS] = {cg.n + nm + 16, 4 * nm + 16, nm + 16, 14 * nm + 16, nm + 16, cg.n + 2 * nm + 16};
         for (int st = 0; st < SWSEM_NSTREAMS; st++) { e.streamBase[st] = arena; arena += (szs[st] + 15) & ~15ull; }
     }
-    if ((r = h->dECg.reserve(n)) || (r = h->dEOut.reserve(n)) || (r = h->dEWhich.reserve(n)) || (r = h->dEM.reserve(rows)) ||
-        (r = h->dENext0.reserve(rows)) || (r = h->dETf.reserve(rows)) || (r = h->dERm.reserve(rows)) ||
-        (r = h->dEKeep.reserve(rows)) || (r = h->dEMeta.reserve(rows)) || (r = h->dECorr.reserve(rows)) ||
-        (r = h->dESz.reserve(rows * 6)) || (r = h->dEOfs.reserve(rows * 6)) || (r = h->dEArena.reserve(arena)) || (r = h->dELoaded.reserve(nLoaded + 1)))
-        return r;
-    const uint32_t chunks = (uint32_t) h->chunkOwner.size();
-    if ((r = h->dEStat.reserve(8)) || (r = h->dEOwner.reserve(chunks)) || (r = h->dEStates.reserve((size_t) chunks * 2)) || (r = h->dEChunk.reserve((size_t) chunks * 6)) ||
-        (r = h->dEPack.reserve((size_t) n * SWSEM_NSTREAMS)))
-        return r;
-    if ((r = upload(h, h->dEOwner.p, h->chunkOwner.data(), chunks * sizeof(uint32_t), h->stream))) return r;
-    if ((r = upload(h, h->dECg.p, h->ecg.data(), n * sizeof(EmitContig), h->stream)) || (r = upload(h, h->dEWhich.p, which.data(), n * sizeof(int), h->stream))) return r;
-    h->eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
-    if ((r = upload(h, h->dELoaded.p, h->eloaded.data(), nLoaded * sizeof(uint64_t), h->stream))) return r;
+    const uint32_t chunks = (uint32_t) E.chunkOwner.size();
+    h->capN = std::max<uint64_t>(h->capN, (uint64_t) n); h->capRows = std::max(h->capRows, rows); h->capArena = std::max(h->capArena, arena);
+    h->capLoaded = std::max<uint64_t>(h->capLoaded, nLoaded + 1 + nLoaded / 2); h->capChunks = std::max<uint64_t>(h->capChunks, chunks);
+    {
+        const uint64_t N = h->capN, R = h->capRows, A = h->capArena, Cn = h->capChunks;
+        if ((r = E.dECg.reserve(N)) || (r = E.dEOut.reserve(N)) || (r = E.dEWhich.reserve(N)) || (r = E.dEM.reserve(R)) ||
+            (r = E.dENext0.reserve(R)) || (r = E.dETf.reserve(R)) || (r = E.dERm.reserve(R)) ||
+            (r = E.dEKeep.reserve(R)) || (r = E.dEMeta.reserve(R)) || (r = E.dECorr.reserve(R)) ||
+            (r = E.dESz.reserve(R * 6)) || (r = E.dEOfs.reserve(R * 6)) || (r = E.dEArena.reserve(A)) || (r = E.dELoaded.reserve(h->capLoaded)) ||
+            (r = E.dEStat.reserve(8)) || (r = E.dEOwner.reserve(Cn)) || (r = E.dEStates.reserve((size_t) Cn * 2)) || (r = E.dEChunk.reserve((size_t) Cn * 6)) ||
+            (r = E.dEPack.reserve((size_t) N * SWSEM_NSTREAMS)))
+            return r;
+    }
+    if ((r = upload(h, E.dEOwner.p, E.chunkOwner.data(), chunks * sizeof(uint32_t), h->stream))) return r;
+    if ((r = upload(h, E.dECg.p, E.ecg.data(), n * sizeof(EmitContig), h->stream)) || (r = upload(h, E.dEWhich.p, which.data(), n * sizeof(int), h->stream))) return r;
+    E.eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
+    if ((r = upload(h, E.dELoaded.p, E.eloaded.data(), nLoaded * sizeof(uint64_t), h->stream))) return r;
     // no synchronisation here: the kernels below queue up behind match-finding while it is still running
     EmitView v;
     v.ref = h->ref; v.qbuf = h->qdev; v.matches = h->dMatches.p; v.matchCount = h->dMatchCount.p;
     v.pos1 = (uint64_t) h->pos1; v.refLength = h->refLength(); v.maxRefLength = h->maxRefLength;
-    v.loaded = h->dELoaded.p; v.nLoaded = (uint32_t) nLoaded; v.p = *p;
-    v.em = h->dEM.p; v.next0 = h->dENext0.p; v.tflag = h->dETf.p; v.removed = h->dERm.p; v.keepIdx = h->dEKeep.p;
-    v.meta = h->dEMeta.p; v.corr = h->dECorr.p; v.sz = h->dESz.p; v.arena = h->dEArena.p; v.out = h->dEOut.p;
-    v.packBase = h->dEPack.p;
-    v.ofs = h->dEOfs.p;
-    v.chunkCnt = h->dEChunk.p;
-    v.chunkOwner = h->dEOwner.p;
+    v.loaded = E.dELoaded.p; v.nLoaded = (uint32_t) nLoaded; v.p = *p;
+    v.em = E.dEM.p; v.next0 = E.dENext0.p; v.tflag = E.dETf.p; v.removed = E.dERm.p; v.keepIdx = E.dEKeep.p;
+    v.meta = E.dEMeta.p; v.corr = E.dECorr.p; v.sz = E.dESz.p; v.arena = E.dEArena.p; v.out = E.dEOut.p;
+    v.packBase = E.dEPack.p;
+    v.ofs = E.dEOfs.p;
+    v.chunkCnt = E.dEChunk.p;
+    v.chunkOwner = E.dEOwner.p;
     v.ncontigs = (uint32_t) n;
     const dim3 grid2(chunks);
     h->mark(SWSEM_K_EMIT, true);
-    k_emit_p1_flags<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
-    k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
-    k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
-    k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p, h->dEWhich.p);
-    k_emit_p1_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, h->dECg.p);
-    k_emit_p1_finish<<<dim3((n + 63) / 64), dim3(64), 0, h->stream>>>(v, h->dECg.p);
+    k_emit_p1_flags<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
+    k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
+    k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
+    k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
+    k_emit_p1_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p);
+    k_emit_p1_finish<<<dim3((n + 63) / 64), dim3(64), 0, h->stream>>>(v, E.dECg.p);
     h->mark(SWSEM_K_EMIT, false);
     HIPCHK(hipGetLastError());
     // pass-1 results (unmatchedChars, the dissimilarity verdict), match counts and statistics: one pinned block, one wait
     const bool needCounts = h->matchCount.size() != h->contigs.size();
     if ((r = queue_counts(h, n * sizeof(EmitOut)))) return r;
-    HIPCHK(hipMemcpyAsync(h->pin + h->pinExtraAt, h->dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pin + h->pinExtraAt, E.dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipEventRecord(h->evP1, h->stream));
     // the rest runs on the second stream behind pass 1
-    if (h->pinECap < n * sizeof(EmitOut)) {
-        if (h->pinE) HIPCHK(hipHostFree(h->pinE));
-        h->pinE = nullptr; h->pinECap = 0;
+    if (E.pinECap < n * sizeof(EmitOut)) {
+        if (E.pinE) HIPCHK(hipHostFree(E.pinE));
+        E.pinE = nullptr; E.pinECap = 0;
         const size_t want = std::max<size_t>(2 * n * sizeof(EmitOut), 1 << 20);
-        if (hipHostMalloc((void **) &h->pinE, want, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
-        h->pinECap = want;
+        if (hipHostMalloc((void **) &E.pinE, want, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
+        E.pinECap = want;
     }
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
     h->mark(SWSEM_K_EMIT2, true, h->stream2);
-    k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, h->dECg.p, h->dEStates.p);
-    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, h->dECg.p, h->dEStates.p, h->dEStat.p);
-    k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, h->dECg.p);
-    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream2>>>(v, h->dECg.p);
-    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream2>>>(v, h->dECg.p);
+    k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p);
+    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
+    k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
     k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
-    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, h->dECg.p);
-    k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, h->dECg.p);
+    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h->pinE, h->dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream2));
-    HIPCHK(hipEventRecord(h->evDone, h->stream2));
-    h->emitOutstanding = true; h->refGuarded = false; h->emitN = n; h->emitPos1 = (uint64_t) h->pos1;
-    h->packedBytes = 0; h->hostStreamsValid = false;
+    HIPCHK(hipMemcpyAsync(E.pinE, E.dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream2));
+    HIPCHK(hipEventRecord(E.evDone, h->stream2));
+    h->latest = si; h->selected = -1;
+    E.outstanding = true; E.refGuarded = false; E.emitN = n; E.emitPos1 = (uint64_t) h->pos1;
+    E.packedBytes = 0; E.hostStreamsValid = false;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (needCounts) take_counts(h);
-    h->eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
+    E.eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
     return SWSEM_OK;
 }
 
-// waits for the second phase of the last swsem_emit_batch_begin; afterwards its streams can be fetched
+// waits for every emission still in its second phase (oldest first); afterwards their streams can be fetched
 int swsem_emit_batch_end(swsem_t *h) {
-    if (!h->emitOutstanding) return SWSEM_OK;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipEventSynchronize(h->evDone));
-    h->emitOutstanding = false;
-    const int n = h->emitN;
-    h->eout.assign((const EmitOut *) h->pinE, (const EmitOut *) h->pinE + n);
-    uint64_t tot = 0;
-    h->hostStreamOff.assign((size_t) n * SWSEM_NSTREAMS, 0);
-    for (int k = 0; k < n; k++)
-        for (int st = 0; st < SWSEM_NSTREAMS; st++) {
-            if (h->eout[k].unmatchedChars == UINT64_MAX) h->eout[k].size[st] = 0;
-            h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st] = tot;       // == packBase on the device
-            tot += h->eout[k].size[st];
-        }
-    h->packedBytes = tot;
-    h->hostStreams.resize(tot + 1);
-    h->hostStreamsValid = false;
-    if (h->emitHostCopy) {
-        if (tot) HIPCHK(hipMemcpyAsync(h->hostStreams.data(), h->dEArena.p, tot, hipMemcpyDeviceToHost, h->stream2));
-        HIPCHK(hipStreamSynchronize(h->stream2));
-        h->hostStreamsValid = true;
-    }
+    int r = end_slot(h, h->latest ^ 1);
+    return r ? r : end_slot(h, h->latest);
+}
+
+// result calls read the latest emission (previous = 0) or the one before it (previous = 1), which may have been
+// left running across the next swsem_emit_batch_begin
+int swsem_emit_select(swsem_t *h, int previous) {
+    h->selected = previous ? (h->latest ^ 1) : -1;
     return SWSEM_OK;
 }
 
@@ -1144,7 +1181,8 @@ void swsem_emit_set_host_copy(swsem_t *h, int on) { h->emitHostCopy = on != 0; }
 
 // unmatchedChars (the return value of processMatches, SWSEM_SKIPPED when skipped) of every result
 int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched) {
-    for (size_t k = 0; k < h->eout.size(); k++) unmatched[k] = h->eout[k].unmatchedChars;
+    swsem::EmitSlot &E = h->slot[h->latest];
+    for (size_t k = 0; k < E.eout.size(); k++) unmatched[k] = E.eout[k].unmatchedChars;
     return SWSEM_OK;
 }
 
@@ -1152,32 +1190,35 @@ int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched) {
 // major — so handing it on is one device-to-device copy.
 int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total) {
     HIPCHK(hipSetDevice(h->device));
-    { int e = swsem_emit_batch_end(h); if (e) return e; }
+    swsem::EmitSlot &E = h->sel();
+    { int e = end_slot(h, (int) (&E - h->slot)); if (e) return e; }
     if (sizes)
-        for (size_t k = 0; k < h->eout.size(); k++)
-            for (int st = 0; st < SWSEM_NSTREAMS; st++) sizes[k * SWSEM_NSTREAMS + st] = h->eout[k].size[st];
-    if (dst_dev && h->packedBytes) {
-        if (h->packedBytes > cap) return fail(SWSEM_EINVAL, "swsem_emit_pack_dev: buffer too small");
+        for (size_t k = 0; k < E.eout.size(); k++)
+            for (int st = 0; st < SWSEM_NSTREAMS; st++) sizes[k * SWSEM_NSTREAMS + st] = E.eout[k].size[st];
+    if (dst_dev && E.packedBytes) {
+        if (E.packedBytes > cap) return fail(SWSEM_EINVAL, "swsem_emit_pack_dev: buffer too small");
         // on the emission's own stream, and waited for: the consumer may be on any stream, and the main stream
         // may already hold the next round's match-finding
-        HIPCHK(hipMemcpyAsync(dst_dev, h->dEArena.p, h->packedBytes, hipMemcpyDeviceToDevice, h->stream2));
-        HIPCHK(hipStreamSynchronize(h->stream2));
+        HIPCHK(hipMemcpyAsync(dst_dev, E.dEArena.p, E.packedBytes, hipMemcpyDeviceToDevice, h->stream3));
+        HIPCHK(hipStreamSynchronize(h->stream3));
     }
-    if (total) *total = h->packedBytes;
+    if (total) *total = E.packedBytes;
     return SWSEM_OK;
 }
 
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
-    { int e = swsem_emit_batch_end(h); if (e) return e; }
-    if (k < 0 || k >= (int) h->eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
-    if (!h->hostStreamsValid) {
-        if (h->packedBytes) HIPCHK(hipMemcpyAsync(h->hostStreams.data(), h->dEArena.p, h->packedBytes, hipMemcpyDeviceToHost, h->stream2));
-        HIPCHK(hipStreamSynchronize(h->stream2));
-        h->hostStreamsValid = true;
+    swsem::EmitSlot &E = h->sel();
+    { int e = end_slot(h, (int) (&E - h->slot)); if (e) return e; }
+    if (k < 0 || k >= (int) E.eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
+    if (!E.hostStreamsValid) {
+        E.hostStreams.resize(E.packedBytes + 1);      // (only here: zero-filling megabytes has no place on the round's critical path)
+        if (E.packedBytes) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, E.packedBytes, hipMemcpyDeviceToHost, h->stream3));
+        HIPCHK(hipStreamSynchronize(h->stream3));
+        E.hostStreamsValid = true;
     }
-    const EmitOut &o = h->eout[k];
+    const EmitOut &o = E.eout[k];
     for (int st = 0; st < SWSEM_NSTREAMS; st++) {
-        out->data[st] = h->hostStreams.data() + h->hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st];
+        out->data[st] = E.hostStreams.data() + E.hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st];
         out->size[st] = o.size[st];
     }
     out->unmatchedChars = o.unmatchedChars;

@@ -113,6 +113,7 @@ class RoundRunner:
         unmatched = [None] * ncont
         packs = []                                  # (contig ids, sizes, device tensor) of accepted emissions
         finalized = 0                               # targets of the round already loaded into the reference
+        emitted_here = False                        # an emission of THIS round has been begun (the deferred one is then "previous")
         ext_done = {}
         while True:
             if pending:
@@ -121,13 +122,12 @@ class RoundRunner:
                 if next_batch is not None and hasattr(m, "hash_batch_dev"):
                     m.hash_batch_dev(next_batch[0].data_ptr(), next_batch[1])
                     next_batch = None
-                # the previous round's streams: its emission's second phase ran beside the launches above
-                self.flush()
                 if self.p is not None:
                     tgt = [first + self.rank * T + targets[c] for c in pending]
                     m.emit_batch_begin(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
                                        [self.targets_done + finalized] * len(pending), tgt, self.loaded, n=len(pending))
                     un = m.emit_unmatched(len(pending))
+                    emitted_here = True
                 else:
                     un = [int(offsets[c + 1] - offsets[c]) for c in pending]     # matcher only: always extend
                 cnt = m.batch_counts()          # after the emission launches: no host round trip in between
@@ -157,6 +157,10 @@ class RoundRunner:
                     (self.rank * T + targets[c] == first_skip and c >= cut)]
             self._finalize_range(qbuf, offsets, targets, T, locks, unmatched, finalized, upto, ext_done)
             finalized = upto
+            # the previous round's streams: the second phase of its emission ran beside everything above (two
+            # emissions may be in flight) and is collected only now, with this round's finalize already queued
+            if self._deferred is not None:
+                self.flush(previous=self.p is not None and emitted_here)
             if finalized >= ntot:
                 break
             # retry: the skipping contig itself, and every contig of the targets after it
@@ -171,14 +175,19 @@ class RoundRunner:
         self.targets_done += ntot
         return counts
 
-    def flush(self):
-        """waits for the emission still in flight (if any) and merges its streams; call after the last round"""
+    def flush(self, previous=False):
+        """waits for the emission whose streams are still to be collected (if any) and merges them; call after
+        the last round. previous: a newer emission has been begun since (run_round's own call)."""
         d, self._deferred = self._deferred, None
         if d is None:
             return
         packs, last, targets, T, offsets, _ = d
         if last is not None:
+            if previous:
+                self.m.emit_select(True)
             packs.append(self._pack(*last, reuse=(self.world == 1 and not packs)))
+            if previous:
+                self.m.emit_select(False)
         self._collect_streams(packs, targets, T, offsets)
 
     def _match(self, qbuf, spans, locks, min_len):
@@ -198,6 +207,10 @@ class RoundRunner:
 
     def _pack(self, ks, cs, n_emitted, reuse=False):
         sizes, total = self.m.emit_pack_sizes(n_emitted)
+        if self.world == 1 and not self.keep_streams:
+            # nobody takes the bytes over: they stay where the emission packed them (the handle's arena), only
+            # their sizes are accounted
+            return dict(cs=cs, ks=ks, sizes=sizes, starts=None, buf=None)
         if reuse:
             # one grow-only buffer for the common case (one emission per round, consumed before the next one is
             # packed): allocating per round goes through the caching allocator, whose occasional hipMalloc stalls

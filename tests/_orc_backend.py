@@ -19,7 +19,7 @@ def _view(ptr, n):
 class OracleDeviceMatcher:
     def __init__(self, max_ref_len, **kw):
         self.o = _orc.OracleMatcher(max_ref_len, **kw)
-        self._contigs, self._locks, self._matches, self._em = [], [], [], []
+        self._contigs, self._locks, self._matches, self._em, self._em_prev, self._sel_prev = [], [], [], [], [], False
 
     # pass-through state API
     def __getattr__(self, name):
@@ -60,7 +60,7 @@ class OracleDeviceMatcher:
 
     def emit_batch(self, params, contigs=None, locks=None, factors=None, processed=None, target_idx=None, loaded=None, n=None):
         n = n if n is not None else len(self._contigs)
-        self._em = []
+        self._em_prev, self._em = self._em, []
         for k in range(n):
             c = k if contigs is None else int(contigs[k])
             em = _orc.OracleEmitter(self.o, params)
@@ -76,18 +76,24 @@ class OracleDeviceMatcher:
     def emit_batch_end(self):
         pass
 
+    def emit_select(self, previous):
+        self._sel_prev = bool(previous)
+
+    def _selected(self):
+        return self._em_prev if self._sel_prev else self._em
+
     def emit_unmatched(self, n):
         return np.array([u for u, _ in self._em[:n]], dtype=np.uint64)
 
     def emit_pack_sizes(self, n):
         sizes = np.zeros((n, 6), dtype=np.uint64)
-        for k, (un, em) in enumerate(self._em[:n]):
+        for k, (un, em) in enumerate(self._selected()[:n]):
             if un != _orc.SKIPPED:
                 sizes[k] = [len(em.stream(i)) for i in range(6)]
         return sizes, int(sizes.sum())
 
     def emit_pack_dev(self, dst, cap):
-        blob = b"".join(em.stream(i) for un, em in self._em if un != _orc.SKIPPED for i in range(6))
+        blob = b"".join(em.stream(i) for un, em in self._selected() if un != _orc.SKIPPED for i in range(6))
         assert len(blob) <= cap
         if blob:
             _view(dst, len(blob))[:] = np.frombuffer(blob, dtype=np.uint8)
