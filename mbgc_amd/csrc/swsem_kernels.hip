@@ -723,6 +723,47 @@ __device__ __forceinline__ bool same_match(const Match &a, const Match &b) {
     return a.posSrc == b.posSrc && a.len == b.len && a.posDest == b.posDest;
 }
 
+// The stitch's acceptance test for block b only looks at the block's own record and — when the block before
+// it was accepted as speculated — at that block's final state, which its record also holds. So the test is
+// evaluated for every block in parallel, "assuming the predecessor is accepted": the boundary scan position
+// equals the predecessor's final one, and the boundary rows the block looked at equal the predecessor's
+// newest rows, all of them pushed by the predecessor itself (then they are true rows once it is accepted).
+// k_stitch walks the blocks in order as before, but for a block that passes, after a predecessor accepted in
+// the same way, only the list bookkeeping is left; everything else takes the complete test below.
+struct __attribute__((aligned(16))) FastRec {
+    int32_t scanF;         // scan position after the block
+    int32_t minKeep;       // first row of the block's region that belongs to the list
+    int32_t npush;         // rows the block adds
+    int32_t popB;          // rows of the predecessor's it removes; -1: take the complete test
+};
+__global__ void __launch_bounds__(256) k_stitch_pre(const Contig *__restrict__ contigs, const uint32_t *__restrict__ rbContig,
+                                                    const BlockRec *__restrict__ recs, uint32_t rb, uint32_t nblocks,
+                                                    FastRec *__restrict__ fast) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nblocks) return;
+    const Contig cg = contigs[rbContig[g]];
+    const uint32_t b = g - cg.rb0;
+    const BlockRec &cur = recs[g];
+    FastRec f;
+    f.scanF = (int32_t) cur.scanF; f.minKeep = cur.minKeep; f.npush = cur.spF - cur.minKeep; f.popB = -1;
+    const bool visited = cur.minTouched != 0x7fffffff;
+    if (b == 0) {
+        if (visited) f.popB = 0;                                      // started from the true (empty) state: spB = minKeep = 0
+    } else if (visited && cur.minTouched >= 0) {
+        const BlockRec &prv = recs[g - 1];
+        const int32_t span = (int32_t) (rb * TILE), w0 = (int32_t) b * span;
+        const int32_t pScanF = (int32_t) prv.scanF;
+        const int cmp = cur.spB - cur.minTouched;
+        const int prevPush = prv.spF - prv.minKeep;
+        bool ok = prv.minTouched != 0x7fffffff && pScanF < w0 + span && (pScanF > w0 ? pScanF : w0) == (int32_t) cur.scanB &&
+                  cmp >= 0 && cmp <= SNAP && cmp <= prevPush;
+        for (int j = 0; ok && j < cmp; j++)
+            ok = cur.bTop[j].posSrc == prv.fTop[j].posSrc && cur.bTop[j].len == prv.fTop[j].len && cur.bTop[j].posDest == prv.fTop[j].posDest;
+        if (ok) f.popB = cur.spB - cur.minKeep;                      // <= cmp <= prevPush: stays inside the predecessor's segment
+    }
+    fast[g] = f;
+}
+
 // One wave per contig: walk the resolve blocks with the true state (see above). Outputs per block the
 // segment (segStart, keepN) of its region that belongs to the final list, the row offsets and the
 // contig's match count. The walk is a dependent chain executed by a single wave, so everything in it
@@ -733,6 +774,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
                                                  const Contig *__restrict__ contigs, const uint32_t *__restrict__ cand,
                                                  Row *__restrict__ regions, Row *__restrict__ replayArea,
                                                  uint32_t cap, uint32_t rb, const BlockRec *__restrict__ recs,
+                                                 const FastRec *__restrict__ fast,
                                                  uint32_t *__restrict__ segStart, uint32_t *__restrict__ keepN,
                                                  int32_t *__restrict__ prev, uint32_t *__restrict__ dstOff,
                                                  uint32_t *__restrict__ matchCount,
@@ -754,18 +796,30 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     const BlockRec *rc = recs + cg.rb0;
     const int32_t span = (int32_t) (rb * TILE);
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
-    constexpr int STAGE = 16;          // block records fetched per coalesced burst
-    __shared__ uint4 srec[STAGE * sizeof(BlockRec) / 16];
+    __shared__ uint4 srec[sizeof(BlockRec) / 16];
+    bool prevPlain = true;             // the block before was accepted as speculated (block 0: the empty state is what it assumed)
+    uint4 fr = make_uint4(0, 0, 0, 0); // FastRec of block (b & ~63) + lane
     for (uint32_t b = 0; b < cg.nrb; b++) {
-        if (b % STAGE == 0) {
-            const uint32_t nrec = cg.nrb - b < STAGE ? cg.nrb - b : STAGE;
+        if ((b & (WAVE - 1)) == 0) fr = b + lane < cg.nrb ? ((const uint4 *) (fast + cg.rb0))[b + lane] : make_uint4(0, 0, 0, 0xFFFFFFFFu);
+        const int32_t w0 = (int32_t) b * span;
+        if (scanT >= w0 + span) { prevPlain = false; continue; }  // the sequential loop jumped over this block
+        const int fl = (int) (b & (WAVE - 1));
+        const int32_t fPop = (int32_t) rl32(fr.w, fl);
+        if (prevPlain && fPop >= 0) {                           // accepted as speculated: only the list bookkeeping is left
+            const int32_t fMinKeep = (int32_t) rl32(fr.y, fl), fPush = (int32_t) rl32(fr.z, fl);
+            if (fPop > 0) vs.pop_segments(fPop);
+            vs.size_ -= fPop;
+            vs.push_segment((int) b, (uint32_t) fMinKeep, (uint32_t) fPush);
+            scanT = (int32_t) rl32(fr.x, fl);
+            known = 0;                                          // the newest-rows window is rebuilt from the list if ever needed
+            continue;
+        }
+        {                                                       // the complete test needs the whole record
             const uint4 *src = (const uint4 *) (rc + b);
-            for (uint32_t i = lane; i < nrec * (sizeof(BlockRec) / 16); i += WAVE) srec[i] = src[i];
+            for (uint32_t i = lane; i < sizeof(BlockRec) / 16; i += WAVE) srec[i] = src[i];
             __builtin_amdgcn_s_waitcnt(0);
         }
-        const int32_t w0 = (int32_t) b * span;
-        if (scanT >= w0 + span) continue;                       // the sequential loop jumped over this block
-        const BlockRec *r = (const BlockRec *) (srec + (b % STAGE) * (sizeof(BlockRec) / 16));
+        const BlockRec *r = (const BlockRec *) srec;
         const int32_t rScanB = (int32_t) rfl32((uint32_t) r->scanB), rScanF = (int32_t) rfl32((uint32_t) r->scanF);
         const int spB = (int) rfl32((uint32_t) r->spB), spF = (int) rfl32((uint32_t) r->spF);
         const int minTouched = (int) rfl32((uint32_t) r->minTouched), minKeep = (int) rfl32((uint32_t) r->minKeep);
@@ -814,8 +868,11 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
                 }
                 known = npush + keepOld < SNAP ? npush + keepOld : SNAP;
                 scanT = rScanF;
-            }
+                prevPlain = true;                               // its rows and final state are now known to be the true ones
+            } else
+                prevPlain = false;
         } else {
+            prevPlain = false;
             // Replay the block from the true state. The replay writes its rows to a scratch area and
             // watches the speculative chain's final rows: as soon as it emits a row the speculative chain
             // also ended up with, with the same scan position right after it, the two chains are in the

@@ -107,6 +107,7 @@ struct swsem {
     DevBuf<Match> dMatches;
     DevBuf<Row> dRegions, dReplay;
     DevBuf<BlockRec> dRecs;
+    DevBuf<FastRec> dFast;
     DevBuf<uint32_t> dSegStart, dKeepN, dDstOff;
     DevBuf<int32_t> dPrev;
     DevBuf<unsigned long long> dStats;
@@ -544,6 +545,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if ((r = h->dRegions.reserve((size_t) rblocks * cap))) return r;
         if ((r = h->dReplay.reserve((size_t) n * cap))) return r;
         if ((r = h->dRecs.reserve(rblocks))) return r;
+        if ((r = h->dFast.reserve(rblocks))) return r;
         if ((r = h->dSegStart.reserve(rblocks))) return r;
         if ((r = h->dKeepN.reserve(rblocks))) return r;
         if ((r = h->dDstOff.reserve(rblocks))) return r;
@@ -555,10 +557,11 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
                                                                                  h->dRegions.p, cap, h->rb, h->dRecs.p);
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
-        if (h->lazyProbe) k_stitch<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p,
+        k_stitch_pre<<<dim3((rblocks + 255) / 256), dim3(256), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRecs.p, h->rb, rblocks, h->dFast.p);
+        if (h->lazyProbe) k_stitch<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p, h->dFast.p,
                                                                              h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
                                                                              h->dMatchCount.p, h->dStats.p);
-        else k_stitch<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p,
+        else k_stitch<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p, h->dFast.p,
                                                                    h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
                                                                    h->dMatchCount.p, h->dStats.p);
         k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
@@ -724,7 +727,7 @@ void swsem_destroy(swsem_t *h) {
     if (h->lut) (void) hipFree(h->lut);
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release(); h->dCandNext.release(); h->dPrepTileContig.release(); h->dPrepContigs.release(); h->dPrepStats.release();
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
-    h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
+    h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dFast.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
     for (auto &E : h->slot) E.release();
     h->dTables.release();
