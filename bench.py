@@ -34,11 +34,11 @@ ALG_BYTES = {"probe": 1.0, "resolve": 4 * 0.29 + 0.918 + 0.23, "stitch": 0.23, "
 # HBM bytes per input base each family really moves, from the PMC passes in profiles/r01_pmc_hbm_traffic.json
 # (FETCH_SIZE + WRITE_SIZE of its largest launches = rounds of 16 x 5 Mbp, / 80 M bases)
 TRAFFIC = {"probe": (41035.8 + 313186.5) * 1024 / 80e6, "resolve": (2881920.2 + 57730.2) * 1024 / 80e6,
-           "stitch": (641.2 + 88.2 + 12967.4 + 18365.8) * 1024 / 80e6, "load": (39696.8 + 78735.5) * 1024 / 80e6,
+           "stitch": (600.2 + 76.5 + 111.7 + 88.1 + 12968.7 + 18353.3) * 1024 / 80e6, "load": (39696.8 + 78735.5) * 1024 / 80e6,
            "insert": (40359.1 + 156256.9) * 1024 / 80e6,
            "emit": (9639.8 + 893.6 + 17843.1 + 12633.3 + 24417.4 + 1560.2 + 90062.2 + 21189.8 + 21408.5 + 210015.7 +
                     844.4 + 1149.9 + 33364.4 + 756.1 + 8890.0 + 17190.2 + 127.9 + 16375.0 + 96054.1) * 1024 / 80e6}
-KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query)", "resolve": "k_resolve_blocks<true>", "stitch": "k_stitch + k_gather",
+KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query)", "resolve": "k_resolve_blocks<true>", "stitch": "k_stitch_pre + k_stitch + k_gather",
              "load": "k_copy_multi", "insert": "k_insert_multi", "emit": "k_emit_* (14 launches)"}
 
 
