@@ -117,4 +117,9 @@ void orc_buf_put(orc_buf *b, const void *p, uint64_t n);
 #ifdef __cplusplus
 }
 #endif
+/* ---- input stage (fasta_oracle.c): kseq_read_lossless_fasta over a whole file, utils/kseq.h:233-274 */
+typedef struct { uint64_t headerOff, headerLen, seqOff, seqLen; } orc_fasta_record;
+uint64_t orc_fasta_parse(const uint8_t *file, uint64_t n, int uppercase, uint8_t *seqOut, orc_fasta_record *rec, uint64_t recCap,
+                         uint64_t *seqBytes, uint64_t *dnaLineLen, int *status);
+
 #endif

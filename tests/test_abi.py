@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/mbgc_swsem.h declares (no compute calls:
+"""The C-ABI library loads and exports every symbol include/*.h declares (no compute calls:
 runs without a GPU), error paths that need no device behave, and the product package never reaches
 for the oracle."""
 import ctypes
@@ -10,9 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "mbgc_swsem.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(swsem_[A-Za-z0-9_]+)\s*\(", src)))
+    syms = set()
+    for header, prefix in (("mbgc_swsem.h", "swsem_"), ("mbgc_fasta.h", "mbgc_fasta_")):
+        src = open(os.path.join(ROOT, "include", header)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        syms |= set(re.findall(r"\b(%s[A-Za-z0-9_]+)\s*\(" % prefix, src))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,7 +27,8 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     from mbgc_amd import binding
-    assert set(binding.EXPORTS) <= set(syms)
+    from mbgc_amd import fasta
+    assert set(binding.EXPORTS) <= set(syms) and set(fasta.EXPORTS) <= set(syms)
 
 
 def test_no_device_means_loud_failure_not_fallback():
