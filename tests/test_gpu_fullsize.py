@@ -1,0 +1,51 @@
+"""BASELINE.json configs[1] at full size — 128 synthetic 5 Mbp genomes, rounds of 16, the 1.28e9-byte reference
+and 2^27-bucket table `mbgc c` derives for them — through the product's whole pipeline (RoundRunner: look-ahead
+hashing, on-demand table lookups with fingerprints, block-speculative resolve, two emission slots on a second
+stream, batched finalize) against the oracle driven through the reference's target loop with the same round
+schedule: every byte of the six streams, the lock and refExtSize streams and the final hash-table image."""
+import numpy as np
+import pytest
+
+import _driver
+import _orc
+from mbgc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+L, N, R = 5_000_000, 128, 16
+MAX_REF_LEN = 1_280_000_000
+
+
+def test_configs1_all_rounds_equal_oracle():
+    import torch
+    from mbgc_amd import binding
+    from mbgc_amd.rounds import RoundRunner
+    base = synth.base_codes(L)
+    gs = [synth.genome(base, i) for i in range(N)]
+    # oracle side (CPU, ~0.07 Gbases/s)
+    o = _orc.OracleMatcher(MAX_REF_LEN)
+    exp = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], R)
+    # device side
+    h = binding.SlidingWindowSparseEMMatcher(MAX_REF_LEN)
+    h.set_sliding_window_size(16)
+    g0 = torch.from_numpy(gs[0]).to("cuda:0")
+    torch.cuda.synchronize()
+    h.load_ref_dev(g0.data_ptr(), g0.numel(), True, True, 0)
+    runner = RoundRunner(h, 0, 1, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1), keep_streams=True)
+    runner.start()
+    rounds = [gs[r0:r0 + R] for r0 in range(1, N, R)]
+    bufs = []
+    for chunk in rounds:
+        offs = np.zeros(len(chunk) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([c.size for c in chunk])
+        bufs.append((torch.from_numpy(np.concatenate(chunk)).to("cuda:0"), offs))
+    torch.cuda.synchronize()
+    for i, (buf, offs) in enumerate(bufs):
+        runner.run_round(buf, offs, next_batch=bufs[i + 1] if i + 1 < len(bufs) else None)
+    runner.flush()
+    for k, v in exp["streams"].items():
+        assert bytes(runner.streams[k]) == v, "stream %s differs (%d vs %d bytes)" % (k, len(runner.streams[k]), len(v))
+    assert bytes(runner.locks_stream) == exp["locks"] and bytes(runner.ref_ext_sizes) == exp["refExtSize"]
+    assert h.loaded_ref_length() == o.loaded_ref_length()
+    assert np.array_equal(h.ht(), o.ht())
+    assert sum(len(v) for v in exp["streams"].values()) > 50_000_000      # ~0.14 B per base of 635 Mbases
