@@ -158,6 +158,25 @@ int swsem_emit_batch(swsem_t *h, const swsem_emit_params_t *p, int n, const int 
 int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
                            const int *unmatchedFractionFactor, const int64_t *processedTargetsCount, const int64_t *targetIdx,
                            const uint64_t *refExtLoadedPos, uint64_t nLoaded);
+/* swsem_emit_batch_begin with a speculative finalize: the caller predicts, per emitted contig, how
+ * isContigProperForRefExtension / isContigProperForRefRCExtension (MGMP_Params.h:178-190, factors as in MGMP.cpp:389-398)
+ * will come out, and hands over the swsem_finalize_targets arguments that follow from the prediction. The copies
+ * and the table insertion are queued directly behind pass 1, gated by a device-side check of the prediction, so
+ * they need not wait for the host's round trip. *applied = 1: every decision came out as predicted (and no contig
+ * was given up as dissimilar): the finalize has been done — loadedAfter is filled, the locks are released — and
+ * must not be repeated. *applied = 0: nothing has changed, device or host; finalize as usual. */
+typedef struct {
+    int ntargets;
+    const uint8_t *const *ext_dev; const uint64_t *ext_len;   /* as swsem_finalize_targets */
+    int addSep, sep, lazySeparator;
+    const uint64_t *lockPos;
+    uint64_t *loadedAfter;
+    const uint8_t *predExt, *predRC;                            /* [n emitted contigs] predicted decisions */
+    int factor, rcFactor;                                       /* unmatchedFractionFactor, unmatchedFractionRCFactor */
+} swsem_spec_finalize_t;
+int swsem_emit_batch_begin_spec(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+                                const int *unmatchedFractionFactor, const int64_t *processedTargetsCount, const int64_t *targetIdx,
+                                const uint64_t *refExtLoadedPos, uint64_t nLoaded, const swsem_spec_finalize_t *spec, int *applied);
 int swsem_emit_batch_end(swsem_t *h);
 /* Two emissions can be in flight: _begin only waits for the one before the previous (whose buffers it takes
  * over). swsem_emit_result / swsem_emit_pack_dev read the latest emission, or — after swsem_emit_select(h, 1) —

@@ -21,8 +21,14 @@ swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circula
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_hash_batch_dev swsem_batch_counts swsem_batch_matches
-swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
+swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_copy""".split()
+
+
+class SpecFinalize(C.Structure):
+    _fields_ = [("ntargets", C.c_int), ("ext_dev", C.c_void_p), ("ext_len", C.POINTER(C.c_uint64)), ("addSep", C.c_int), ("sep", C.c_int),
+                ("lazySeparator", C.c_int), ("lockPos", C.POINTER(C.c_uint64)), ("loadedAfter", C.POINTER(C.c_uint64)),
+                ("predExt", C.c_void_p), ("predRC", C.c_void_p), ("factor", C.c_int), ("rcFactor", C.c_int)]
 
 
 class SwsemError(RuntimeError):
@@ -102,6 +108,7 @@ def lib():
         L.swsem_emit_batch.argtypes = [vp, C.POINTER(EmitParams), ci, vp, vp, vp, vp, vp, vp, u64]
         L.swsem_emit_batch_begin.argtypes = L.swsem_emit_batch.argtypes
         L.swsem_emit_batch_end.argtypes = [vp]
+        L.swsem_emit_batch_begin_spec.argtypes = L.swsem_emit_batch.argtypes + [C.POINTER(SpecFinalize), C.POINTER(C.c_int)]
         L.swsem_emit_select.argtypes = [vp, ci]
         L.swsem_emit_result.argtypes = [vp, ci, C.POINTER(Streams)]
         L.swsem_emit_set_host_copy.argtypes = [vp, ci]
@@ -267,6 +274,28 @@ class SlidingWindowSparseEMMatcher:
         return self.emit_batch(*a, _entry="swsem_emit_batch_begin", **k)
 
     def emit_batch_end(self): _chk(lib().swsem_emit_batch_end(self.h))
+
+    def emit_batch_begin_spec(self, params, locks, factors, processed, target_idx, loaded, n, ext_ptrs, ext_lens, target_locks,
+                              pred_ext, pred_rc, factor, rc_factor, lazy=True, add_sep=True, sep=0):
+        """emit_batch_begin plus a speculative finalize of the round's targets (see include/mbgc_swsem.h). Returns
+        (applied, loaded_after): applied False means nothing was done and finalize_targets is still to be called."""
+        u64, P = np.uint64, C.POINTER(C.c_uint64)
+        lk, fa = np.ascontiguousarray(locks, dtype=u64), np.ascontiguousarray(factors, dtype=np.int32)
+        pr, ti = np.ascontiguousarray(processed, dtype=np.int64), np.ascontiguousarray(target_idx, dtype=np.int64)
+        ld = np.ascontiguousarray(loaded if loaded is not None else [0], dtype=u64)
+        nt = len(ext_lens)
+        ptrs = (C.c_void_p * nt)(*[int(x) for x in ext_ptrs])
+        lens = np.ascontiguousarray(ext_lens, dtype=u64)
+        tl = np.ascontiguousarray(target_locks, dtype=u64)
+        after = np.zeros(nt, dtype=u64)
+        pe, prc = np.ascontiguousarray(pred_ext, dtype=np.uint8), np.ascontiguousarray(pred_rc, dtype=np.uint8)
+        sp = SpecFinalize(nt, C.cast(ptrs, C.c_void_p), lens.ctypes.data_as(P), int(add_sep), sep, int(lazy), tl.ctypes.data_as(P),
+                          after.ctypes.data_as(P), pe.ctypes.data_as(C.c_void_p), prc.ctypes.data_as(C.c_void_p), int(factor), int(rc_factor))
+        applied = C.c_int()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _chk(lib().swsem_emit_batch_begin_spec(self.h, C.byref(params), n, None, vp(lk), vp(fa), vp(pr), vp(ti), vp(ld), ld.size,
+                                               C.byref(sp), C.byref(applied)))
+        return bool(applied.value), after
     def emit_select(self, previous): _chk(lib().swsem_emit_select(self.h, int(previous)))
 
     def emit_set_host_copy(self, on): lib().swsem_emit_set_host_copy(self.h, int(on))

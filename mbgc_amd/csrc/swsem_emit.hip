@@ -476,10 +476,35 @@ __global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const Emi
     const uint32_t lane = threadIdx.x;
     const bool lazy = v.p.lazyDecompressionSupport != 0;
     const int64_t nb = (n + META_BLOCK - 1) / META_BLOCK;
+    // A block that started from the state its predecessor ended in is correct if the predecessor is (block 0 starts
+    // from the true, empty state). That comparison needs nothing but the stored states, so it is made for 64
+    // blocks at a time; the sequential walk below only starts at the first block that fails it — on similar
+    // genomes there is none and the kernel ends here.
+    const MetaState *S0 = states + (size_t) cg.chunk0 * 2;
+    int64_t firstBad = nb;
+    for (int64_t g0 = 1; g0 < nb && firstBad == nb; g0 += WAVE) {
+        const int64_t b = g0 + lane;
+        bool bad = false;
+        if (b < nb) {
+            const MetaState *A = S0 + 2 * b, *F = S0 + 2 * (b - 1) + 1;      // b's start, b-1's end
+            bad = A->claimed != F->claimed || A->gapStartIdx != F->gapStartIdx || A->gapEndIdx != F->gapEndIdx ||
+                  (A->curClaimed != 0) != (F->curClaimed != 0);
+            for (int k = 0; k <= WAVE && !bad; k++) bad = A->nx[k] != F->nx[k];
+        }
+        const unsigned long long mb = __ballot(bad);
+        if (mb) firstBad = g0 + __builtin_ctzll(mb);
+    }
+    if (firstBad == nb) return;
     MetaRun st;                                                      // true state at the start of block b
-    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1; st.nxA = 0; st.nxB = 0;
+    {
+        const MetaState *F = S0 + 2 * (firstBad - 1) + 1;
+        st.claimed = rfl64(F->claimed); st.curClaimed = rfl32(F->curClaimed) != 0;
+        st.gapStartIdx = (int64_t) rfl64((uint64_t) F->gapStartIdx); st.gapEndIdx = (int64_t) rfl64((uint64_t) F->gapEndIdx);
+        st.nxA = F->nx[lane];
+        st.nxB = lane == 0 ? F->nx[WAVE] : 0;
+    }
     uint32_t replayed = 0;
-    for (int64_t b = 0; b < nb; b++) {
+    for (int64_t b = firstBad; b < nb; b++) {
         const int64_t j0 = b * META_BLOCK, j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
         const MetaState *S = states + ((size_t) cg.chunk0 + b) * 2;
         bool same = true;
@@ -511,9 +536,43 @@ __global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const Emi
 // ------------------------------------------------------------------------------------------------
 struct ExtRes { uint32_t consumed, nlit, nfl, matched, mism; };
 
+// The automata walk the reference and the query one byte at a time, and every byte used to be a dependent
+// global load (a microsecond each once the GPU is busy). ByteWin keeps the 8 bytes around the last index in
+// a register: one load per 8 steps, forward (window starts at the index) or backward (window ends at it).
+__device__ __forceinline__ uint64_t ld_u64(const uint8_t *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
+// index of the first zero byte of w counted from the low end (8: none) / from the high end
+__device__ __forceinline__ int zero_lo(uint64_t w) {
+    const uint64_t t = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;
+    return t ? (__builtin_ctzll(t) >> 3) : 8;
+}
+__device__ __forceinline__ int zero_hi(uint64_t w) {
+    // (the borrow trick above is only exact for the lowest zero byte: test the bytes from the top one by one)
+    for (int k = 0; k < 8; k++) if (((w >> (56 - 8 * k)) & 0xFF) == 0) return k;
+    return 8;
+}
+
+template <bool FWD>
+struct ByteWin {
+    const uint8_t *base;
+    int64_t hi;                       // bytes [0, hi) of base may be read
+    int64_t at;
+    uint64_t w;
+    __device__ __forceinline__ ByteWin(const uint8_t *b, int64_t limit) : base(b), hi(limit), at(INT64_MIN / 2), w(0) {}
+    __device__ __forceinline__ uint8_t get(int64_t i) {
+        if (hi < 8) return base[i];
+        if (i < at || i >= at + 8) {
+            at = FWD ? i : i - 7;
+            if (at < 0) at = 0;
+            if (at + 8 > hi) at = hi - 8;
+            __builtin_memcpy(&w, base + at, 8);
+        }
+        return (uint8_t) (w >> (8 * (int) (i - at)));
+    }
+};
+
 // extendMatchRight, MBGC_Encoder.cpp:310-371
 template <bool W>
-__device__ ExtRes ext_right(const EmitView &v, const uint8_t *gap, int64_t src, uint64_t length, bool isGap, bool gapStart,
+__device__ ExtRes ext_right(const EmitView &v, const uint8_t *gapPtr, int64_t gapAvail, int64_t src, uint64_t length, bool isGap, bool gapStart,
                             bool gapMiddle, bool gapEnd, uint8_t *lit, uint8_t *fl) {
     ExtRes r = {0, 0, 0, 0, 0};
     const swsem_emit_params_t &p = v.p;
@@ -521,7 +580,7 @@ __device__ ExtRes ext_right(const EmitView &v, const uint8_t *gap, int64_t src, 
         if (gapMiddle) { if (W) fl[0] = 1; r.nfl = 1; }
         return r;
     }
-    const uint8_t *ref = v.ref;
+    ByteWin<true> ref(v.ref, (int64_t) v.maxRefLength + 8), gap(gapPtr, gapAvail);
     const bool lazy = p.lazyDecompressionSupport != 0;
     const int64_t loading = (int64_t) v.pos1;
     const int64_t srcGuard = src + (int64_t) length;
@@ -534,23 +593,37 @@ __device__ ExtRes ext_right(const EmitView &v, const uint8_t *gap, int64_t src, 
     }
     uint32_t g = 0;
     if (gapStart || !isGap) {
-        if (lazy && ref[src] == 0) valid = src;
+        if (lazy && ref.get(src) == 0) valid = src;
         r.mism++;
-        const uint8_t b = p.mismatchesWithExclusion && src < valid ? mismatch2code(ref[src], gap[0]) : gap[0];
+        const uint8_t b = p.mismatchesWithExclusion && src < valid ? mismatch2code(ref.get(src), gap.get(0)) : gap.get(0);
         if (W) lit[r.nlit] = b;
         r.nlit++;
         g++;
     } else
         src--;
     int score = p.mmsMismatchesInitialScore;
-    while (++src < valid && (!lazy || ref[src] != 0) && (isGap || score < p.mmsMismatchesScoreThreshold)) {
-        const bool mm = gap[g] != ref[src];
+    while (++src < valid && (!lazy || ref.get(src) != 0) && (isGap || score < p.mmsMismatchesScoreThreshold)) {
+        // A stretch of matching bytes changes nothing but counters (flag 0 each, the score only falls): 8 bytes at a
+        // time up to the first mismatch / separator byte. What is left takes the byte-wise step below.
+        while (src + 8 <= valid && (int64_t) g + 8 <= gapAvail) {
+            const uint64_t rw = ld_u64(v.ref + src), x = rw ^ ld_u64(gapPtr + g);
+            int c = x ? (__builtin_ctzll(x) >> 3) : 8;
+            if (lazy) { const int z = zero_lo(rw); if (z < c) c = z; }
+            if (c == 0) break;
+            if (W) for (int k = 0; k < c; k++) fl[r.nfl + k] = 0;
+            r.nfl += c; r.matched += c; g += c; src += c;
+            score -= p.mmsMatchBonus * c;
+            if (score < 0) score = 0;
+            if (c < 8) break;
+        }
+        if (!(src < valid && (!lazy || ref.get(src) != 0))) break;   // (the score test still holds: it only fell)
+        const bool mm = gap.get(g) != ref.get(src);
         if (W) fl[r.nfl] = mm ? 1 : 0;
         r.nfl++;
         if (mm) {
             r.mism++;
             score += p.mmsMismatchPenalty;
-            const uint8_t b = p.mismatchesWithExclusion ? mismatch2code(ref[src], gap[g]) : gap[g];
+            const uint8_t b = p.mismatchesWithExclusion ? mismatch2code(ref.get(src), gap.get(g)) : gap.get(g);
             if (W) lit[r.nlit] = b;
             r.nlit++;
         } else {
@@ -561,7 +634,7 @@ __device__ ExtRes ext_right(const EmitView &v, const uint8_t *gap, int64_t src, 
         g++;
     }
     while (src++ < srcGuard && (isGap || score < p.mmsMismatchesScoreThreshold)) {
-        if (W) { fl[r.nfl] = 1; lit[r.nlit] = gap[g]; }
+        if (W) { fl[r.nfl] = 1; lit[r.nlit] = gap.get(g); }
         r.nfl++; r.nlit++; g++;
         r.mism++;
         score += p.mmsMismatchPenalty;
@@ -573,11 +646,11 @@ __device__ ExtRes ext_right(const EmitView &v, const uint8_t *gap, int64_t src, 
 
 // extendMatchLeft, MBGC_Encoder.cpp:373-427
 template <bool W>
-__device__ ExtRes ext_left(const EmitView &v, const uint8_t *dest, uint64_t length, const EMatch &m, uint64_t lockPos,
+__device__ ExtRes ext_left(const EmitView &v, const uint8_t *dest, int64_t destLen, uint64_t length, const EMatch &m, uint64_t lockPos,
                            uint8_t *lit, uint8_t *fl) {
     ExtRes r = {0, 0, 0, 0, 0};
     const swsem_emit_params_t &p = v.p;
-    const uint8_t *ref = v.ref;
+    ByteWin<false> ref(v.ref, (int64_t) v.maxRefLength + 8), gq(dest, destLen);
     const bool lazy = p.lazyDecompressionSupport != 0;
     const int64_t srcMatch = (int64_t) m.posSrc;
     int64_t guard = 1;
@@ -588,25 +661,38 @@ __device__ ExtRes ext_left(const EmitView &v, const uint8_t *dest, uint64_t leng
     if (guard < srcMatch - (int64_t) length) { guard = srcMatch - (int64_t) length; guardKnown = false; }
     if (guard == srcMatch) return r;
     int64_t src = srcMatch - 1;
-    const uint8_t *gp = dest + m.posDest - 1;
-    bool validRegion = !lazy || ref[src] != 0;
+    int64_t gp = (int64_t) m.posDest - 1;                 // index into the contig
+    bool validRegion = !lazy || ref.get(src) != 0;
     r.mism++;
     {
-        const uint8_t b = p.mismatchesWithExclusion && validRegion ? mismatch2code(ref[src], *gp) : *gp;
+        const uint8_t b = p.mismatchesWithExclusion && validRegion ? mismatch2code(ref.get(src), gq.get(gp)) : gq.get(gp);
         if (W) lit[r.nlit] = b;
         r.nlit++;
     }
     int score = p.mmsMismatchesInitialScore;
     while (validRegion && src > guard && score < p.mmsMismatchesScoreThreshold) {
+        // matching stretches 8 bytes at a time (see ext_right), walking down: bytes src-1 .. src-8 against gp-1 .. gp-8
+        while (src - 8 >= guard && gp >= 8) {
+            const uint64_t rw = ld_u64(v.ref + src - 8), x = rw ^ ld_u64(dest + gp - 8);
+            int c = x ? (__builtin_clzll(x) >> 3) : 8;
+            if (lazy) { const int z = zero_hi(rw); if (z < c) c = z; }
+            if (c == 0) break;
+            if (W) for (int k = 0; k < c; k++) fl[r.nfl + k] = 0;
+            r.nfl += c; r.matched += c; gp -= c; src -= c;
+            score -= p.mmsMatchBonus * c;
+            if (score < 0) score = 0;
+            if (c < 8) break;
+        }
+        if (!(src > guard)) break;
         --gp; --src;
-        const bool mm = *gp != ref[src];
-        if (lazy && ref[src] == 0) { validRegion = false; src++; gp++; break; }
+        const bool mm = gq.get(gp) != ref.get(src);
+        if (lazy && ref.get(src) == 0) { validRegion = false; src++; gp++; break; }
         if (W) fl[r.nfl] = mm ? 1 : 0;
         r.nfl++;
         if (mm) {
             score += p.mmsMismatchPenalty;
             r.mism++;
-            const uint8_t b = p.mismatchesWithExclusion ? mismatch2code(ref[src], *gp) : *gp;
+            const uint8_t b = p.mismatchesWithExclusion ? mismatch2code(ref.get(src), gq.get(gp)) : gq.get(gp);
             if (W) lit[r.nlit] = b;
             r.nlit++;
         } else {
@@ -618,7 +704,7 @@ __device__ ExtRes ext_left(const EmitView &v, const uint8_t *dest, uint64_t leng
     while (!validRegion && src > guard && score < p.mmsMismatchesScoreThreshold) {
         src--;
         --gp;
-        if (W) { fl[r.nfl] = 1; lit[r.nlit] = *gp; }
+        if (W) { fl[r.nfl] = 1; lit[r.nlit] = gq.get(gp); }
         r.nfl++; r.nlit++;
         r.mism++;
         score += p.mmsMismatchPenalty;
@@ -660,8 +746,8 @@ __device__ uint32_t gap_right(const EmitView &v, const EmitContig &cg, const EMa
         const EMatch core = E[v.corr[cg.scratchBase + t - 1]];
         const int64_t src = isGapBefore ? (int64_t) (core.posSrc + (mp.posDest + mp.len) - core.posDest)
                                         : (int64_t) (mp.posSrc + mp.len);
-        const ExtRes r = ext_right<W>(v, q + pos, src, litLeft, isGapBefore, (meta & META_GSTART) != 0, (meta & META_GMID) != 0,
-                                      (meta & META_GEND) != 0, rLit, rFl);
+        const ExtRes r = ext_right<W>(v, q + pos, (int64_t) cg.n - (int64_t) pos, src, litLeft, isGapBefore, (meta & META_GSTART) != 0,
+                                      (meta & META_GMID) != 0, (meta & META_GEND) != 0, rLit, rFl);
         s.rLit = r.nlit; s.rFl = r.nfl;
         pos += r.consumed;
         if (!W) { counters[0] += r.matched; counters[1] += r.mism; }
@@ -679,7 +765,7 @@ __device__ GapSizes gap_sizes(const EmitView &v, const EmitContig &cg, const EMa
         const EMatch m = E[t];
         uint64_t litLeft = m.posDest - pos;                                             // :216
         if (v.p.enableExtensionsWithMismatches && !isGapBefore && litLeft) {            // :218-221
-            const ExtRes r = ext_left<false>(v, q, litLeft, m, cg.lock, nullptr, nullptr);
+            const ExtRes r = ext_left<false>(v, q, (int64_t) cg.n, litLeft, m, cg.lock, nullptr, nullptr);
             s.lLit = r.nlit; s.lFl = r.nfl;
             litLeft -= r.consumed;
             counters[0] += r.matched; counters[1] += r.mism;
@@ -865,7 +951,7 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
     uint8_t *rLit = plainDst + z[4] + 1, *rFl = lFl + z[3];
     if (z[2] | z[3]) {
         const EMatch m = E[t];
-        ext_left<true>(v, q, m.posDest - z[5], m, cg.lock, lLit, lFl);
+        ext_left<true>(v, q, (int64_t) cg.n, m.posDest - z[5], m, cg.lock, lLit, lFl);
     }
     plainDst[z[4]] = MATCH_MARK;
     if (zn[0] | zn[1]) {
@@ -882,6 +968,24 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
     if (frugal) frugal_write(v.arena + pb[SWSEM_LEN] + w[4], E[t].len);
     else put_bytes(v.arena + pb[SWSEM_LEN] + w[4], (uint32_t) E[t].len, 4);
     if (meta & META_HASGAP) v.arena[pb[SWSEM_GAP] + w[5]] = (uint8_t) (meta >> 8);
+}
+
+// The prediction a speculative finalize was queued on (swsem_emit_batch_begin_spec): every contig's reference
+// extension decision — isContigProperForRefExtension / isContigProperForRefRCExtension, MGMP_Params.h:178-190,
+// as MGMP.cpp:389-398 applies them — must come out as predicted, and no contig may have been given up as
+// dissimilar. gate[0] = 1 lets the finalize kernels queued behind this one run.
+__global__ void k_spec_verify(const EmitOut *__restrict__ out, const EmitContig *__restrict__ cgs, int n, const uint8_t *__restrict__ predExt,
+                              const uint8_t *__restrict__ predRC, int factor, int rcFactor, uint32_t *__restrict__ gate) {
+    __shared__ uint32_t bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const uint64_t un = out[k].unmatchedChars, len = cgs[k].n;
+        const bool ext = un * (uint64_t) factor > len, rc = un * (uint64_t) rcFactor > len;
+        if (un == UINT64_MAX || ext != (predExt[k] != 0) || rc != (predRC[k] != 0)) atomicOr(&bad, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) gate[0] = bad ? 0u : 1u;
 }
 
 }  // namespace swk

@@ -33,8 +33,11 @@ __global__ void k_set_byte(uint8_t *p, uint8_t v) { *p = v; }
 // alignment), then the separator bytes in program order by one thread.
 struct CopyPiece { uint64_t dst; const uint8_t *src; uint64_t len; };
 struct BytePiece { uint64_t off, val; };
+// gate: when not null the launch belongs to a speculative finalize (swsem_emit_batch_begin_spec) and does nothing
+// unless the device-side check of the prediction stored a 1 there.
 __global__ void __launch_bounds__(256) k_copy_multi(uint8_t *__restrict__ ref, const CopyPiece *__restrict__ pieces,
-                                                    const uint64_t *__restrict__ first, int np) {
+                                                    const uint64_t *__restrict__ first, int np, const uint32_t *__restrict__ gate) {
+    if (gate && *gate == 0) return;
     int lo = 0, hi = np - 1;                                        // piece p with first[p] <= blockIdx.x < first[p+1]
     while (lo < hi) {
         const int mid = (lo + hi + 1) / 2;
@@ -63,7 +66,8 @@ __global__ void __launch_bounds__(256) k_upload(uint8_t *__restrict__ dst, const
     } else
         for (uint64_t k = o; k < n; k++) dst[k] = src[k];
 }
-__global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restrict__ b, int n) {
+__global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restrict__ b, int n, const uint32_t *__restrict__ gate) {
+    if (gate && *gate == 0) return;
     for (int i = 0; i < n; i++) ref[b[i].off] = (uint8_t) b[i].val;
 }
 
@@ -92,7 +96,9 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
 struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, pad; };
 __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                       const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first,
-                                                      int np, int k1, int k1ord, int K, uint32_t mask, int fpBits) {
+                                                      int np, int k1, int k1ord, int K, uint32_t mask, int fpBits,
+                                                      const uint32_t *__restrict__ gate) {
+    if (gate && *gate == 0) return;
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= first[np]) return;
     int lo = 0, hi = np;                               // largest p with first[p] <= g

@@ -17,6 +17,8 @@
 
 using namespace swk;
 
+#define SWSEM_ESPEC (-100)   /* internal: a speculative finalize cannot be queued (it would need an ungated write) */
+
 namespace {
 
 thread_local std::string g_err;
@@ -79,6 +81,9 @@ struct swsem {
     int fpBits = 0;                        // fingerprint bits of a table entry: what the bucket index leaves of the 32-bit hash, at most 8
     bool lazyProbe = true;                 // chains gather the hash table on demand (SWSEM_PROBE=lazy) instead of a dense probe pass
     bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
+    bool specMode = false;                 // a speculative finalize is being queued: nothing may be written outside its gated launches
+    DevBuf<uint32_t> dGate;
+    DevBuf<uint8_t> dPred;
     std::vector<InsertPiece> pendingPieces;
     std::vector<CopyPiece> pendingCopies;    // ... and its byte writes: device-to-device copies,
     std::vector<BytePiece> pendingBytes;     // then single bytes (separators), each list in program order
@@ -335,14 +340,14 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
     return SWSEM_OK;
 }
 
-int flush_inserts(swsem *h);
+int flush_inserts(swsem *h, const uint32_t *gate = nullptr);
 }  // namespace
 // (defined below, after run_batch's helpers)
 namespace {
 // everything collected while deferInserts was set: all copies in one launch, the separator bytes in one
 // (in program order; no copy of a round lands on a byte written by an earlier separator of the same
 // round), then every insertion phase in one launch. The tables travel in a single upload.
-int flush_inserts(swsem *h) {
+int flush_inserts(swsem *h, const uint32_t *gate) {
     const size_t np = h->pendingPieces.size(), nc = h->pendingCopies.size(), nb = h->pendingBytes.size();
     if (!np && !nc && !nb) return SWSEM_OK;
     {
@@ -363,7 +368,7 @@ int flush_inserts(swsem *h) {
         ht.p = nullptr; ht.cap = 0;
         // generous: (re)allocating pinned memory synchronises the whole device, it must not recur in steady state
         const size_t want = std::max<size_t>(2 * words, 1 << 16);
-        if (hipHostMalloc((void **) &ht.p, want * 8, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want * 8);
+        if (hipHostMalloc((void **) &ht.p, want * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want * 8);
         ht.cap = want;
     }
     if (!ht.ev) HIPCHK(hipEventCreateWithFlags(&ht.ev, hipEventDisableTiming));
@@ -378,26 +383,35 @@ int flush_inserts(swsem *h) {
     if (nb) memcpy(tBytes, h->pendingBytes.data(), nb * sizeof(BytePiece));
     int r;
     if ((r = h->dTables.reserve(std::max<size_t>(2 * tab.size(), 1 << 16)))) return r;   // regrowing = hipFree = a device-wide wait
-    HIPCHK(hipMemcpyAsync(h->dTables.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, h->stream));
+    // (a kernel reading the pinned table: a runtime copy here costs an engine switch in the middle of the main stream)
+    k_upload<<<dim3((unsigned) ((tab.size() * 8 + 4095) / 4096)), dim3(256), 0, h->stream>>>((uint8_t *) h->dTables.p, (const uint8_t *) tab.data(), tab.size() * 8);
     HIPCHK(hipEventRecord(ht.ev, h->stream));
     ht.pending = true;
     const uint64_t *d = h->dTables.p;
     if (nc) {
         h->mark(SWSEM_K_LOAD, true);
         k_copy_multi<<<dim3((unsigned) tCFirst[nc]), dim3(256), 0, h->stream>>>(h->ref, (const CopyPiece *) (d + (tCopies - tab.data())),
-                                                                              d + (tCFirst - tab.data()), (int) nc);
+                                                                              d + (tCFirst - tab.data()), (int) nc, gate);
         h->mark(SWSEM_K_LOAD, false);
     }
-    if (nb) k_set_bytes<<<1, 1, 0, h->stream>>>(h->ref, (const BytePiece *) (d + (tBytes - tab.data())), (int) nb);
+    if (nb) k_set_bytes<<<1, 1, 0, h->stream>>>(h->ref, (const BytePiece *) (d + (tBytes - tab.data())), (int) nb, gate);
     if (np) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert_multi<<<dim3((unsigned) ((tFirst[np] + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits);
+            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
         h->mark(SWSEM_K_INSERT, false);
     }
     HIPCHK(hipGetLastError());
     h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear();
     return SWSEM_OK;
+}
+
+// small device results -> pinned (mapped) host memory, by a kernel on `st`; visible to the host once an event recorded
+// behind it has completed
+void download(swsem *h, void *dstPinned, const void *srcDev, size_t bytes, hipStream_t st) {
+    (void) h;
+    if (!bytes) return;
+    k_upload<<<dim3((unsigned) ((bytes + 4095) / 4096)), dim3(256), 0, st>>>((uint8_t *) dstPinned, (const uint8_t *) srcDev, bytes);
 }
 
 // copies `bytes` of host data to the device through the pinned ring, asynchronously on `st`
@@ -409,7 +423,7 @@ int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
         if (h->ring) HIPCHK(hipHostFree(h->ring));
         h->ring = nullptr; h->ringCap = 0; h->ringAt = 0;
         const size_t want = std::max<size_t>(need * 8, 8u << 20);
-        if (hipHostMalloc((void **) &h->ring, want, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want);
+        if (hipHostMalloc((void **) &h->ring, want, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want);
         h->ringCap = want;
     }
     if (h->ringAt + need > h->ringCap) {               // wrap: everything staged a lap ago has long been copied, but make sure
@@ -524,7 +538,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     // hashes announced ahead for exactly these buffers: adopt them
     const bool adopted = h->prepValid && h->lazyProbe && h->prepQ == qdev && h->prepOffsets.size() == (size_t) n + 1 &&
                          std::equal(h->prepOffsets.begin(), h->prepOffsets.end(), offsets);
-    h->prepValid = false;
+    if (adopted) h->prepValid = false;                  // (a batch in between — a retry inside a round — leaves the announcement standing)
     if (adopted && tiles) {
         std::swap(h->dCand, h->dCandNext);
         HIPCHK(hipStreamWaitEvent(h->stream, h->evHash, 0));
@@ -585,7 +599,7 @@ int pin_reserve(swsem *h, size_t bytes) {
     if (h->pin) HIPCHK(hipHostFree(h->pin));
     h->pin = nullptr; h->pinCap = 0;
     const size_t want = std::max<size_t>(2 * bytes, 1 << 20);          // see flush_inserts: no regrowth in steady state
-    if (hipHostMalloc((void **) &h->pin, want, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want);
+    if (hipHostMalloc((void **) &h->pin, want, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin %zu B of host memory", want);
     h->pinCap = want;
     return SWSEM_OK;
 }
@@ -596,8 +610,8 @@ int queue_counts(swsem *h, size_t extraBytes) {
     const size_t countsAt = 64, extraAt = (countsAt + n * sizeof(uint32_t) + 63) & ~(size_t) 63;
     int r = pin_reserve(h, extraAt + extraBytes);
     if (r) return r;
-    HIPCHK(hipMemcpyAsync(h->pin, h->dStats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->pin + countsAt, h->dMatchCount.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    download(h, h->pin, h->dStats.p, 8 * sizeof(unsigned long long), h->stream);
+    download(h, h->pin + countsAt, h->dMatchCount.p, n * sizeof(uint32_t), h->stream);
     h->pinExtraAt = extraAt;
     return SWSEM_OK;
 }
@@ -708,7 +722,9 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     HIPCHK(hipMemsetAsync(h->ht, 0, (size_t) h->hash_size * sizeof(ht_entry), h->stream));
     // start1[0] = 0 (.cpp:335); the rest of the buffer is written before it is ever read, the slack
     // past the end is zeroed because the reference's own reads run a few bytes over (:224, ENC:337)
-    HIPCHK(hipMemsetAsync(h->ref, 0, 64, h->stream));
+    // the whole buffer starts out as zeros (the reference reads — harmlessly — bytes it has not loaded yet, e.g. the one at the
+    // loading position in extendMatchRight; left as allocated they would be whatever an earlier process had there)
+    HIPCHK(hipMemsetAsync(h->ref, 0, maxRefLength, h->stream));
     HIPCHK(hipMemsetAsync(h->ref + maxRefLength, 0, REF_SLACK, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *out = h;
@@ -730,7 +746,7 @@ void swsem_destroy(swsem_t *h) {
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dFast.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release();
     for (auto &E : h->slot) E.release();
-    h->dTables.release();
+    h->dTables.release(); h->dGate.release(); h->dPred.release();
     if (h->pin) { hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
     if (h->ring) { hipHostFree(h->ring); h->ring = nullptr; h->ringCap = 0; }
     for (auto &t : h->hostTables) { if (t.p) hipHostFree(t.p); if (t.ev) hipEventDestroy(t.ev); t = swsem::HostTab(); }
@@ -832,6 +848,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
     if ((uint64_t) h->pos1 == h->swEnd) {
         // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was
         h->pristine = false;
+        if (h->specMode) return SWSEM_ESPEC;                      // an ungated write in the middle: give the speculation up
         if (h->deferInserts) { int r = flush_inserts(h); if (r) return r; }
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1 - 1, (uint8_t) sep);
     } else if (h->deferInserts) {
@@ -846,8 +863,8 @@ int swsem_load_separator(swsem_t *h, int sep) {
 // finalizeParallelProcessingOfTarget for n targets in order (MGMP.cpp:440-457, MBGC_Encoder.cpp:557-562):
 // loadRef of the target's extension, the lazy-mode region separator, release of its lock position.
 // loadedAfter[i] = getLoadedRefLength() after target i (what the encoder appends to refExtLoadedPosArr).
-int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
-                           int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter) {
+static int finalize_impl(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
+                         int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter, const uint32_t *gate) {
     HIPCHK(hipSetDevice(h->device));
     // all byte writes of the round first (copies, region separators), then every insertion phase in one
     // launch: hashing a window needs its bytes — including a separator written by a later step — in place
@@ -860,8 +877,14 @@ int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, con
         if (!r && lockPos) r = swsem_release_lock(h, lockPos[i]);
     }
     h->deferInserts = false;
-    const int r2 = flush_inserts(h);
+    if (r == SWSEM_ESPEC) { h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear(); return r; }
+    const int r2 = flush_inserts(h, gate);
     return r ? r : r2;
+}
+
+int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
+                           int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter) {
+    return finalize_impl(h, n, ext_dev, ext_len, addSep, sep, lazySeparator, lockPos, loadedAfter, nullptr);
 }
 
 int swsem_hash_batch_dev(swsem_t *h, const uint8_t *q, const uint64_t *offsets, int n) {
@@ -1045,10 +1068,14 @@ void swsem_emit_params_default(swsem_emit_params_t *p, int mode) {
 
 // processMatches for `n` contigs of the last batch in one pass (the reference runs it per contig on the
 // worker thread that matched it, MGMP.cpp:381). Results stay on the handle until the next emit call.
-int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+static int finalize_impl(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
+                         int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter, const uint32_t *gate);
+
+static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
                            const int *factor, const int64_t *processed, const int64_t *targetIdx,
-                           const uint64_t *refExtLoadedPos, uint64_t nLoaded) {
+                           const uint64_t *refExtLoadedPos, uint64_t nLoaded, const swsem_spec_finalize_t *spec, int *applied) {
     HIPCHK(hipSetDevice(h->device));
+    if (applied) *applied = 0;
     const int si = h->latest ^ 1;                                     // the slot not used by the previous emission
     { int e = end_slot(h, si); if (e) return e; }                    // its scratch is about to be reused
     swsem::EmitSlot &E = h->slot[si];
@@ -1127,14 +1154,14 @@ int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     // pass-1 results (unmatchedChars, the dissimilarity verdict), match counts and statistics: one pinned block, one wait
     const bool needCounts = h->matchCount.size() != h->contigs.size();
     if ((r = queue_counts(h, n * sizeof(EmitOut)))) return r;
-    HIPCHK(hipMemcpyAsync(h->pin + h->pinExtraAt, E.dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream));
+    download(h, h->pin + h->pinExtraAt, E.dEOut.p, n * sizeof(EmitOut), h->stream);
     HIPCHK(hipEventRecord(h->evP1, h->stream));
     // the rest runs on the second stream behind pass 1
     if (E.pinECap < n * sizeof(EmitOut)) {
         if (E.pinE) HIPCHK(hipHostFree(E.pinE));
         E.pinE = nullptr; E.pinECap = 0;
         const size_t want = std::max<size_t>(2 * n * sizeof(EmitOut), 1 << 20);
-        if (hipHostMalloc((void **) &E.pinE, want, hipHostMallocDefault) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
+        if (hipHostMalloc((void **) &E.pinE, want, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
         E.pinECap = want;
     }
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
@@ -1149,15 +1176,61 @@ int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(E.pinE, E.dEOut.p, n * sizeof(EmitOut), hipMemcpyDeviceToHost, h->stream2));
+    download(h, E.pinE, E.dEOut.p, n * sizeof(EmitOut), h->stream2);
     HIPCHK(hipEventRecord(E.evDone, h->stream2));
     h->latest = si; h->selected = -1;
     E.outstanding = true; E.refGuarded = false; E.emitN = n; E.emitPos1 = (uint64_t) h->pos1;
     E.packedBytes = 0; E.hostStreamsValid = false;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // Speculative finalize: the round's loadRef / loadSeparator / lock releases are worked out on the host now, under
+    // the caller's prediction of every contig's extension decision, and queued behind a device-side check of that
+    // prediction — so the copies and the table insertion start the moment pass 1 ends instead of after the host's
+    // round trip. The host comes to the same verdict from the values pass 1 hands back and keeps or undoes its
+    // bookkeeping accordingly; when the prediction fails nothing on the device has changed.
+    struct { int64_t pos1; int laps; uint64_t samplingPos, swEnd; uint32_t epoch; bool pristine; std::deque<uint64_t> locks; } snap;
+    bool queued = false;
+    if (spec && spec->ntargets > 0) {
+        snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch;
+        snap.pristine = h->pristine; snap.locks = h->locks;
+        if ((r = h->dGate.reserve(4)) || (r = h->dPred.reserve(2 * (size_t) n + 64))) return r;
+        if ((r = upload(h, h->dPred.p, spec->predExt, n, h->stream)) || (r = upload(h, h->dPred.p + n, spec->predRC, n, h->stream))) return r;
+        k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, h->dGate.p);
+        h->specMode = true;
+        r = finalize_impl(h, spec->ntargets, spec->ext_dev, spec->ext_len, spec->addSep, spec->sep, spec->lazySeparator, spec->lockPos,
+                          spec->loadedAfter, h->dGate.p);
+        h->specMode = false;
+        if (r == SWSEM_ESPEC) r = SWSEM_OK;                         // not possible this time: nothing was queued
+        else if (r) return r;
+        else queued = true;
+        if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch;
+                       h->pristine = snap.pristine; h->locks = snap.locks; }
+    }
+    HIPCHK(hipEventSynchronize(h->evP1));                           // pass 1 and its copies to the host (not what was queued after them)
     if (needCounts) take_counts(h);
     E.eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
+    if (queued) {
+        bool ok = true;                                             // the same test k_spec_verify makes
+        for (int k = 0; k < n && ok; k++) {
+            const uint64_t un = E.eout[k].unmatchedChars, len = E.ecg[k].n;
+            ok = un != UINT64_MAX && (un * (uint64_t) spec->factor > len) == (spec->predExt[k] != 0) &&
+                 (un * (uint64_t) spec->rcFactor > len) == (spec->predRC[k] != 0);
+        }
+        if (ok) { if (applied) *applied = 1; }
+        else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch;
+               h->pristine = snap.pristine; h->locks = snap.locks; }
+    }
     return SWSEM_OK;
+}
+
+int swsem_emit_batch_begin(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+                           const int *factor, const int64_t *processed, const int64_t *targetIdx,
+                           const uint64_t *refExtLoadedPos, uint64_t nLoaded) {
+    return emit_begin_impl(h, p, n, contigIdx, lockPos, factor, processed, targetIdx, refExtLoadedPos, nLoaded, nullptr, nullptr);
+}
+
+int swsem_emit_batch_begin_spec(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
+                                const int *factor, const int64_t *processed, const int64_t *targetIdx,
+                                const uint64_t *refExtLoadedPos, uint64_t nLoaded, const swsem_spec_finalize_t *spec, int *applied) {
+    return emit_begin_impl(h, p, n, contigIdx, lockPos, factor, processed, targetIdx, refExtLoadedPos, nLoaded, spec, applied);
 }
 
 // waits for every emission still in its second phase (oldest first); afterwards their streams can be fetched

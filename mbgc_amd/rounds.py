@@ -50,6 +50,11 @@ class RoundRunner:
                  policy=None, keep_streams=True):
         self.m, self.rank, self.world, self.group = matcher, rank, world, group
         self.device = torch.device(device)
+        # The protocol mixes the handle's launches with torch operations on the same buffers (reverse complements
+        # written by the handle and concatenated by torch, concatenations read by the handle's copies): both must
+        # run on one stream, or they race.
+        if self.device.type == "cuda" and hasattr(matcher, "set_stream"):
+            matcher.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.lazy = lazy
         self.p = emit_params                         # None: matcher only, every contig extends the reference
         self.policy = policy or Policy()
@@ -63,6 +68,7 @@ class RoundRunner:
         self._keep = []                              # temporaries handed to finalize_targets: alive until the next host wait
         self._deferred = None                        # emission whose streams have not been collected yet
         self._pack_buf = None
+        self._pred_ext = None                        # what every contig of the last round decided about extending the reference
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -122,10 +128,21 @@ class RoundRunner:
                 if next_batch is not None and hasattr(m, "hash_batch_dev"):
                     m.hash_batch_dev(next_batch[0].data_ptr(), next_batch[1])
                     next_batch = None
+                spec_applied = False
                 if self.p is not None:
                     tgt = [first + self.rank * T + targets[c] for c in pending]
-                    m.emit_batch_begin(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
-                                       [self.targets_done + finalized] * len(pending), tgt, self.loaded, n=len(pending))
+                    spec = self._speculation(qbuf, offsets, targets, T, pending, finalized, ncont)
+                    if spec is not None:
+                        # the round's finalize is queued behind pass 1 under the prediction "every contig decides as the
+                        # last round's did"; the library applies it only if that is what pass 1 finds
+                        before = m.loaded_ref_length()
+                        spec_applied, after = m.emit_batch_begin_spec(
+                            self.p, [lock_of[c] for c in pending], [self.policy.factor] * ncont, [self.targets_done] * ncont, tgt,
+                            self.loaded, ncont, spec[0], spec[1], locks, [self._pred_ext] * ncont, [False] * ncont,
+                            self.policy.factor, self.policy.rc_factor, self.lazy)
+                    else:
+                        m.emit_batch_begin(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
+                                           [self.targets_done + finalized] * len(pending), tgt, self.loaded, n=len(pending))
                     un = m.emit_unmatched(len(pending))
                     emitted_here = True
                 else:
@@ -155,8 +172,12 @@ class RoundRunner:
             cut = min([c for c in skipped_local if self.rank * T + targets[c] == first_skip], default=ncont)
             redo = [c for c in range(ncont) if self.rank * T + targets[c] > first_skip or
                     (self.rank * T + targets[c] == first_skip and c >= cut)]
-            self._finalize_range(qbuf, offsets, targets, T, locks, unmatched, finalized, upto, ext_done)
+            if pending and spec_applied:            # (implies: no skip, the whole round) only the bookkeeping is left
+                self._note_finalized(locks, after, before)
+            else:
+                self._finalize_range(qbuf, offsets, targets, T, locks, unmatched, finalized, upto, ext_done)
             finalized = upto
+            self._learn(offsets, unmatched, skipped_local)
             # the previous round's streams: the second phase of its emission ran beside everything above (two
             # emissions may be in flight) and is collected only now, with this round's finalize already queued
             if self._deferred is not None:
@@ -283,6 +304,51 @@ class RoundRunner:
             cur[r] += ln
             idx[r] += 1
         self._finalize_many(ptrs, lens, [locks[t] for t in range(lo, hi)])
+
+    def _speculation(self, qbuf, offsets, targets, T, pending, finalized, ncont):
+        """(ext pointers, ext lengths) per target under the prediction, or None when this emission cannot carry a
+        speculative finalize: not the whole round on a single GPU, no uniform prediction yet, or targets whose
+        contigs are not one contiguous span of qbuf."""
+        if (self.world != 1 or self._pred_ext is None or finalized or len(pending) != ncont or
+                not hasattr(self.m, "emit_batch_begin_spec")):
+            return None
+        ptrs, lens, base = [0] * T, [0] * T, qbuf.data_ptr()
+        span = {}
+        for c, t in enumerate(targets):
+            s, e = int(offsets[c]), int(offsets[c + 1])
+            if t in span:
+                if span[t][1] != s:
+                    return None
+                span[t][1] = e
+            else:
+                span[t] = [s, e]
+        if self._pred_ext:
+            for t, (s, e) in span.items():
+                ptrs[t], lens[t] = (base + s, e - s) if e > s else (0, 0)
+        return ptrs, lens
+
+    def _learn(self, offsets, unmatched, skipped):
+        """prediction for the next round: what every contig of this one decided, if they all decided alike"""
+        if self.p is None or self.world != 1:
+            return
+        ext, rc = set(), False
+        for c, un in enumerate(unmatched):
+            if un is None:
+                continue
+            n = int(offsets[c + 1] - offsets[c])
+            ext.add(bool(self.policy.proper_for_ext(n, un)))
+            rc = rc or bool(self.policy.proper_for_rc_ext(n, un))
+        self._pred_ext = ext.pop() if len(ext) == 1 and not rc and not skipped else None
+
+    def _note_finalized(self, locks, after, before):
+        """the bookkeeping of _finalize_many for a finalize the library has already applied"""
+        for lk, a in zip(locks, after.tolist()):
+            if self.lazy:
+                self.ref_ext_sizes += frugal64(a - before)
+                if self.loaded is not None:
+                    self.loaded.append(a)
+                before = a
+            self.locks_stream += int(lk).to_bytes(8, "little")
 
     def _finalize_many(self, ptrs, lens, locks):
         """finalizeParallelProcessingOfTarget for consecutive targets in one call into the library:

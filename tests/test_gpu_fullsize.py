@@ -40,9 +40,32 @@ def test_configs1_all_rounds_equal_oracle():
         offs[1:] = np.cumsum([c.size for c in chunk])
         bufs.append((torch.from_numpy(np.concatenate(chunk)).to("cuda:0"), offs))
     torch.cuda.synchronize()
+    got_counts = []
     for i, (buf, offs) in enumerate(bufs):
-        runner.run_round(buf, offs, next_batch=bufs[i + 1] if i + 1 < len(bufs) else None)
+        cnt = runner.run_round(buf, offs, next_batch=bufs[i + 1] if i + 1 < len(bufs) else None)
+        got_counts += [int(x) for x in cnt]
+        if i >= 1:                                              # rounds without retries: the batch on the handle is the whole round
+            for c in range(len(cnt)):
+                want = exp["matches"][i * R + c]
+                got = h.batch_matches(c, int(cnt[c]))
+                if got.shape != want.shape or not np.array_equal(got, want):
+                    n = min(len(got), len(want))
+                    k = next((j for j in range(n) if not np.array_equal(got[j], want[j])), n)
+                    print("round %d contig %d: first differing row %d of %d/%d" % (i, c, k, len(got), len(want)))
+                    print(" got ", got[max(0, k - 2): k + 3].tolist())
+                    print(" want", want[max(0, k - 2): k + 3].tolist())
+                    print(" block of 16384 positions:", int(want[k][2]) // 16384 if k < len(want) else -1, "pos in block", int(want[k][2]) % 16384 if k < len(want) else -1)
+                    break
+    want_counts = [len(m) for m in exp["matches"]]
+    bad = [i for i, (a, b) in enumerate(zip(got_counts, want_counts)) if a != b]
+    if bad:
+        print("match counts differ for contigs", bad[:10], [(got_counts[i], want_counts[i]) for i in bad[:10]])
     runner.flush()
+    got, want = bytes(runner.streams["literals"]), exp["streams"]["literals"]
+    if got != want:                                            # say which contig (one per target here) before failing
+        i = next((j for j in range(min(len(got), len(want))) if got[j] != want[j]), min(len(got), len(want)))
+        print("literals differ at %d: contig %d of the collection, round %d, slot in round %d" %
+              (i, want[:i].count(0xA2), want[:i].count(0xA2) // R, want[:i].count(0xA2) % R))
     for k, v in exp["streams"].items():
         assert bytes(runner.streams[k]) == v, "stream %s differs (%d vs %d bytes)" % (k, len(runner.streams[k]), len(v))
     assert bytes(runner.locks_stream) == exp["locks"] and bytes(runner.ref_ext_sizes) == exp["refExtSize"]
