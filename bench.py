@@ -167,7 +167,7 @@ def main():
     replayed = 0
     for s in range(warm, warm + steps):
         # every timed step also hashes a following round's queries (the last one a round that is not matched here)
-        tot_matches += int(runner.run_round(*bufs[s], next_batch=bufs[(s + 1) % len(bufs)]).sum())
+        tot_matches += int(runner.run_round(*bufs[s], next_batch=None if os.environ.get('MBGC_BENCH_NO_LOOKAHEAD') else bufs[(s + 1) % len(bufs)]).sum())
         replayed += m.batch_stats()["replayed_blocks"]
     runner.flush()                                     # the last round's emission (its second phase runs beside the next round)
     barrier()
@@ -184,6 +184,8 @@ def main():
         t = buf[: 3 * nb.value].reshape(-1, 3).astype(np.float64)
         print("resolve blocks %d: ticks mean %.0f max %.0f (100 MHz), visits %d (mean %.0f/block), rows %d" %
               (nb.value, t[:, 0].mean(), t[:, 0].max(), t[:, 1].sum(), t[:, 1].mean(), t[:, 2].sum()), file=sys.stderr)
+        if os.environ.get("MBGC_BENCH_BLOCK_DUMP"):
+            np.save(os.environ["MBGC_BENCH_BLOCK_DUMP"], buf[: 3 * nb.value].reshape(-1, 3))
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -77,7 +77,8 @@ __global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restri
 // (the tail runs after the main loop on the CPU, so it wins collisions against it).
 __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                 uint64_t S, uint64_t nMain, uint64_t T, uint64_t nTail, int k1,
-                                                int k1ord, int K, uint32_t mask, uint32_t epoch, int fpBits) {
+                                                int k1ord, int K, uint32_t mask, uint32_t epoch, int fpBits,
+                                                uint32_t *__restrict__ bloom, uint32_t bloomMask) {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nMain + nTail) return;
     const bool tail = t >= nMain;
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
     const ht_entry key = ht_key(epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
     atomicMax(&ht[h & mask], key);
+    if (bloom) bloom_set(bloom, bloomMask, h);
 }
 
 // The same for several loadRef pieces in one launch. Epochs make the result independent of the order in
@@ -97,7 +99,7 @@ struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, pad; };
 __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                       const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first,
                                                       int np, int k1, int k1ord, int K, uint32_t mask, int fpBits,
-                                                      const uint32_t *__restrict__ gate) {
+                                                      const uint32_t *__restrict__ gate, uint32_t *__restrict__ bloom, uint32_t bloomMask) {
     if (gate && *gate == 0) return;
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= first[np]) return;
@@ -113,6 +115,7 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
     const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
     atomicMax(&ht[h & mask], key);
+    if (bloom) bloom_set(bloom, bloomMask, h);
 }
 
 __global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict__ ht, uint32_t *__restrict__ out, uint64_t n, int fpBits) {
@@ -558,6 +561,13 @@ struct NoStop { __device__ __forceinline__ bool operator()() { return false; } }
 #define SWSEM_WL 32
 #endif
 constexpr int WL = SWSEM_WL;
+// Scalar registers of the block-resolve kernel. A SIMD has 800 of them and a wave is given its count plus ~20,
+// rounded up to 16: the 106 the compiler takes when left alone allow 6 waves per SIMD, 72 allow 8 (measured
+// with a spinning kernel: 6144 and 8192 resident waves chip-wide). The chains are latency-bound, so resident
+// waves are throughput.
+#ifndef SWSEM_RESOLVE_SGPRS
+#define SWSEM_RESOLVE_SGPRS 72
+#endif
 template <class Stack, class Stop = NoStop>
 __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ hashes,
                                int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
@@ -565,17 +575,28 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
     int32_t wb = -0x40000000;                                         // window [wb, wb + WL)
     uint32_t w = 0;
     unsigned long long m = 0;
+    uint32_t prioTick = 0;
     while (true) {
         const int32_t s = ch.scan > p0 ? ch.scan : p0;
         if (s >= p1) break;
         ch.scan = s;
         if (s < wb || s >= wb + WL) {
+            // The SIMD's arbiter serves its oldest wave first, and with every CU's memory pipeline saturated that
+            // is a lasting advantage: blocks dispatched first ran 25 % faster than the last ones, and the launch
+            // lasts as long as its slowest wave. Each wave therefore walks through the four priority levels,
+            // one scan window at a time (spread 761-986 us -> 828-897 us per contig, the launch 1.10 -> 1.02 ms).
+            switch ((prioTick++ + blockIdx.x) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
             wb = s;
             const int32_t pos = s + lane;
             uint32_t e = 0;
             if (lane < WL && pos < p1) {
                 const uint32_t hv = hashes[pos];
-                e = ht_value(v, v.ht[hv & v.mask], hv);
+                if (!v.bloom || bloom_has(v, hv)) e = ht_value(v, v.ht[hv & v.mask], hv);
                 if (e != 0) {
                     uint64_t lo, hi;
                     if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;
@@ -686,7 +707,7 @@ __device__ __forceinline__ void snapshot_top(const Row *st, int sp, Match *out) 
 
 // resolve block rbIdx of a contig = tiles [rbIdx*rb, (rbIdx+1)*rb) of it
 template <bool LAZY>
-__global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RESOLVE_SGPRS))) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ rbContig,
                                                          const uint32_t *__restrict__ cand,
@@ -703,6 +724,9 @@ __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_
     Chain ch;
     ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
     const uint64_t tstart = __builtin_amdgcn_s_memtime();
+#ifdef SWSEM_DIAG_T0
+    const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     ArrayStack<Row> stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
@@ -722,6 +746,10 @@ __global__ void __launch_bounds__(WAVE) k_resolve_blocks(RefView v, const uint8_
     snapshot_top(stk.st, stk.sp, r.fTop);
     r.cycles = __builtin_amdgcn_s_memtime() - tstart;
     r.visits = ch.cands; r.emits = (uint32_t) (stk.sp);
+#ifdef SWSEM_DIAG_T0
+    r.visits = (uint32_t) rt0;                            // diagnostics build: the wave's start and end on the 100 MHz clock
+    r.emits = (uint32_t) __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) recs[g] = r;
 }
 

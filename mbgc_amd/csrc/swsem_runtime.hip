@@ -19,6 +19,13 @@ using namespace swk;
 
 #define SWSEM_ESPEC (-100)   /* internal: a speculative finalize cannot be queued (it would need an ungated write) */
 
+#ifdef SWSEM_HTRACE
+#include <time.h>
+static inline void htrace(const char *what) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "HT %lld.%03ld %s\n", (long long) ts.tv_sec * 1000000 + ts.tv_nsec / 1000, ts.tv_nsec % 1000, what); }
+#define HT(x) htrace(x)
+#else
+#define HT(x) ((void) 0)
+#endif
 namespace {
 
 thread_local std::string g_err;
@@ -166,7 +173,9 @@ struct swsem {
     hipEvent_t evP1 = nullptr;
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
-    uint32_t rb = 4;                       // probe tiles per resolve block (SWSEM_RB)
+    uint32_t rb = 4;                       // probe tiles per resolve block: chosen per batch (run_batch) unless SWSEM_RB fixes it
+    uint32_t rbFixed = 0;
+    uint32_t waveSlots = 8192;             // waves the device holds at 8 per SIMD
     std::vector<Contig> contigs;
     std::vector<uint32_t> matchCount;
     std::vector<swsem_match_t> hostMatches;
@@ -177,15 +186,20 @@ struct swsem {
     uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
     // --- profiling
     bool prof = false;
+    uint32_t profMask = ~0u;               // families that get event brackets (SWSEM_PROF_FAMS: every bracket is two markers in the queue)
     std::deque<ProfEvent> events;
     double profMs[SWSEM_K_COUNT] = {0};
     uint64_t profN[SWSEM_K_COUNT] = {0};
+
+    uint32_t *bloom = nullptr;             // presence bits in front of the table (swsem_device.h: bloom_has); an experiment, off by default
+    uint32_t bloomMask = 0;
 
     uint64_t refLength() const { return laps ? maxRefLength : (uint64_t) pos1; }
     RefView view() const {
         RefView v;
         v.ref = ref; v.ht = ht; v.pos1 = (uint64_t) pos1; v.refLength = refLength(); v.maxRefLength = maxRefLength;
         v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? 1 : 0; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
+        v.bloom = (v.fpCheck && bloom) ? bloom : nullptr; v.bloomMask = bloomMask;
         return v;
     }
     // event pairs are recycled: creating events by the hundred makes the runtime grow its signal pool now and
@@ -198,7 +212,7 @@ struct swsem {
         idle.push_back(e);
     }
     void mark(int fam, bool begin, hipStream_t on = nullptr) {
-        if (!prof) return;
+        if (!prof || !((profMask >> fam) & 1u)) return;
         if (!on) on = stream;
         if (begin) {
             while (events.size() > 1 && hipEventQuery(events.front().b) == hipSuccess) {   // harvest what has finished
@@ -274,7 +288,7 @@ int insert_samples(swsem *h) {
     } else if (total) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch, h->fpBits);
+            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch, h->fpBits, h->bloom, h->bloomMask);
         h->mark(SWSEM_K_INSERT, false);
         HIPCHK(hipGetLastError());
     }
@@ -313,15 +327,15 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
         uint64_t tmpLength = len;
         const uint64_t tmpMax = tmpEnd < (uint64_t) h->pos1 ? h->maxRefLength : tmpEnd;
         if ((uint64_t) h->pos1 + tmpLength > tmpMax) tmpLength = tmpMax - (uint64_t) h->pos1;
-        if (tmpLength) {
+        if (tmpLength && !rc && h->deferInserts) {                  // (nothing is launched here: no profiling bracket)
+            CopyPiece cp; cp.dst = (uint64_t) h->pos1; cp.src = text; cp.len = tmpLength;
+            h->pendingCopies.push_back(cp);
+        } else if (tmpLength) {
             h->mark(SWSEM_K_LOAD, true);
             if (rc) {
                 const uint64_t thr = (tmpLength + 3) / 4;
                 const unsigned blocks = (unsigned) std::min<uint64_t>((thr + 255) / 256, 8192);
                 k_load_rc<<<dim3(blocks), dim3(256), 0, h->stream>>>(text + len - tmpLength, h->ref + h->pos1, tmpLength, h->lut);
-            } else if (h->deferInserts) {
-                CopyPiece cp; cp.dst = (uint64_t) h->pos1; cp.src = text; cp.len = tmpLength;
-                h->pendingCopies.push_back(cp);
             } else
                 HIPCHK(hipMemcpyAsync(h->ref + h->pos1, text, tmpLength, hipMemcpyDeviceToDevice, h->stream));
             h->mark(SWSEM_K_LOAD, false);
@@ -398,7 +412,7 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     if (np) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert_multi<<<dim3((unsigned) ((tFirst[np] + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
+            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->bloom, h->bloomMask);
         h->mark(SWSEM_K_INSERT, false);
     }
     HIPCHK(hipGetLastError());
@@ -443,6 +457,7 @@ int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
 
 // K-mer hashes of a future batch, beside whatever the main stream is doing (the hashes depend on the query only)
 int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n) {
+    HT("prepare_hashes enter");
     h->prepValid = false;
     hipStream_t hs = h->stream3;
     if (n <= 0 || !h->lazyProbe) return SWSEM_OK;
@@ -486,6 +501,7 @@ int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n
 }
 
 int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {
+    HT("run_batch enter");
     if (n <= 0) return fail(SWSEM_EINVAL, "empty batch");
     if (minLen < (uint32_t) h->K)   // SlidingWindowSparseEMMatcher.cpp:480-483
         return fail(SWSEM_EINVAL, "Minimal matching length cannot be smaller than K (%u < %d)", minLen, h->K);
@@ -497,6 +513,19 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     tileContig.clear(); rbContig.clear();
     uint64_t matchRows = 0, bases = 0;
     uint32_t tiles = 0, rblocks = 0;
+    {
+        // Block chains are latency-bound and a launch lasts as long as its slowest wave: the blocks are sized so
+        // that all of them are resident at once (one wave each, 8 per SIMD) and there are as many as that allows.
+        // Fewer, longer blocks leave wave slots empty; more of them run in two generations and lengthen the
+        // sequential stitch. At least two tiles, so that the warm-up stays a small part of a block.
+        uint64_t allTiles = 0;
+        for (int c = 0; c < n; c++) {
+            const uint64_t len = offsets[c + 1] - offsets[c];
+            allTiles += len >= (uint64_t) h->K ? (len - h->K + 1 + TILE - 1) / TILE : 0;
+        }
+        const uint64_t slots = std::max<uint64_t>(1, (uint64_t) h->waveSlots * 19 / 20);
+        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(16, std::max<uint64_t>(2, (allTiles + slots - 1) / slots));
+    }
     for (int c = 0; c < n; c++) {
         Contig &cg = h->contigs[c];
         cg.qoff = offsets[c];
@@ -708,13 +737,28 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
         hipEventCreateWithFlags(&h->evMatchedPrev, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
     if (const char *e = getenv("SWSEM_PROBE")) h->lazyProbe = strcmp(e, "dense") != 0;
-    if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rb = (uint32_t) x; }
+    if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
+    if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rbFixed = (uint32_t) x; }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 32u; }
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
         hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
         hipMalloc((void **) &h->lut, 256) != hipSuccess) {
         swsem_destroy(h);
         return fail(SWSEM_ENOMEM, "cannot allocate %llu B reference + %llu B hash table in HBM",
                     (unsigned long long) maxRefLength, (unsigned long long) h->hash_size * 8ull);
+    }
+    {
+        int extra = -1;                                                  // off unless SWSEM_BLOOM=n asks for 2^(n-1) filter bits per bucket
+        if (const char *e = getenv("SWSEM_BLOOM")) extra = atoi(e) <= 0 ? -1 : atoi(e) - 1;
+        int bits = 0;
+        while ((1ull << bits) < h->hash_size) bits++;
+        bits = std::min(32, bits + extra);
+        if (extra >= 0 && h->fpBits && bits >= 5) {
+            const size_t bytes = (size_t) 1 << (bits - 3);
+            if (hipMalloc((void **) &h->bloom, bytes) != hipSuccess) { swsem_destroy(h); return fail(SWSEM_ENOMEM, "cannot allocate the %zu B presence filter", bytes); }
+            h->bloomMask = bits == 32 ? ~0u : (1u << bits) - 1u;
+            HIPCHK(hipMemsetAsync(h->bloom, 0, bytes, h->stream));
+        }
     }
     uint8_t lut[256];
     build_lut(lut);
@@ -740,6 +784,7 @@ void swsem_destroy(swsem_t *h) {
     h->drain_events();
     if (h->ref) (void) hipFree(h->ref);
     if (h->ht) (void) hipFree(h->ht);
+    if (h->bloom) (void) hipFree(h->bloom);
     if (h->lut) (void) hipFree(h->lut);
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release(); h->dCandNext.release(); h->dPrepTileContig.release(); h->dPrepContigs.release(); h->dPrepStats.release();
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
@@ -877,8 +922,10 @@ static int finalize_impl(swsem_t *h, int n, const uint8_t *const *ext_dev, const
         if (!r && lockPos) r = swsem_release_lock(h, lockPos[i]);
     }
     h->deferInserts = false;
+    HT("finalize: pieces done");
     if (r == SWSEM_ESPEC) { h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear(); return r; }
     const int r2 = flush_inserts(h, gate);
+    HT("finalize: flushed");
     return r ? r : r2;
 }
 
@@ -1075,9 +1122,11 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
                            const int *factor, const int64_t *processed, const int64_t *targetIdx,
                            const uint64_t *refExtLoadedPos, uint64_t nLoaded, const swsem_spec_finalize_t *spec, int *applied) {
     HIPCHK(hipSetDevice(h->device));
+    HT("emit_begin enter");
     if (applied) *applied = 0;
     const int si = h->latest ^ 1;                                     // the slot not used by the previous emission
     { int e = end_slot(h, si); if (e) return e; }                    // its scratch is about to be reused
+    HT("slot ended");
     swsem::EmitSlot &E = h->slot[si];
     if (!h->batchValid) return fail(SWSEM_EINVAL, "swsem_emit: no match results on the handle");
     if (n <= 0) return fail(SWSEM_EINVAL, "swsem_emit: empty request");
@@ -1113,8 +1162,10 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         for (int st = 0; st < SWSEM_NSTREAMS; st++) { e.streamBase[st] = arena; arena += (szs[st] + 15) & ~15ull; }
     }
     const uint32_t chunks = (uint32_t) E.chunkOwner.size();
+    HT("tables built");
     h->capN = std::max<uint64_t>(h->capN, (uint64_t) n); h->capRows = std::max(h->capRows, rows); h->capArena = std::max(h->capArena, arena);
-    h->capLoaded = std::max<uint64_t>(h->capLoaded, nLoaded + 1 + nLoaded / 2); h->capChunks = std::max<uint64_t>(h->capChunks, chunks);
+    if (nLoaded + 1 > h->capLoaded) h->capLoaded = std::max<uint64_t>(4096, 2 * (nLoaded + 1));   // (regrowing a buffer waits for the whole device: rarely)
+    h->capChunks = std::max<uint64_t>(h->capChunks, chunks);
     {
         const uint64_t N = h->capN, R = h->capRows, A = h->capArena, Cn = h->capChunks;
         if ((r = E.dECg.reserve(N)) || (r = E.dEOut.reserve(N)) || (r = E.dEWhich.reserve(N)) || (r = E.dEM.reserve(R)) ||
@@ -1125,7 +1176,9 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
             (r = E.dEPack.reserve((size_t) N * SWSEM_NSTREAMS)))
             return r;
     }
+    HT("reserved");
     if ((r = upload(h, E.dEOwner.p, E.chunkOwner.data(), chunks * sizeof(uint32_t), h->stream))) return r;
+    HT("owner uploaded");
     if ((r = upload(h, E.dECg.p, E.ecg.data(), n * sizeof(EmitContig), h->stream)) || (r = upload(h, E.dEWhich.p, which.data(), n * sizeof(int), h->stream))) return r;
     E.eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
     if ((r = upload(h, E.dELoaded.p, E.eloaded.data(), nLoaded * sizeof(uint64_t), h->stream))) return r;
@@ -1142,6 +1195,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     v.chunkOwner = E.dEOwner.p;
     v.ncontigs = (uint32_t) n;
     const dim3 grid2(chunks);
+    HT("p1 launch");
     h->mark(SWSEM_K_EMIT, true);
     k_emit_p1_flags<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
     k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
@@ -1164,6 +1218,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (hipHostMalloc((void **) &E.pinE, want, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
         E.pinECap = want;
     }
+    HT("phase2 launch");
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
     h->mark(SWSEM_K_EMIT2, true, h->stream2);
     k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p);
@@ -1188,6 +1243,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     // bookkeeping accordingly; when the prediction fails nothing on the device has changed.
     struct { int64_t pos1; int laps; uint64_t samplingPos, swEnd; uint32_t epoch; bool pristine; std::deque<uint64_t> locks; } snap;
     bool queued = false;
+    HT("spec begin");
     if (spec && spec->ntargets > 0) {
         snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch;
         snap.pristine = h->pristine; snap.locks = h->locks;
@@ -1204,7 +1260,9 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch;
                        h->pristine = snap.pristine; h->locks = snap.locks; }
     }
+    HT("spec queued, waiting");
     HIPCHK(hipEventSynchronize(h->evP1));                           // pass 1 and its copies to the host (not what was queued after them)
+    HT("evP1 done");
     if (needCounts) take_counts(h);
     E.eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
     if (queued) {
