@@ -55,7 +55,7 @@ struct EmitView {
     // scratch (rows indexed by EmitContig::scratchBase + t)
     EMatch *em;                                      // compacted matches
     uint64_t *next0;                                 // upper_bound(loaded, lp)
-    uint8_t *tflag, *removed;
+    uint8_t *removed;
     uint32_t *keepIdx;
     uint32_t *meta;                                  // per kept match, see META_*
     uint32_t *corr;                                  // gapStartIdx when in a gap
@@ -129,20 +129,11 @@ __device__ uint32_t block_scan(uint32_t x, uint32_t *lds, uint32_t *total) {
 constexpr int CH = 256;
 
 // (a) the locally computable part of the removal test (:176-178), taking j-1 as the kept predecessor
-__global__ void __launch_bounds__(CH) k_emit_p1_flags(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
-    const uint32_t gk = v.chunkOwner[blockIdx.x];
-    const EmitContig cg = cgs[gk];
-    const uint32_t gx = blockIdx.x - cg.chunk0;
-    const int64_t n = v.matchCount[which[gk]];
-    const int64_t j = (int64_t) gx * CH + threadIdx.x;
-    if (j >= n) return;
-    const Match *M = v.matches + cg.matchBase;
-    bool t = false;
-    if (v.p.enableExtensionsWithMismatches && j >= 1 && j + 1 < n)
-        t = paired(M[j + 1].posSrc, M[j + 1].posDest, M[j - 1].posSrc, M[j - 1].posDest) &&
-            !paired(M[j].posSrc, M[j].posDest, M[j - 1].posSrc, M[j - 1].posDest) &&
-            M[j].len < v.p.gapBreakingMatchMinLength;
-    v.tflag[cg.scratchBase + j] = t;
+__device__ __forceinline__ bool p1_flag(const EmitView &v, const Match *__restrict__ M, int64_t n, int64_t j) {
+    if (!v.p.enableExtensionsWithMismatches || j < 1 || j + 1 >= n) return false;
+    const Match a = M[j - 1], b = M[j], c = M[j + 1];
+    return paired(c.posSrc, c.posDest, a.posSrc, a.posDest) && !paired(b.posSrc, b.posDest, a.posSrc, a.posDest) &&
+           b.len < v.p.gapBreakingMatchMinLength;
 }
 
 // (b) a removed match keeps its successor (the successor is then paired with the kept predecessor), so
@@ -154,16 +145,17 @@ __global__ void __launch_bounds__(CH) k_emit_p1_removed(EmitView v, const EmitCo
     const EmitContig cg = cgs[gk];
     const uint32_t gx = blockIdx.x - cg.chunk0;
     const int64_t n = v.matchCount[which[gk]];
+    if ((int64_t) gx * CH >= n) { if (threadIdx.x == 0) v.chunkCnt[(size_t) blockIdx.x] = 0; return; }
     const int64_t j = (int64_t) gx * CH + threadIdx.x;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    const uint8_t *tf = v.tflag + cg.scratchBase;
+    const Match *M = v.matches + cg.matchBase;
     bool keep = false;
     if (j < n) {
         bool r = false;
-        if (tf[j]) {
+        if (p1_flag(v, M, n, j)) {
             int64_t k = 0;
-            while (j - 1 - k >= 0 && tf[j - 1 - k]) k++;
+            while (j - 1 - k >= 0 && p1_flag(v, M, n, j - 1 - k)) k++;
             r = (k & 1) == 0;
         }
         v.removed[cg.scratchBase + j] = r;
@@ -235,12 +227,15 @@ __global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitCo
     }
 }
 
-// (e) unmatchedChars / totalMatched with the reference's integer types (uint32 pos, :145,:193-196)
+// (e) unmatchedChars / totalMatched with the reference's integer types (uint32 pos, :145,:193-196): per-chunk
+// partial sums (two u64 at the chunk's slot of chunkCnt, whose kept-match offsets compaction has consumed) ...
 __global__ void __launch_bounds__(CH) k_emit_p1_sums(EmitView v, const EmitContig *__restrict__ cgs) {
+    __shared__ unsigned long long part[2 * (CH / WAVE)];
     const uint32_t gk = v.chunkOwner[blockIdx.x];
     const EmitContig cg = cgs[gk];
     const uint32_t gx = blockIdx.x - cg.chunk0;
     const uint32_t nk = (uint32_t) v.out[gk].nmatches;
+    if (gx * CH >= nk) return;
     const uint32_t t = gx * CH + threadIdx.x;
     const EMatch *E = v.em + cg.scratchBase;
     unsigned long long um = 0, tm = 0;
@@ -253,23 +248,43 @@ __global__ void __launch_bounds__(CH) k_emit_p1_sums(EmitView v, const EmitConti
         um += (unsigned long long) __shfl_down((long long) um, d);
         tm += (unsigned long long) __shfl_down((long long) tm, d);
     }
-    if ((threadIdx.x & (WAVE - 1)) == 0 && (um | tm)) {
-        atomicAdd((unsigned long long *) &v.out[gk].unmatchedChars, um);
-        atomicAdd((unsigned long long *) &v.out[gk].totalMatched, tm);
+    if ((threadIdx.x & (WAVE - 1)) == 0) { part[2 * (threadIdx.x / WAVE)] = um; part[2 * (threadIdx.x / WAVE) + 1] = tm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int w = 0; w < CH / WAVE; w++) { a += part[2 * w]; b += part[2 * w + 1]; }
+        unsigned long long *o = (unsigned long long *) (v.chunkCnt + (size_t) blockIdx.x * 6);
+        o[0] = a; o[1] = b;
     }
 }
 
-// (f) tail literal + the dissimilarity early-out (:200-205, isContigDissimilar MGMP_Params.h:193-196)
-__global__ void k_emit_p1_finish(EmitView v, const EmitContig *__restrict__ cgs) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= (int) v.ncontigs) return;
+// (f) ... summed per contig (one block each), the tail literal and the dissimilarity early-out (:200-205,
+// isContigDissimilar MGMP_Params.h:193-196)
+__global__ void __launch_bounds__(CH) k_emit_p1_finish(EmitView v, const EmitContig *__restrict__ cgs) {
+    __shared__ unsigned long long part[2 * (CH / WAVE)];
+    const int k = blockIdx.x;
     const EmitContig cg = cgs[k];
     EmitOut *o = v.out + k;
     const uint32_t nk = (uint32_t) o->nmatches;
+    const uint32_t nch = (nk + CH - 1) / CH;
+    unsigned long long um = 0, tm = 0;
+    for (uint32_t c = threadIdx.x; c < nch; c += CH) {
+        const unsigned long long *p = (const unsigned long long *) (v.chunkCnt + ((size_t) cg.chunk0 + c) * 6);
+        um += p[0]; tm += p[1];
+    }
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        um += (unsigned long long) __shfl_down((long long) um, d);
+        tm += (unsigned long long) __shfl_down((long long) tm, d);
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) { part[2 * (threadIdx.x / WAVE)] = um; part[2 * (threadIdx.x / WAVE) + 1] = tm; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    um = 0; tm = 0;
+    for (int w = 0; w < CH / WAVE; w++) { um += part[2 * w]; tm += part[2 * w + 1]; }
     const EMatch *E = v.em + cg.scratchBase;
     const uint32_t pos = nk ? (uint32_t) (E[nk - 1].posDest + E[nk - 1].len) : 0u;
-    const int64_t unmatched = (int64_t) (o->unmatchedChars + (cg.n - (uint64_t) pos));
-    o->totalMatched = (uint32_t) o->totalMatched;
+    const int64_t unmatched = (int64_t) (um + (cg.n - (uint64_t) pos));
+    o->totalMatched = (uint32_t) tm;
     o->unmatchedChars = (uint64_t) unmatched;
     if (cg.processed < cg.targetIdx - v.p.allowedTargetsOutrunForDissimilarContigs &&
         cg.n > v.p.minimalLengthForDissimilarContigs &&
@@ -785,6 +800,7 @@ __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig
     const EmitOut o = v.out[gk];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
+    if ((int64_t) gx * 256 > n) return;
     const int64_t t = (int64_t) gx * 256 + threadIdx.x;
     uint32_t cloc[2] = {0, 0};
     if (t <= n) {
@@ -796,9 +812,17 @@ __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig
         cloc[0] += (uint32_t) __shfl_down((int) cloc[0], d);
         cloc[1] += (uint32_t) __shfl_down((int) cloc[1], d);
     }
-    if ((threadIdx.x & (WAVE - 1)) == 0 && (cloc[0] | cloc[1])) {
-        atomicAdd((unsigned long long *) &v.out[gk].extMatched, (unsigned long long) cloc[0]);
-        atomicAdd((unsigned long long *) &v.out[gk].extMismatches, (unsigned long long) cloc[1]);
+    // one pair of atomics per block: every block of a contig adds to the same two words
+    __shared__ uint32_t part[2 * (256 / WAVE)];
+    if ((threadIdx.x & (WAVE - 1)) == 0) { part[2 * (threadIdx.x / WAVE)] = cloc[0]; part[2 * (threadIdx.x / WAVE) + 1] = cloc[1]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int w = 0; w < 256 / WAVE; w++) { a += part[2 * w]; b += part[2 * w + 1]; }
+        if (a | b) {
+            atomicAdd((unsigned long long *) &v.out[gk].extMatched, a);
+            atomicAdd((unsigned long long *) &v.out[gk].extMismatches, b);
+        }
     }
 }
 

@@ -66,6 +66,22 @@ __global__ void __launch_bounds__(256) k_upload(uint8_t *__restrict__ dst, const
     } else
         for (uint64_t k = o; k < n; k++) dst[k] = src[k];
 }
+// several such copies in one launch (every launch costs the stream 5-10 us however small): block b serves the
+// segment whose block range holds it; a segment without a source is zero-filled
+struct CopySegs { static constexpr int MAX = 8; uint8_t *dst[MAX]; const uint8_t *src[MAX]; uint64_t bytes[MAX]; uint32_t first[MAX + 1]; int n; };
+__global__ void __launch_bounds__(256) k_copy_segs(CopySegs sg) {
+    int k = 0;
+    while (k + 1 < sg.n && blockIdx.x >= sg.first[k + 1]) k++;
+    const uint64_t o = 16 * ((uint64_t) (blockIdx.x - sg.first[k]) * 256 + threadIdx.x), n = sg.bytes[k];
+    uint8_t *dst = sg.dst[k];
+    const uint8_t *src = sg.src[k];
+    if (o + 16 <= n) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (src) memcpy(&t, src + o, 16);
+        memcpy(dst + o, &t, 16);
+    } else
+        for (uint64_t i = o; i < n; i++) dst[i] = src ? src[i] : (uint8_t) 0;
+}
 __global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restrict__ b, int n, const uint32_t *__restrict__ gate) {
     if (gate && *gate == 0) return;
     for (int i = 0; i < n; i++) ref[b[i].off] = (uint8_t) b[i].val;

@@ -131,7 +131,7 @@ struct swsem {
         DevBuf<uint32_t> dEOwner;
         DevBuf<EMatch> dEM;
         DevBuf<uint64_t> dENext0, dELoaded, dEPack;
-        DevBuf<uint8_t> dETf, dERm, dEArena;
+        DevBuf<uint8_t> dERm, dEArena;
         DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs, dEChunk;
         DevBuf<MetaState> dEStates;
         DevBuf<unsigned long long> dEStat;
@@ -151,7 +151,7 @@ struct swsem {
         uint64_t packedBytes = 0;
         void release() {
             dECg.release(); dEOut.release(); dEWhich.release(); dEOwner.release(); dEM.release(); dENext0.release(); dELoaded.release();
-            dEPack.release(); dETf.release(); dERm.release(); dEArena.release(); dEKeep.release(); dEMeta.release(); dECorr.release();
+            dEPack.release(); dERm.release(); dEArena.release(); dEKeep.release(); dEMeta.release(); dECorr.release();
             dESz.release(); dEOfs.release(); dEChunk.release(); dEStates.release(); dEStat.release();
             if (pinE) { (void) hipHostFree(pinE); pinE = nullptr; pinECap = 0; }
             if (evDone) { (void) hipEventDestroy(evDone); evDone = nullptr; }
@@ -191,6 +191,8 @@ struct swsem {
     double profMs[SWSEM_K_COUNT] = {0};
     uint64_t profN[SWSEM_K_COUNT] = {0};
 
+    CopySegs segs;                         // small copies staged for one launch (stage_copy / flush_copies)
+    hipStream_t segStream = nullptr;
     uint32_t *bloom = nullptr;             // presence bits in front of the table (swsem_device.h: bloom_has); an experiment, off by default
     uint32_t bloomMask = 0;
 
@@ -420,19 +422,39 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     return SWSEM_OK;
 }
 
-// small device results -> pinned (mapped) host memory, by a kernel on `st`; visible to the host once an event recorded
-// behind it has completed
-void download(swsem *h, void *dstPinned, const void *srcDev, size_t bytes, hipStream_t st) {
-    (void) h;
-    if (!bytes) return;
-    k_upload<<<dim3((unsigned) ((bytes + 4095) / 4096)), dim3(256), 0, st>>>((uint8_t *) dstPinned, (const uint8_t *) srcDev, bytes);
+// Small copies between host and device go through pinned host memory that is mapped into the device's address
+// space and are made by a kernel (the runtime's own small copies can block the calling thread for milliseconds on a
+// side stream, and switch engines in the middle of the main one). They are staged and leave in one launch per
+// flush_copies(): up to CopySegs::MAX segments, zero-fills among them.
+int flush_copies(swsem *h) {
+    CopySegs &sg = h->segs;
+    if (sg.n == 0) return SWSEM_OK;
+    const uint32_t blocks = sg.first[sg.n];
+    k_copy_segs<<<dim3(blocks), dim3(256), 0, h->segStream>>>(sg);
+    sg.n = 0;
+    HIPCHK(hipGetLastError());
+    return SWSEM_OK;
 }
+int stage_copy(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (!bytes) return SWSEM_OK;
+    CopySegs &sg = h->segs;
+    if (sg.n && (h->segStream != st || sg.n == CopySegs::MAX)) { int r = flush_copies(h); if (r) return r; }
+    if (sg.n == 0) { h->segStream = st; sg.first[0] = 0; }
+    sg.dst[sg.n] = (uint8_t *) dst; sg.src[sg.n] = (const uint8_t *) src; sg.bytes[sg.n] = bytes;
+    sg.first[sg.n + 1] = sg.first[sg.n] + (uint32_t) ((bytes + 4095) / 4096);
+    sg.n++;
+    return SWSEM_OK;
+}
+// device results -> pinned host memory; visible to the host once an event recorded behind the flush has completed
+int download(swsem *h, void *dstPinned, const void *srcDev, size_t bytes, hipStream_t st) { return stage_copy(h, dstPinned, srcDev, bytes, st); }
+int zero_dev(swsem *h, void *dst, size_t bytes, hipStream_t st) { return stage_copy(h, dst, nullptr, bytes, st); }
 
-// copies `bytes` of host data to the device through the pinned ring, asynchronously on `st`
+// host data -> device through the pinned ring (staged: flush_copies() launches)
 int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
     if (!bytes) return SWSEM_OK;
     const size_t need = (bytes + 255) & ~(size_t) 255;
     if (need * 4 > h->ringCap) {                       // (re)allocation: rare, and the only place that waits
+        { int r = flush_copies(h); if (r) return r; }
         HIPCHK(hipDeviceSynchronize());
         if (h->ring) HIPCHK(hipHostFree(h->ring));
         h->ring = nullptr; h->ringCap = 0; h->ringAt = 0;
@@ -441,6 +463,7 @@ int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
         h->ringCap = want;
     }
     if (h->ringAt + need > h->ringCap) {               // wrap: everything staged a lap ago has long been copied, but make sure
+        { int r = flush_copies(h); if (r) return r; }
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipStreamSynchronize(h->stream2));
         HIPCHK(hipStreamSynchronize(h->stream3));
@@ -449,10 +472,7 @@ int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
     uint8_t *slot = h->ring + h->ringAt;
     h->ringAt += need;
     memcpy(slot, src, bytes);
-    // pinned host memory is mapped into the device's address space: a kernel does the copy
-    k_upload<<<dim3((unsigned) ((bytes + 4095) / 4096)), dim3(256), 0, st>>>((uint8_t *) dst, slot, bytes);
-    HIPCHK(hipGetLastError());
-    return SWSEM_OK;
+    return stage_copy(h, dst, slot, bytes, st);
 }
 
 // K-mer hashes of a future batch, beside whatever the main stream is doing (the hashes depend on the query only)
@@ -486,7 +506,7 @@ int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n
     // but say so to the third stream
     if (h->matchedRecorded >= 2) HIPCHK(hipStreamWaitEvent(hs, h->evMatchedPrev, 0));
     if ((r = upload(h, h->dPrepContigs.p, h->prepContigs.data(), n * sizeof(Contig), hs)) ||
-        (r = upload(h, h->dPrepTileContig.p, h->prepTileContig.data(), tiles * sizeof(uint32_t), hs)))
+        (r = upload(h, h->dPrepTileContig.p, h->prepTileContig.data(), tiles * sizeof(uint32_t), hs)) || (r = flush_copies(h)))
         return r;
     const RefView v = h->view();
     h->mark(SWSEM_K_PROBE, true, hs);
@@ -562,7 +582,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
             (r = upload(h, h->dRbContig.p, rbContig.data(), rblocks * sizeof(uint32_t), h->stream)))
             return r;
     }
-    HIPCHK(hipMemsetAsync(h->dStats.p, 0, 8 * sizeof(unsigned long long), h->stream));
+    if ((r = zero_dev(h, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) || (r = flush_copies(h))) return r;
     const RefView v = h->view();
     // hashes announced ahead for exactly these buffers: adopt them
     const bool adopted = h->prepValid && h->lazyProbe && h->prepQ == qdev && h->prepOffsets.size() == (size_t) n + 1 &&
@@ -639,10 +659,11 @@ int queue_counts(swsem *h, size_t extraBytes) {
     const size_t countsAt = 64, extraAt = (countsAt + n * sizeof(uint32_t) + 63) & ~(size_t) 63;
     int r = pin_reserve(h, extraAt + extraBytes);
     if (r) return r;
-    download(h, h->pin, h->dStats.p, 8 * sizeof(unsigned long long), h->stream);
-    download(h, h->pin + countsAt, h->dMatchCount.p, n * sizeof(uint32_t), h->stream);
+    if ((r = download(h, h->pin, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) ||
+        (r = download(h, h->pin + countsAt, h->dMatchCount.p, n * sizeof(uint32_t), h->stream)))
+        return r;
     h->pinExtraAt = extraAt;
-    return SWSEM_OK;
+    return SWSEM_OK;                                   // (staged: the caller adds what it wants beside them and flushes)
 }
 
 // after the wait: pinned block -> host state
@@ -658,7 +679,7 @@ void take_counts(swsem *h) {
 
 int fetch_counts(swsem *h) {
     int r = queue_counts(h, 0);
-    if (r) return r;
+    if (r || (r = flush_copies(h))) return r;
     HIPCHK(hipStreamSynchronize(h->stream));
     take_counts(h);
     return SWSEM_OK;
@@ -1169,7 +1190,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     {
         const uint64_t N = h->capN, R = h->capRows, A = h->capArena, Cn = h->capChunks;
         if ((r = E.dECg.reserve(N)) || (r = E.dEOut.reserve(N)) || (r = E.dEWhich.reserve(N)) || (r = E.dEM.reserve(R)) ||
-            (r = E.dENext0.reserve(R)) || (r = E.dETf.reserve(R)) || (r = E.dERm.reserve(R)) ||
+            (r = E.dENext0.reserve(R)) || (r = E.dERm.reserve(R)) ||
             (r = E.dEKeep.reserve(R)) || (r = E.dEMeta.reserve(R)) || (r = E.dECorr.reserve(R)) ||
             (r = E.dESz.reserve(R * 6)) || (r = E.dEOfs.reserve(R * 6)) || (r = E.dEArena.reserve(A)) || (r = E.dELoaded.reserve(h->capLoaded)) ||
             (r = E.dEStat.reserve(8)) || (r = E.dEOwner.reserve(Cn)) || (r = E.dEStates.reserve((size_t) Cn * 2)) || (r = E.dEChunk.reserve((size_t) Cn * 6)) ||
@@ -1182,12 +1203,17 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     if ((r = upload(h, E.dECg.p, E.ecg.data(), n * sizeof(EmitContig), h->stream)) || (r = upload(h, E.dEWhich.p, which.data(), n * sizeof(int), h->stream))) return r;
     E.eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
     if ((r = upload(h, E.dELoaded.p, E.eloaded.data(), nLoaded * sizeof(uint64_t), h->stream))) return r;
+    if (spec && spec->ntargets > 0) {                                // the prediction k_spec_verify checks pass 1 against
+        if ((r = h->dGate.reserve(4)) || (r = h->dPred.reserve(2 * (size_t) n + 64))) return r;
+        if ((r = upload(h, h->dPred.p, spec->predExt, n, h->stream)) || (r = upload(h, h->dPred.p + n, spec->predRC, n, h->stream))) return r;
+    }
+    if ((r = flush_copies(h))) return r;
     // no synchronisation here: the kernels below queue up behind match-finding while it is still running
     EmitView v;
     v.ref = h->ref; v.qbuf = h->qdev; v.matches = h->dMatches.p; v.matchCount = h->dMatchCount.p;
     v.pos1 = (uint64_t) h->pos1; v.refLength = h->refLength(); v.maxRefLength = h->maxRefLength;
     v.loaded = E.dELoaded.p; v.nLoaded = (uint32_t) nLoaded; v.p = *p;
-    v.em = E.dEM.p; v.next0 = E.dENext0.p; v.tflag = E.dETf.p; v.removed = E.dERm.p; v.keepIdx = E.dEKeep.p;
+    v.em = E.dEM.p; v.next0 = E.dENext0.p; v.removed = E.dERm.p; v.keepIdx = E.dEKeep.p;
     v.meta = E.dEMeta.p; v.corr = E.dECorr.p; v.sz = E.dESz.p; v.arena = E.dEArena.p; v.out = E.dEOut.p;
     v.packBase = E.dEPack.p;
     v.ofs = E.dEOfs.p;
@@ -1197,18 +1223,17 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     const dim3 grid2(chunks);
     HT("p1 launch");
     h->mark(SWSEM_K_EMIT, true);
-    k_emit_p1_flags<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
     k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
     k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
     k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
     k_emit_p1_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p);
-    k_emit_p1_finish<<<dim3((n + 63) / 64), dim3(64), 0, h->stream>>>(v, E.dECg.p);
+    k_emit_p1_finish<<<dim3(n), dim3(CH), 0, h->stream>>>(v, E.dECg.p);
     h->mark(SWSEM_K_EMIT, false);
     HIPCHK(hipGetLastError());
     // pass-1 results (unmatchedChars, the dissimilarity verdict), match counts and statistics: one pinned block, one wait
     const bool needCounts = h->matchCount.size() != h->contigs.size();
     if ((r = queue_counts(h, n * sizeof(EmitOut)))) return r;
-    download(h, h->pin + h->pinExtraAt, E.dEOut.p, n * sizeof(EmitOut), h->stream);
+    if ((r = download(h, h->pin + h->pinExtraAt, E.dEOut.p, n * sizeof(EmitOut), h->stream)) || (r = flush_copies(h))) return r;
     HIPCHK(hipEventRecord(h->evP1, h->stream));
     // the rest runs on the second stream behind pass 1
     if (E.pinECap < n * sizeof(EmitOut)) {
@@ -1231,7 +1256,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
-    download(h, E.pinE, E.dEOut.p, n * sizeof(EmitOut), h->stream2);
+    if ((r = download(h, E.pinE, E.dEOut.p, n * sizeof(EmitOut), h->stream2)) || (r = flush_copies(h))) return r;
     HIPCHK(hipEventRecord(E.evDone, h->stream2));
     h->latest = si; h->selected = -1;
     E.outstanding = true; E.refGuarded = false; E.emitN = n; E.emitPos1 = (uint64_t) h->pos1;
@@ -1247,8 +1272,6 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     if (spec && spec->ntargets > 0) {
         snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch;
         snap.pristine = h->pristine; snap.locks = h->locks;
-        if ((r = h->dGate.reserve(4)) || (r = h->dPred.reserve(2 * (size_t) n + 64))) return r;
-        if ((r = upload(h, h->dPred.p, spec->predExt, n, h->stream)) || (r = upload(h, h->dPred.p + n, spec->predRC, n, h->stream))) return r;
         k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, h->dGate.p);
         h->specMode = true;
         r = finalize_impl(h, spec->ntargets, spec->ext_dev, spec->ext_len, spec->addSep, spec->sep, spec->lazySeparator, spec->lockPos,
