@@ -855,13 +855,45 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
         if (scanT >= w0 + span) { prevPlain = false; continue; }  // the sequential loop jumped over this block
         const int fl = (int) (b & (WAVE - 1));
         const int32_t fPop = (int32_t) rl32(fr.w, fl);
-        if (prevPlain && fPop >= 0) {                           // accepted as speculated: only the list bookkeeping is left
-            const int32_t fMinKeep = (int32_t) rl32(fr.y, fl), fPush = (int32_t) rl32(fr.z, fl);
-            if (fPop > 0) vs.pop_segments(fPop);
-            vs.size_ -= fPop;
-            vs.push_segment((int) b, (uint32_t) fMinKeep, (uint32_t) fPush);
-            scanT = (int32_t) rl32(fr.x, fl);
+        if (prevPlain && fPop >= 0) {
+            // Accepted as speculated, and so is every block after it whose quick test passed, up to the end of this
+            // batch of 64 records: only the list bookkeeping is left, and for such a run it is done by all lanes at
+            // once (one block each) instead of block after block. A block of the run removes rows only from the
+            // segment of the block right before it (k_stitch_pre: popB <= the predecessor's pushes), and a block
+            // that pushes nothing removes nothing, so the rows a segment keeps are its pushes minus the next
+            // block's pops, and its predecessor in the list is the nearest earlier block that pushed anything.
+            const unsigned long long fastMask = __ballot((int32_t) fr.w >= 0);
+            const unsigned long long rest = ~(fastMask >> fl);
+            const int L = rest ? __builtin_ctzll(rest) : WAVE - fl;                  // blocks b .. b + L - 1 (>= 1)
+            const bool inRun = (int) lane >= fl && (int) lane < fl + L;
+            const int32_t myPop = inRun ? (int32_t) fr.w : 0, myPush = inRun ? (int32_t) fr.z : 0;
+            int32_t nextPop = __shfl_down(myPop, 1);
+            if ((int) lane + 1 >= fl + L) nextPop = 0;
+            if (fPop > 0) vs.pop_segments(fPop);                                       // the first block's pops hit the list as it stands
+            const unsigned long long segMask = __ballot(inRun && myPush > 0);
+            int32_t delta = myPush - myPop;
+            for (int d = WAVE / 2; d > 0; d >>= 1) delta += __shfl_xor(delta, d);
+            vs.size_ += delta;
+            if (segMask) {
+                if (lane == 0 && vs.segTop >= 0) vs.keepN[vs.segTop] = (uint32_t) vs.topKeep;
+                const int32_t b0 = (int32_t) b - fl;                                  // block of lane 0
+                const unsigned long long below = segMask & ((1ull << lane) - 1ull);
+                const int32_t pv = below ? b0 + (63 - __builtin_clzll(below)) : vs.segTop;
+                const int32_t keepMine = myPush - nextPop;
+                if (inRun && myPush > 0) {
+                    vs.segStart[b0 + (int32_t) lane] = (uint32_t) fr.y;
+                    vs.prev[b0 + (int32_t) lane] = pv;
+                    vs.keepN[b0 + (int32_t) lane] = (uint32_t) keepMine;
+                }
+                const int top = 63 - __builtin_clzll(segMask);
+                vs.segTop = b0 + top;
+                vs.topKeep = (int32_t) rl32((uint32_t) keepMine, top);
+                vs.topPrev = (int32_t) rl32((uint32_t) pv, top);
+                vs.curSeg = -1;
+            }
+            scanT = (int32_t) rl32(fr.x, fl + L - 1);
             known = 0;                                          // the newest-rows window is rebuilt from the list if ever needed
+            b += (uint32_t) (L - 1);
             continue;
         }
         {                                                       // the complete test needs the whole record
