@@ -48,6 +48,7 @@ struct RefView {
     uint32_t minLen;
     const uint32_t *bloom;    // presence bits of the hashes ever inserted (nullptr: not usable, see bloom_has)
     uint32_t bloomMask;
+    int flyHash;              // scan windows hash their K-mers themselves (no hash array)
 };
 
 // little-endian loads at arbitrary byte addresses. gfx950 under HSA runs global memory in unaligned

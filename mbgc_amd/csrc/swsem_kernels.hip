@@ -249,7 +249,10 @@ constexpr int RING = 64;
 __device__ __forceinline__ uint32_t rl32(uint32_t x, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) x, lane); }
 __device__ __forceinline__ uint32_t rfl32(uint32_t x) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) x); }
 __device__ __forceinline__ uint64_t rfl64(uint64_t x) { return ((uint64_t) rfl32((uint32_t) (x >> 32)) << 32) | rfl32((uint32_t) x); }
-constexpr int OVERLAP = 1024;          // warm-up positions of a speculative block chain (<= TILE)
+#ifndef SWSEM_OVERLAP
+#define SWSEM_OVERLAP 1024
+#endif
+constexpr int OVERLAP = SWSEM_OVERLAP;          // warm-up positions of a speculative block chain (<= TILE)
 constexpr int SNAP = 4;                // stack elements snapshotted at a block boundary / end
 
 // A row of a block chain's stack: the match plus the scan position the chain had right after emitting it.
@@ -584,6 +587,29 @@ constexpr int WL = SWSEM_WL;
 #ifndef SWSEM_RESOLVE_SGPRS
 #define SWSEM_RESOLVE_SGPRS 72
 #endif
+// K-mer hashes of the scan window [s, s + cnt) (cnt <= WL), one position per lane, from the query bytes: the
+// window's bytes are loaded once as aligned dwords (one per lane), every lane picks the nine it needs with
+// ds_bpermute and shifts them into place. The chains wait on memory most of the time, so the multiplications
+// are free there, while a hash array written ahead by its own kernel costs that kernel (0.27 ms per round of
+// 80 M positions, at the multiplier's quarter rate) and 4 bytes of HBM traffic per position each way.
+__device__ __forceinline__ uint32_t window_hash(const RefView &v, const uint8_t *q, int32_t s, int32_t cnt, int32_t lane) {
+    const uintptr_t A = (uintptr_t) (q + s);
+    const uint32_t sh = (uint32_t) (A & 3);
+    const uint32_t *A0 = (const uint32_t *) (A & ~(uintptr_t) 3);
+    const uint32_t ndw = (sh + (uint32_t) cnt + (uint32_t) v.K - 1u + 3u) >> 2;     // <= 64 (swsem_create checks K)
+    const uint32_t a = (uint32_t) lane < ndw ? A0[lane] : 0u;
+    const uint32_t o = sh + (uint32_t) lane, wi = o >> 2, sft = o & 3u;
+    const int nw = v.K / 4;
+    uint32_t h = (uint32_t) v.K;
+    uint32_t lo = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (wi << 2), (int) a);
+    for (int x = 0; x < nw; x++) {
+        const uint32_t hi = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((wi + (uint32_t) x + 1u) << 2), (int) a);
+        h = hash_step(h, __builtin_amdgcn_alignbyte(hi, lo, sft), (uint32_t) x);
+        lo = hi;
+    }
+    return h;
+}
+
 template <class Stack, class Stop = NoStop>
 __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ hashes,
                                int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
@@ -610,8 +636,10 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
             wb = s;
             const int32_t pos = s + lane;
             uint32_t e = 0;
+            uint32_t hf = 0;
+            if (v.flyHash) hf = window_hash(v, q, s, p1 - s < WL ? p1 - s : WL, lane);
             if (lane < WL && pos < p1) {
-                const uint32_t hv = hashes[pos];
+                const uint32_t hv = v.flyHash ? hf : hashes[pos];
                 if (!v.bloom || bloom_has(v, hv)) e = ht_value(v, v.ht[hv & v.mask], hv);
                 if (e != 0) {
                     uint64_t lo, hi;

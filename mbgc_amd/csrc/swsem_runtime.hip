@@ -86,6 +86,8 @@ struct swsem {
     uint32_t epoch = 1;
     bool pristine = true;                  // no byte of the buffer has been rewritten after it was hashed (no wrap yet)
     int fpBits = 0;                        // fingerprint bits of a table entry: what the bucket index leaves of the 32-bit hash, at most 8
+    uint64_t hostProbes = 0;               // query positions of the batch (what the hash kernel counts when there is one)
+    bool flyHash = true;                   // lazy chains hash their scan windows themselves (SWSEM_HASH=pre: a hash array written ahead)
     bool lazyProbe = true;                 // chains gather the hash table on demand (SWSEM_PROBE=lazy) instead of a dense probe pass
     bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
     bool specMode = false;                 // a speculative finalize is being queued: nothing may be written outside its gated launches
@@ -202,6 +204,7 @@ struct swsem {
         v.ref = ref; v.ht = ht; v.pos1 = (uint64_t) pos1; v.refLength = refLength(); v.maxRefLength = maxRefLength;
         v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? 1 : 0; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
         v.bloom = (v.fpCheck && bloom) ? bloom : nullptr; v.bloomMask = bloomMask;
+        v.flyHash = (flyHash && lazyProbe) ? 1 : 0;
         return v;
     }
     // event pairs are recycled: creating events by the hundred makes the runtime grow its signal pool now and
@@ -480,7 +483,7 @@ int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n
     HT("prepare_hashes enter");
     h->prepValid = false;
     hipStream_t hs = h->stream3;
-    if (n <= 0 || !h->lazyProbe) return SWSEM_OK;
+    if (n <= 0 || !h->lazyProbe || h->flyHash) return SWSEM_OK;   // (nothing to prepare: the chains hash their own windows)
     (void) hipStreamQuery(hs);             // lets the runtime retire what this stream has completed (it is never waited on by the host)
     h->prepContigs.assign(n, Contig());
     h->prepTileContig.clear();
@@ -531,7 +534,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     h->contigs.assign(n, Contig());
     std::vector<uint32_t> &tileContig = h->tileContigHost, &rbContig = h->rbContigHost;   // uploaded asynchronously
     tileContig.clear(); rbContig.clear();
-    uint64_t matchRows = 0, bases = 0;
+    uint64_t matchRows = 0, bases = 0, probes = 0;
     uint32_t tiles = 0, rblocks = 0;
     {
         // Block chains are latency-bound and a launch lasts as long as its slowest wave: the blocks are sized so
@@ -554,6 +557,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if (cg.n >= (1ull << 31) - (1ull << 20)) return fail(SWSEM_EINVAL, "contig %d longer than 2^31 - 2^20 bytes", c);
         cg.lock = lockPos ? lockPos[c] : UINT64_MAX;
         const uint64_t npos = cg.n >= (uint64_t) h->K ? cg.n - h->K + 1 : 0;
+        probes += npos;
         cg.tile0 = tiles;
         cg.ntiles = (uint32_t) ((npos + TILE - 1) / TILE);
         cg.candBase = (uint64_t) tiles * TILE;
@@ -573,7 +577,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if ((r = h->dMatchCount.reserve(n))) return r;
     if ((r = h->dStats.reserve(8))) return r;
     if ((r = h->dTileContig.reserve(std::max<uint32_t>(tiles, 1)))) return r;
-    if ((r = h->dCand.reserve((size_t) std::max<uint32_t>(tiles, 1) * TILE))) return r;
+    if (!(h->flyHash && h->lazyProbe) && (r = h->dCand.reserve((size_t) std::max<uint32_t>(tiles, 1) * TILE))) return r;
     if ((r = h->dMatches.reserve(matchRows))) return r;
     if ((r = upload(h, h->dContigs.p, h->contigs.data(), n * sizeof(Contig), h->stream))) return r;
     if ((r = h->dRbContig.reserve(std::max<uint32_t>(rblocks, 1)))) return r;
@@ -591,7 +595,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if (adopted && tiles) {
         std::swap(h->dCand, h->dCandNext);
         HIPCHK(hipStreamWaitEvent(h->stream, h->evHash, 0));
-    } else if (tiles) {
+    } else if (tiles && !v.flyHash) {
         h->mark(SWSEM_K_PROBE, true);
         if (h->lazyProbe) k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
         else k_probe<false><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
@@ -637,6 +641,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if (h->matchedRecorded < 2) h->matchedRecorded++;
     h->qdev = qdev;
     h->stats[0] = bases;
+    h->hostProbes = probes;
     h->batchValid = true;
     return SWSEM_OK;
 }
@@ -671,7 +676,7 @@ void take_counts(swsem *h) {
     const size_t n = h->contigs.size();
     const unsigned long long *st = (const unsigned long long *) h->pin;
     h->matchCount.assign((const uint32_t *) (h->pin + 64), (const uint32_t *) (h->pin + 64) + n);
-    h->stats[1] = st[1]; h->stats[2] = st[2]; h->stats[5] = st[3];
+    h->stats[1] = (h->flyHash && h->lazyProbe) ? h->hostProbes : st[1]; h->stats[2] = st[2]; h->stats[5] = st[3];
     uint64_t tot = 0;
     for (size_t c = 0; c < n; c++) tot += h->matchCount[c];
     h->stats[3] = tot;
@@ -758,6 +763,8 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
         hipEventCreateWithFlags(&h->evMatchedPrev, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
     if (const char *e = getenv("SWSEM_PROBE")) h->lazyProbe = strcmp(e, "dense") != 0;
+    if (const char *e = getenv("SWSEM_HASH")) h->flyHash = strcmp(e, "pre") != 0;
+    if (h->K > 128) h->flyHash = false;                               // (a window's bytes must fit one dword per lane)
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 32u; }
