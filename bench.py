@@ -25,21 +25,25 @@ MAX_REF_LEN = 1_280_000_000          # 128 files -> referenceFactor 128 -> 128 *
 ALG_BYTES_PER_BASE = 5.5             # whole path, per input base
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
 # SURVEY.md §8(d) splits that figure by term; per kernel family (bytes per input base of a launch):
-#   probe   k_probe<true>: the query scan, 1 B
-#   resolve k_resolve_blocks: the table probes the sequential loop performs (0.29 x 4 B), the reference
-#           bytes it compares (0.918 B) and the match rows it writes (24 B x 766 k rows / 80 M bases)
+#   resolve k_resolve_blocks: the query scan (1 B: the scan windows hash their K-mers from the query bytes; with
+#           SWSEM_HASH=pre that byte belongs to the "probe" family, k_probe<true>, instead), the table probes the
+#           sequential loop performs (0.29 x 4 B), the reference bytes it compares (0.918 B) and the match rows it
+#           writes (24 B x 766 k rows / 80 M bases)
 #   load    extension copy, read + write (2 B);  insert  one 4-B table entry per 16 bases
 #   emit    the six streams (0.14 B)
 ALG_BYTES = {"probe": 1.0, "resolve": 4 * 0.29 + 0.918 + 0.23, "stitch": 0.23, "load": 2.0, "insert": 0.25, "emit": 0.14}
+QUERY_SCAN_BYTES = 1.0               # moves to "resolve" when no hash kernel ran
 # HBM bytes per input base each family really moves, from the PMC passes in profiles/r01_pmc_hbm_traffic.json
 # (FETCH_SIZE + WRITE_SIZE of its largest launches = rounds of 16 x 5 Mbp, / 80 M bases)
-TRAFFIC = {"probe": (41035.8 + 313186.5) * 1024 / 80e6, "resolve": (2881920.2 + 57730.2) * 1024 / 80e6,
-           "stitch": (600.2 + 76.5 + 111.7 + 88.1 + 12968.7 + 18353.3) * 1024 / 80e6, "load": (39696.8 + 78735.5) * 1024 / 80e6,
-           "insert": (40359.1 + 156256.9) * 1024 / 80e6,
-           "emit": (9639.8 + 893.6 + 17843.1 + 12633.3 + 24417.4 + 1560.2 + 90062.2 + 21189.8 + 21408.5 + 210015.7 +
-                    844.4 + 1149.9 + 33364.4 + 756.1 + 8890.0 + 17190.2 + 127.9 + 16375.0 + 96054.1) * 1024 / 80e6}
-KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query)", "resolve": "k_resolve_blocks<true>", "stitch": "k_stitch_pre + k_stitch + k_gather",
-             "load": "k_copy_multi", "insert": "k_insert_multi", "emit": "k_emit_* (14 launches)"}
+TRAFFIC = {"probe": (41035.8 + 313186.5) * 1024 / 80e6, "resolve": (2963970.9 + 50785.1) * 1024 / 80e6,
+           "stitch": (891.8 + 114.6 + 124.2 + 116.6 + 13243.2 + 18341.4) * 1024 / 80e6, "load": (39692.8 + 78735.5) * 1024 / 80e6,
+           "insert": (40302.3 + 156256.9) * 1024 / 80e6,
+           "emit": (24414.1 + 8602.6 + 1492.6 + 0.0 + 17843.9 + 33364.6 + 62.0 + 1.0 + 9646.2 + 1149.9 + 25.8 + 13.8 + 12625.5 +
+                    118.3 + 3.2 + 0.8 + 21404.4 + 16375.0 + 62.4 + 65.3 + 21189.8 + 127.9 + 102860.9 + 16637.0 + 136645.7 +
+                    30694.6) * 1024 / 80e6}
+KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query, SWSEM_HASH=pre only)", "resolve": "k_resolve_blocks<true>",
+             "stitch": "k_stitch_pre + k_stitch + k_gather", "load": "k_copy_multi", "insert": "k_insert_multi",
+             "emit": "k_emit_* (13 launches)"}
 
 
 def cpu_baseline(sample_targets, length, emit):
@@ -194,13 +198,16 @@ def main():
     bases_step = R * world * args.length
     value = bases_step * steps / dt / 1e9
     if rank == 0:
-        # the dominant kernel: the families that are a single kernel per launch (emission is 14 small kernels,
+        # the dominant kernel: the families that are a single kernel per launch (emission is 13 small kernels,
         # the second half of which runs beside other work on a second stream and is timed as elapsed time)
         dom = max(("probe", "resolve", "stitch", "insert", "load"), key=lambda k: prof[k][0])
         per_launch_ms = {k: (prof[k][0] / prof[k][1] if prof[k][1] else 0.0) for k in prof}
         dom_ms = per_launch_ms[dom]
         launch_bases = R * args.length                     # bases one launch of a family processes (this rank's round)
-        ach = ALG_BYTES[dom] * launch_bases / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+        alg = dict(ALG_BYTES)
+        if prof["probe"][1] == 0:                          # no hash kernel ran: the chains read the query themselves
+            alg["resolve"] += QUERY_SCAN_BYTES
+        ach = alg[dom] * launch_bases / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         out = {
             "metric": "input Gbases/s (compress hot path, -m1: match-finding + stream emission)" if emit else
                       "input Gbases/s (compress path, SlidingWindowSparseEMMatcher only)",
@@ -216,7 +223,7 @@ def main():
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": round(TRAFFIC[dom] * launch_bases),
                          "traffic_GBs": round(TRAFFIC[dom] * launch_bases / (dom_ms * 1e-3) / 1e9, 1) if dom_ms else 0.0,
-                         "alg_bytes_per_base": round(ALG_BYTES[dom], 3), "avg_launch_ms": round(dom_ms, 4),
+                         "alg_bytes_per_base": round(alg[dom], 3), "avg_launch_ms": round(dom_ms, 4),
                          "whole_step_frac": round(ALG_BYTES_PER_BASE * value / world / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items()},
             "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof}, "dominant_kernel": dom,

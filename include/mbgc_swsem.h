@@ -99,7 +99,8 @@ int swsem_match_batch_dev(swsem_t *h, const uint8_t *queries_dev, const uint64_t
  * batch that will be matched NEXT can be announced while the current one is still being matched; they are
  * computed on a third stream and adopted by the swsem_match_batch_dev call with the same (queries_dev,
  * offsets, n). The buffer must hold its final bytes when announced. Purely an overlap: results are those of
- * swsem_match_batch_dev alone. */
+ * swsem_match_batch_dev alone. By default the match kernel hashes its scan windows itself and this call does
+ * nothing; it computes hash arrays ahead only when the environment sets SWSEM_HASH=pre. */
 int swsem_hash_batch_dev(swsem_t *h, const uint8_t *queries_dev, const uint64_t *offsets, int n);
 int swsem_batch_counts(swsem_t *h, uint64_t *nmatches /* [n] */);
 int swsem_batch_matches(swsem_t *h, int contig, swsem_match_t *out, uint64_t cap);
