@@ -581,12 +581,18 @@ struct NoStop { __device__ __forceinline__ bool operator()() { return false; } }
 #endif
 constexpr int WL = SWSEM_WL;
 // Scalar registers of the block-resolve kernel. A SIMD has 800 of them and a wave is given its count plus ~20,
-// rounded up to 16: the 106 the compiler takes when left alone allow 6 waves per SIMD, 72 allow 8 (measured
-// with a spinning kernel: 6144 and 8192 resident waves chip-wide). The chains are latency-bound, so resident
-// waves are throughput.
+// rounded up to 16: the 106 the compiler takes when left alone allow 6 waves per SIMD, 88 allow 7, 72 allow 8
+// (measured with a spinning kernel: 6144 / 7168 / 8192 resident waves chip-wide). The chains are latency-bound,
+// so resident waves are throughput — but every register taken away is a spill to a vector lane in the
+// automaton's inner loop (124 at 72, the launch 1.12 ms; at 88: 1.07 ms), and a round's blocks are sized to the
+// slots there are (run_batch), so 7 per SIMD it is. RESOLVE_WAVES_PER_SIMD must say what this cap allows.
 #ifndef SWSEM_RESOLVE_SGPRS
-#define SWSEM_RESOLVE_SGPRS 72
+#define SWSEM_RESOLVE_SGPRS 88
 #endif
+#ifndef SWSEM_RESOLVE_WAVES
+#define SWSEM_RESOLVE_WAVES 7
+#endif
+constexpr int RESOLVE_WAVES_PER_SIMD = SWSEM_RESOLVE_WAVES;
 // K-mer hashes of the scan window [s, s + cnt) (cnt <= WL), one position per lane, from the query bytes: the
 // window's bytes are loaded once as aligned dwords (one per lane), every lane picks the nine it needs with
 // ds_bpermute and shifts them into place. The chains wait on memory most of the time, so the multiplications

@@ -177,7 +177,7 @@ struct swsem {
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 4;                       // probe tiles per resolve block: chosen per batch (run_batch) unless SWSEM_RB fixes it
     uint32_t rbFixed = 0;
-    uint32_t waveSlots = 8192;             // waves the device holds at 8 per SIMD
+    uint32_t waveSlots = 256 * 4 * RESOLVE_WAVES_PER_SIMD;   // resolve waves the device holds at once (CUs x SIMDs x waves)
     std::vector<Contig> contigs;
     std::vector<uint32_t> matchCount;
     std::vector<swsem_match_t> hostMatches;
@@ -538,7 +538,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     uint32_t tiles = 0, rblocks = 0;
     {
         // Block chains are latency-bound and a launch lasts as long as its slowest wave: the blocks are sized so
-        // that all of them are resident at once (one wave each, 8 per SIMD) and there are as many as that allows.
+        // that all of them are resident at once (one wave each, RESOLVE_WAVES_PER_SIMD per SIMD) and there are as many as that allows.
         // Fewer, longer blocks leave wave slots empty; more of them run in two generations and lengthen the
         // sequential stitch. At least two tiles, so that the warm-up stays a small part of a block.
         uint64_t allTiles = 0;
@@ -767,7 +767,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (h->K > 128) h->flyHash = false;                               // (a window's bytes must fit one dword per lane)
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rbFixed = (uint32_t) x; }
-    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 32u; }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
         hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
         hipMalloc((void **) &h->lut, 256) != hipSuccess) {
