@@ -46,8 +46,6 @@ struct RefView {
     int fpCheck;              // fingerprints may be used to reject entries (see ht_value)
     int K, k1ord, skipMargin;
     uint32_t minLen;
-    const uint32_t *bloom;    // presence bits of the hashes ever inserted (nullptr: not usable, see bloom_has)
-    uint32_t bloomMask;
     int flyHash;              // scan windows hash their K-mers themselves (no hash array)
 };
 
@@ -87,25 +85,6 @@ __device__ __forceinline__ uint32_t ht_value(const RefView &v, ht_entry e, uint3
     const uint32_t fp = (uint32_t) e & ((1u << v.fpBits) - 1u);
     if (v.fpCheck && fp != (hash >> (32 - v.fpBits))) return 0u;
     return (uint32_t) (e >> v.fpBits);
-}
-
-// Presence filter in front of the table (an experiment, SWSEM_BLOOM=n; off by default). One bit per value of
-// the low bits of a K-mer's hash (the bucket index plus n-1 bits of the fingerprint), set when a K-mer with that
-// hash is inserted and never cleared. A clear bit says what a fingerprint mismatch says — no entry of this K-mer
-// is in the table — under the same condition (fpCheck), without fetching the bucket: at 99 % identity all but
-// two of the 32 lookups of a scan window are of K-mers that were never sampled. Results are identical (the GPU
-// suite passes with it), but it is SLOWER on the headline workload: resolve 1.20 -> 1.33 ms, insertion
-// 0.35 -> 0.43 ms for 32, 64 and 128 MiB of bits alike. The resolve kernel is not bound by the table's HBM
-// sectors but by the number of dependent vector-memory instructions per chain, and the filter adds one.
-__device__ __forceinline__ bool bloom_has(const RefView &v, uint32_t hash) {
-    const uint32_t i = hash & v.bloomMask;
-    return (v.bloom[i >> 5] >> (i & 31u)) & 1u;
-}
-__device__ __forceinline__ void bloom_set(uint32_t *bloom, uint32_t bloomMask, uint32_t hash) {
-    const uint32_t i = hash & bloomMask, bit = 1u << (i & 31u);
-    // (most K-mers of a collection have been seen before: the plain read saves the atomic; a stale read can
-    // only show a set bit as clear — bits are never cleared — and then the atomic sets it again)
-    if (!(bloom[i >> 5] & bit)) atomicOr(&bloom[i >> 5], bit);
 }
 
 // window test of SlidingWindowSparseEMMatcher.cpp:212-222. Returns false when the entry is rejected.

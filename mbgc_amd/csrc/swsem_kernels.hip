@@ -93,8 +93,7 @@ __global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restri
 // (the tail runs after the main loop on the CPU, so it wins collisions against it).
 __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                 uint64_t S, uint64_t nMain, uint64_t T, uint64_t nTail, int k1,
-                                                int k1ord, int K, uint32_t mask, uint32_t epoch, int fpBits,
-                                                uint32_t *__restrict__ bloom, uint32_t bloomMask) {
+                                                int k1ord, int K, uint32_t mask, uint32_t epoch, int fpBits) {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nMain + nTail) return;
     const bool tail = t >= nMain;
@@ -105,7 +104,6 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
     const ht_entry key = ht_key(epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
     atomicMax(&ht[h & mask], key);
-    if (bloom) bloom_set(bloom, bloomMask, h);
 }
 
 // The same for several loadRef pieces in one launch. Epochs make the result independent of the order in
@@ -115,7 +113,7 @@ struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, pad; };
 __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                       const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first,
                                                       int np, int k1, int k1ord, int K, uint32_t mask, int fpBits,
-                                                      const uint32_t *__restrict__ gate, uint32_t *__restrict__ bloom, uint32_t bloomMask) {
+                                                      const uint32_t *__restrict__ gate) {
     if (gate && *gate == 0) return;
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= first[np]) return;
@@ -131,7 +129,6 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
     const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
     atomicMax(&ht[h & mask], key);
-    if (bloom) bloom_set(bloom, bloomMask, h);
 }
 
 __global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict__ ht, uint32_t *__restrict__ out, uint64_t n, int fpBits) {
@@ -646,7 +643,7 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
             if (v.flyHash) hf = window_hash(v, q, s, p1 - s < WL ? p1 - s : WL, lane);
             if (lane < WL && pos < p1) {
                 const uint32_t hv = v.flyHash ? hf : hashes[pos];
-                if (!v.bloom || bloom_has(v, hv)) e = ht_value(v, v.ht[hv & v.mask], hv);
+                e = ht_value(v, v.ht[hv & v.mask], hv);
                 if (e != 0) {
                     uint64_t lo, hi;
                     if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;

@@ -195,15 +195,12 @@ struct swsem {
 
     CopySegs segs;                         // small copies staged for one launch (stage_copy / flush_copies)
     hipStream_t segStream = nullptr;
-    uint32_t *bloom = nullptr;             // presence bits in front of the table (swsem_device.h: bloom_has); an experiment, off by default
-    uint32_t bloomMask = 0;
 
     uint64_t refLength() const { return laps ? maxRefLength : (uint64_t) pos1; }
     RefView view() const {
         RefView v;
         v.ref = ref; v.ht = ht; v.pos1 = (uint64_t) pos1; v.refLength = refLength(); v.maxRefLength = maxRefLength;
         v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? 1 : 0; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
-        v.bloom = (v.fpCheck && bloom) ? bloom : nullptr; v.bloomMask = bloomMask;
         v.flyHash = (flyHash && lazyProbe) ? 1 : 0;
         return v;
     }
@@ -293,7 +290,7 @@ int insert_samples(swsem *h) {
     } else if (total) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch, h->fpBits, h->bloom, h->bloomMask);
+            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch, h->fpBits);
         h->mark(SWSEM_K_INSERT, false);
         HIPCHK(hipGetLastError());
     }
@@ -417,7 +414,7 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     if (np) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert_multi<<<dim3((unsigned) ((tFirst[np] + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->bloom, h->bloomMask);
+            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
         h->mark(SWSEM_K_INSERT, false);
     }
     HIPCHK(hipGetLastError());
@@ -775,19 +772,6 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
         return fail(SWSEM_ENOMEM, "cannot allocate %llu B reference + %llu B hash table in HBM",
                     (unsigned long long) maxRefLength, (unsigned long long) h->hash_size * 8ull);
     }
-    {
-        int extra = -1;                                                  // off unless SWSEM_BLOOM=n asks for 2^(n-1) filter bits per bucket
-        if (const char *e = getenv("SWSEM_BLOOM")) extra = atoi(e) <= 0 ? -1 : atoi(e) - 1;
-        int bits = 0;
-        while ((1ull << bits) < h->hash_size) bits++;
-        bits = std::min(32, bits + extra);
-        if (extra >= 0 && h->fpBits && bits >= 5) {
-            const size_t bytes = (size_t) 1 << (bits - 3);
-            if (hipMalloc((void **) &h->bloom, bytes) != hipSuccess) { swsem_destroy(h); return fail(SWSEM_ENOMEM, "cannot allocate the %zu B presence filter", bytes); }
-            h->bloomMask = bits == 32 ? ~0u : (1u << bits) - 1u;
-            HIPCHK(hipMemsetAsync(h->bloom, 0, bytes, h->stream));
-        }
-    }
     uint8_t lut[256];
     build_lut(lut);
     HIPCHK(hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
@@ -812,7 +796,6 @@ void swsem_destroy(swsem_t *h) {
     h->drain_events();
     if (h->ref) (void) hipFree(h->ref);
     if (h->ht) (void) hipFree(h->ht);
-    if (h->bloom) (void) hipFree(h->bloom);
     if (h->lut) (void) hipFree(h->lut);
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release(); h->dCandNext.release(); h->dPrepTileContig.release(); h->dPrepContigs.release(); h->dPrepStats.release();
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
