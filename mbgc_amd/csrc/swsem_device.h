@@ -46,7 +46,6 @@ struct RefView {
     int fpCheck;              // fingerprints may be used to reject entries (see ht_value)
     int K, k1ord, skipMargin;
     uint32_t minLen;
-    int flyHash;              // scan windows hash their K-mers themselves (no hash array)
 };
 
 // little-endian loads at arbitrary byte addresses. gfx950 under HSA runs global memory in unaligned

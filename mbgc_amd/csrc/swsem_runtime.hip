@@ -201,7 +201,6 @@ struct swsem {
         RefView v;
         v.ref = ref; v.ht = ht; v.pos1 = (uint64_t) pos1; v.refLength = refLength(); v.maxRefLength = maxRefLength;
         v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? 1 : 0; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
-        v.flyHash = (flyHash && lazyProbe) ? 1 : 0;
         return v;
     }
     // event pairs are recycled: creating events by the hundred makes the runtime grow its signal pool now and
@@ -585,6 +584,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     }
     if ((r = zero_dev(h, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) || (r = flush_copies(h))) return r;
     const RefView v = h->view();
+    const int mode = h->lazyProbe ? (h->flyHash ? 2 : 1) : 0;       // template argument of the chain kernels (swsem_kernels.hip: chain_run)
     // hashes announced ahead for exactly these buffers: adopt them
     const bool adopted = h->prepValid && h->lazyProbe && h->prepQ == qdev && h->prepOffsets.size() == (size_t) n + 1 &&
                          std::equal(h->prepOffsets.begin(), h->prepOffsets.end(), offsets);
@@ -592,7 +592,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if (adopted && tiles) {
         std::swap(h->dCand, h->dCandNext);
         HIPCHK(hipStreamWaitEvent(h->stream, h->evHash, 0));
-    } else if (tiles && !v.flyHash) {
+    } else if (tiles && !(h->flyHash && h->lazyProbe)) {
         h->mark(SWSEM_K_PROBE, true);
         if (h->lazyProbe) k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
         else k_probe<false><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
@@ -600,8 +600,9 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     }
     if (h->seqResolve || tiles == 0) {
         h->mark(SWSEM_K_RESOLVE, true);
-        if (h->lazyProbe) k_resolve_seq<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
-        else k_resolve_seq<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
+        if (mode == 2) k_resolve_seq<2><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
+        else if (mode == 1) k_resolve_seq<1><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
+        else k_resolve_seq<0><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
         h->mark(SWSEM_K_RESOLVE, false);
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
@@ -615,19 +616,18 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if ((r = h->dDstOff.reserve(rblocks))) return r;
         if ((r = h->dPrev.reserve(rblocks))) return r;
         h->mark(SWSEM_K_RESOLVE, true);
-        if (h->lazyProbe) k_resolve_blocks<true><<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p,
-                                                                                           h->dRegions.p, cap, h->rb, h->dRecs.p);
-        else k_resolve_blocks<false><<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p,
-                                                                                 h->dRegions.p, cap, h->rb, h->dRecs.p);
+#define SWSEM_LAUNCH_RB(M) k_resolve_blocks<M><<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p, \
+                                                                                      h->dRegions.p, cap, h->rb, h->dRecs.p)
+        if (mode == 2) SWSEM_LAUNCH_RB(2); else if (mode == 1) SWSEM_LAUNCH_RB(1); else SWSEM_LAUNCH_RB(0);
+#undef SWSEM_LAUNCH_RB
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
         k_stitch_pre<<<dim3((rblocks + 255) / 256), dim3(256), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRecs.p, h->rb, rblocks, h->dFast.p);
-        if (h->lazyProbe) k_stitch<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p, h->dFast.p,
-                                                                             h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
-                                                                             h->dMatchCount.p, h->dStats.p);
-        else k_stitch<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p, h->dFast.p,
-                                                                   h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p,
-                                                                   h->dMatchCount.p, h->dStats.p);
+#define SWSEM_LAUNCH_ST(M) k_stitch<M><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, \
+                                                                      h->dRecs.p, h->dFast.p, h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p, \
+                                                                      h->dMatchCount.p, h->dStats.p)
+        if (mode == 2) SWSEM_LAUNCH_ST(2); else if (mode == 1) SWSEM_LAUNCH_ST(1); else SWSEM_LAUNCH_ST(0);
+#undef SWSEM_LAUNCH_ST
         k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
                                                             h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
         h->mark(SWSEM_K_STITCH, false);

@@ -198,7 +198,8 @@ def test_batch_round_on_device(binding):
 
 @pytest.mark.parametrize("env", [{"SWSEM_RESOLVE": "seq"}, {"SWSEM_RB": "1"}, {"SWSEM_RB": "2"}, {"SWSEM_RB": "16"},
                                  {"SWSEM_PROBE": "dense"}, {"SWSEM_PROBE": "dense", "SWSEM_RESOLVE": "seq"},
-                                 {"SWSEM_PROBE": "dense", "SWSEM_RB": "1"}])
+                                 {"SWSEM_PROBE": "dense", "SWSEM_RB": "1"}, {"SWSEM_HASH": "pre"}, {"SWSEM_HASH": "pre", "SWSEM_RB": "1"},
+                                 {"SWSEM_HASH": "pre", "SWSEM_RESOLVE": "seq"}])
 def test_resolve_variants_agree_with_oracle(binding, env, monkeypatch):
     """sequential replay, block-parallel speculation at several block sizes, and the dense probe pass instead
     of the chains' on-demand table lookups: same rows"""
