@@ -5,7 +5,9 @@
  * Parity status: PINNED. Every function is checked against the reference itself compiled from
  * /root/reference into oracle/_ref (tests/test_oracle_vs_ref.py, run in the build container) and
  * against the golden fixtures under tests/golden/ generated from that reference build
- * (tests/golden/make_golden.py), which travel to the GPU box.
+ * (tests/golden/make_golden.py), which travel to the GPU box. decode_oracle.c (the decoder's per-contig automaton,
+ * used for the round-trip property) is pinned by decoding streams written by that reference build's encoder
+ * (tests/test_decode_roundtrip.py).
  *
  * All file:line citations are relative to /root/reference (MBGC v2.1.5).
  */
@@ -109,6 +111,14 @@ uint64_t orc_process_matches(const orc_matcher *m, const orc_emit_params *p, orc
                              uint64_t lockPos, int unmatchedFractionFactor, int64_t processedTargetsCount,
                              int64_t targetIdx, const uint64_t *refExtLoadedPos, uint64_t nLoaded,
                              orc_streams *out);
+
+/* The inverse (decode_oracle.c): MBGC_Decoder::decodeSequenceAndReturnUnmatchedChars with extendMatchLeft/Right,
+ * mbgccoder/MBGC_Decoder.cpp:319-523, for the six streams of ONE contig (ORC_* order) against the reference buffer
+ * `ref` the encoder matched against. Writes the contig to dest; returns unmatchedChars, or -1 if a stream ran
+ * out, an index left its buffer, dest is too small or stream bytes were left over. */
+int64_t orc_decode_contig(const uint8_t *ref, const orc_emit_params *p, const uint8_t *const streams[ORC_NSTREAMS],
+                          const uint64_t sizes[ORC_NSTREAMS], uint64_t refLockPos, uint8_t *dest, uint64_t destCap,
+                          uint64_t *destLen);
 
 /* writeUInt64Frugal, utils/helper.cpp:237-246 */
 void orc_write_frugal64(orc_buf *b, uint64_t v);

@@ -216,6 +216,29 @@ class OracleEmitter:
                     totalDestLen=s.totalDestLen, removedGapBreakingMatches=s.removedGapBreakingMatches)
 
 
+def decode_contig(ref, params, streams, lock=NO_LOCK, cap=None):
+    """MBGC_Decoder::decodeSequenceAndReturnUnmatchedChars (oracle/decode_oracle.c) for the six streams of one contig
+    (dict by STREAM_NAMES, bytes or uint8 arrays) against the reference bytes `ref` (a uint8 array, or a ctypes
+    pointer to the matcher's buffer). Returns (contig bytes as uint8 array, unmatchedChars); raises on a malformed
+    stream set."""
+    arrs = [np.ascontiguousarray(np.frombuffer(streams[n], dtype=np.uint8) if isinstance(streams[n], (bytes, bytearray))
+                                 else streams[n], dtype=np.uint8) for n in STREAM_NAMES]
+    ptrs = (C.c_void_p * 6)(*[a.ctypes.data if a.size else None for a in arrs])
+    sizes = (C.c_uint64 * 6)(*[a.size for a in arrs])
+    if cap is None:
+        cap = 1 << 28                                  # (untouched pages cost nothing)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    refp = ref.ctypes.data_as(C.c_void_p) if isinstance(ref, np.ndarray) else ref
+    f = lib().orc_decode_contig
+    f.restype = C.c_int64
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    r = f(refp, C.byref(params), ptrs, sizes, lock, out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    if r < 0:
+        raise ValueError("orc_decode_contig: malformed streams (consumed into %d output bytes)" % n.value)
+    return out[: n.value], int(r)
+
+
 def fingerprint(matches):
     """FNV-style fingerprint of a match list, SURVEY.md §8c."""
     fp = 0xcbf29ce484222325

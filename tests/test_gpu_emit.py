@@ -175,3 +175,30 @@ def test_round_runner_equals_driver_rounds(binding, lim, div):
     assert bytes(runner.locks_stream) == b["locks"] and bytes(runner.ref_ext_sizes) == b["refExtSize"]
     assert h.loaded_ref_length() == o.loaded_ref_length()
     assert np.array_equal(h.ht(), o.ht())
+
+
+@pytest.mark.parametrize("mode,lazy,lim", [(1, True, 4_000_000), (2, False, 4_000_000), (1, True, 600_000)])
+def test_hip_streams_decode_back_to_the_contig(binding, mode, lazy, lim):
+    """round trip through the decoder's automaton (oracle/decode_oracle.c, MBGC_Decoder.cpp:319-523): the HIP path's
+    six streams, decoded against the HIP handle's own reference buffer, give the contig back (lim = 600 000: the
+    circular buffer has wrapped)"""
+    gs = small_collection(9 if lim < 1_000_000 else 5, 100_000, 0.012, seed=31 + mode)
+    p = binding.emit_params(mode)
+    p.lazyDecompressionSupport = int(lazy)
+    po = _orc.emit_params(mode)
+    po.lazyDecompressionSupport = int(lazy)
+    h = binding.SlidingWindowSparseEMMatcher(lim, skip_margin=24 if mode >= 2 else 16)
+    h.load_ref(gs[0], load_rc=True)
+    loaded = [h.loaded_ref_length()]
+    for t, g in enumerate(gs[1:]):
+        for c in (g[:40_000], g[40_000:]):
+            h.match(c)
+            un, streams, _ = h.emit(p, 0, binding.NO_LOCK, 128, t, t, loaded)
+            back, un2 = _orc.decode_contig(h.ref(h.max_ref_length()), po, streams, _orc.NO_LOCK)
+            assert back.size == c.size and np.array_equal(back, c), (mode, lazy, t)
+            assert un2 == (un & 0xFFFFFFFF)
+            h.load_ref(c)
+            if lazy:
+                h.load_separator(0)
+            loaded.append(h.loaded_ref_length())
+    h.close()

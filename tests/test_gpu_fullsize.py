@@ -72,3 +72,43 @@ def test_configs1_all_rounds_equal_oracle():
     assert h.loaded_ref_length() == o.loaded_ref_length()
     assert np.array_equal(h.ht(), o.ht())
     assert sum(len(v) for v in exp["streams"].values()) > 50_000_000      # ~0.14 B per base of 635 Mbases
+
+
+def test_configs1_round_trip_through_the_decoder():
+    """size-independent property at full size, with no encoder oracle in the loop: rounds of 16 x 5 Mbp against the
+    1.28e9-byte reference; every contig's six streams, decoded by the decoder's automaton (oracle/decode_oracle.c,
+    MBGC_Decoder.cpp:319-523) against the reference buffer on the device, give the contig back, and its return
+    value is the unmatchedChars the encoder reported."""
+    import torch
+    from mbgc_amd import binding
+    base = synth.base_codes(L)
+    h = binding.SlidingWindowSparseEMMatcher(MAX_REF_LEN)
+    h.set_sliding_window_size(16)
+    g0 = torch.from_numpy(synth.genome(base, 0)).to("cuda:0")
+    torch.cuda.synchronize()
+    h.load_ref_dev(g0.data_ptr(), g0.numel(), True, True, 0)
+    p, po = binding.emit_params(1), _orc.emit_params(1)
+    loaded = [h.loaded_ref_length()]
+    done = 0
+    for rnd in range(3):
+        gs = [synth.genome(base, 1 + rnd * R + t) for t in range(R)]
+        buf = torch.from_numpy(np.concatenate(gs)).to("cuda:0")
+        offs = np.arange(R + 1, dtype=np.uint64) * L
+        torch.cuda.synchronize()
+        locks = [h.acquire_lock() for _ in range(R)]
+        h.match_batch_dev(buf.data_ptr(), offs, 32, locks)
+        # (processed = the target's own index: no contig is put off as dissimilar, MGMP_Params.h:193-196 — the retry
+        # protocol is the other full-size test's business)
+        h.emit_batch(p, None, locks, [128] * R, [done + t for t in range(R)], [done + t for t in range(R)], loaded, n=R)
+        ref = h.ref(int(h.loading_position()) + 64)                # everything loaded so far (no wrap in three rounds)
+        for c in range(R):
+            un, streams, _ = h.emit_result(c)
+            assert un != binding.SKIPPED
+            back, un2 = _orc.decode_contig(ref, po, streams, int(locks[c]), cap=L + 64)
+            assert back.size == L and np.array_equal(back, gs[c]), (rnd, c)
+            assert un2 == (un & 0xFFFFFFFF)
+        after = h.finalize_targets([buf.data_ptr() + c * L for c in range(R)], [L] * R, locks, lazy=True)
+        loaded += [int(x) for x in after]
+        done += R
+        torch.cuda.synchronize()
+    h.close()
