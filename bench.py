@@ -229,6 +229,8 @@ def main():
             "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof}, "dominant_kernel": dom,
             "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps, "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
         }
+        if world > 1:
+            out["extension_allgathers_started_ahead"] = {"started": runner.pregathers[0], "used": runner.pregathers[1]}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit)
         print(json.dumps(out), flush=True)

@@ -69,6 +69,9 @@ class RoundRunner:
         self._deferred = None                        # emission whose streams have not been collected yet
         self._pack_buf = None
         self._pred_ext = None                        # what every contig of the last round decided about extending the reference
+        self._gpred = False                          # several ranks: last round every target on every rank was loaded whole, without RC
+        self._pre = None                             # extension all-gather started ahead under that prediction (see _pregather)
+        self.pregathers = [0, 0]                     # started / used (diagnostics)
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -98,6 +101,34 @@ class RoundRunner:
         parts = self._allgather_bytes(t.view(torch.uint8))
         return [p.view(torch.int64).tolist() for p in parts]
 
+    def _pregather(self, qbuf, offsets, targets, T):
+        """Several ranks: in a collection nearly every target ends up loaded into the reference whole, so the bytes the
+        round's all-gather will carry are known before the round starts — they are the queries. When the last round went
+        that way on every rank (a fact all ranks hold, so all of them decide alike), the all-gather is started here,
+        asynchronously, and runs beside match-finding instead of after it; _finalize_range uses its result if this
+        round's decisions come out the same on every rank, and falls back to the ordinary exchange otherwise."""
+        self._pre = None
+        if self.world == 1 or not self._gpred or self.p is None:
+            return
+        ncont = len(offsets) - 1
+        if int(offsets[0]) != 0 or int(offsets[-1]) != qbuf.numel() or any(targets[c] > targets[c + 1] for c in range(ncont - 1)):
+            return
+        import torch.distributed as dist
+        n = torch.tensor([qbuf.numel()], dtype=torch.int64, device=self.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        mx = max(max(sizes), 1)
+        if qbuf.numel() == mx:
+            pad = qbuf
+        else:
+            pad = torch.zeros(mx, dtype=torch.uint8, device=self.device)
+            pad[: qbuf.numel()] = qbuf
+        out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
+        work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
+        self._pre = dict(work=work, out=out, pad=pad, mx=mx, sizes=sizes)
+        self.pregathers[0] += 1
+
     # ---- one round ----------------------------------------------------------------------------
     def run_round(self, qbuf, offsets, targets=None, min_len=32, next_batch=None):
         """qbuf: uint8 device tensor holding this rank's contigs of the round back to back, contig c at
@@ -113,6 +144,7 @@ class RoundRunner:
         ntot = T * self.world
         first = self.targets_done                   # global index of the round's first target
         locks = [m.acquire_lock() for _ in range(ntot)]                     # MGMP.cpp:353-358
+        self._pregather(qbuf, offsets, targets, T)
         lock_of = [locks[self.rank * T + targets[c]] for c in range(ncont)]
         pending = list(range(ncont))                # contigs still to be matched + emitted
         counts = np.zeros(ncont, dtype=np.uint64)
@@ -288,11 +320,26 @@ class RoundRunner:
         if self.world == 1:
             self._finalize_many([x[0] for x in pieces], [x[1] for x in pieces], [locks[t] for t in my])
             return
-        tens = [x[2] if x[2] is not None else qbuf[x[3]: x[3] + x[1]] for x in pieces if x[1]]
-        local = torch.cat(tens) if tens else torch.empty(0, dtype=torch.uint8, device=self.device)
-        all_ext = self._allgather_bytes(local)
+        # this rank's extensions are exactly its queries, target after target (what _pregather assumed)?
+        whole = (lo == 0 and hi == T * self.world and len(pieces) == T and
+                 all(x[2] is None and x[1] > 0 for x in pieces) and sum(x[1] for x in pieces) == qbuf.numel() and
+                 all(pieces[i][3] + pieces[i][1] == pieces[i + 1][3] for i in range(len(pieces) - 1)) and pieces[0][3] == 0)
+        all_lens = self._allgather_ints([x[1] for x in pieces] + [1 if whole else 0, -1])   # (-1 keeps the tensor non-empty)
+        flags = [l[-2] for l in all_lens]
+        all_lens = [l[:-2] + [-1] for l in all_lens]
+        pre, self._pre = self._pre, None
+        self._gpred = all(flags) and lo == 0 and hi == T * self.world
+        if pre is not None:
+            pre["work"].wait()                       # (always: the collective was entered by every rank)
+        if pre is not None and all(flags) and all(sum(l[:-1]) == pre["sizes"][r] for r, l in enumerate(all_lens)):
+            all_ext = [pre["out"][r * pre["mx"]: r * pre["mx"] + pre["sizes"][r]] for r in range(self.world)]
+            self._keep.append(pre["out"])
+            self.pregathers[1] += 1
+        else:
+            tens = [x[2] if x[2] is not None else qbuf[x[3]: x[3] + x[1]] for x in pieces if x[1]]
+            local = torch.cat(tens) if tens else torch.empty(0, dtype=torch.uint8, device=self.device)
+            all_ext = self._allgather_bytes(local)
         self._keep.extend(all_ext)
-        all_lens = self._allgather_ints([x[1] for x in pieces] + [-1])           # -1 terminator keeps the tensor non-empty
         cur = [0] * self.world
         idx = [0] * self.world
         ptrs, lens = [], []

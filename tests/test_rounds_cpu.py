@@ -74,6 +74,7 @@ def _worker(rank, world, port, outdir, div, cpt):
     gs = collection(9, 60_000, div, seed=17)
     runner, m = run_rank(rank, world, gs, 2, cpt)
     np.save(os.path.join(outdir, "ht%d.npy" % rank), m.ht())
+    open(os.path.join(outdir, "pregathers%d" % rank), "w").write("%d %d" % tuple(runner.pregathers))
     if rank == 0:
         for k, v in runner.streams.items():
             open(os.path.join(outdir, k), "wb").write(bytes(v))
@@ -83,7 +84,7 @@ def _worker(rank, world, port, outdir, div, cpt):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("div,cpt", [(0.012, 1), (0.06, 2)])
+@pytest.mark.parametrize("div,cpt", [(0.012, 1), (0.06, 2), (0.002, 1)])
 def test_world_size_2_gloo(tmp_path, div, cpt):
     """2 ranks x 2 targets per round == one process with rounds of 4; replicas bit-identical"""
     import torch.multiprocessing as mp
@@ -99,3 +100,9 @@ def test_world_size_2_gloo(tmp_path, div, cpt):
     assert (tmp_path / "refext").read_bytes() == res["refExtSize"]
     h0, h1 = np.load(tmp_path / "ht0.npy"), np.load(tmp_path / "ht1.npy")
     assert np.array_equal(h0, ht) and np.array_equal(h1, ht)
+    # the extension all-gather started ahead of the round (RoundRunner._pregather): both ranks decide alike; on the
+    # similar collection the second round starts one and uses it
+    pg = [(tmp_path / ("pregathers%d" % r)).read_text() for r in range(2)]
+    assert pg[0] == pg[1]
+    if div < 0.005 and cpt == 1:                       # (at 1.2 % every round of this small collection has a retry)
+        assert pg[0] == "1 1", pg
