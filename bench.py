@@ -8,7 +8,13 @@ MGMP.cpp:130-168). A *step* is one round: every GPU matches `--round` targets (d
 frozen replica, then every replica loads the round's extensions in target order (hash insertion
 included). With N > 1 the targets are sharded file-per-GPU and the extension bytes are all-gathered
 over RCCL; per-GPU work is fixed, so scaling is weak. Inputs are resident in HBM before the timed
-region. One JSON line is printed by rank 0."""
+region. One JSON line is printed by rank 0.
+
+Diagnostics (never the headline): --no-emit (matcher only), --from-host (queries cross PCIe inside the timed region),
+--check (first round against the oracle); environment: MBGC_BENCH_BLOCK_STATS / MBGC_BENCH_BLOCK_DUMP (per-block clocks
+of the last resolve launch), MBGC_BENCH_NO_LOOKAHEAD, MBGC_BENCH_ONE_DEVICE + MBGC_BENCH_BACKEND=gloo (several ranks
+on one GPU, a rehearsal of the N > 1 protocol), and the library's own switches (SWSEM_RB, SWSEM_PROBE, SWSEM_HASH,
+SWSEM_RESOLVE, SWSEM_PROF_FAMS; see mbgc_amd/csrc/swsem_runtime.hip: swsem_create)."""
 import argparse
 import json
 import os
