@@ -111,13 +111,17 @@ class RoundRunner:
         if self.world == 1 or not self._gpred or self.p is None:
             return
         ncont = len(offsets) - 1
-        if int(offsets[0]) != 0 or int(offsets[-1]) != qbuf.numel() or any(targets[c] > targets[c + 1] for c in range(ncont - 1)):
-            return
+        usable = not (int(offsets[0]) != 0 or int(offsets[-1]) != qbuf.numel() or
+                      any(targets[c] > targets[c + 1] for c in range(ncont - 1)))
         import torch.distributed as dist
-        n = torch.tensor([qbuf.numel()], dtype=torch.int64, device=self.device)
+        # (whether this rank's buffer has the expected layout is local knowledge: it travels with the sizes, so that
+        # every rank enters the big collective or none does)
+        n = torch.tensor([qbuf.numel() if usable else -1], dtype=torch.int64, device=self.device)
         sizes = [torch.zeros_like(n) for _ in range(self.world)]
         dist.all_gather(sizes, n, group=self.group)
         sizes = [int(x.item()) for x in sizes]
+        if min(sizes) < 0:
+            return
         mx = max(max(sizes), 1)
         if qbuf.numel() == mx:
             pad = qbuf
