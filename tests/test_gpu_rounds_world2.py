@@ -1,0 +1,78 @@
+"""The N > 1 round protocol on the device path: two processes, each with its own HIP handle (replica) on the one GPU
+of the test box, exchanging the round's extensions and streams with torch.distributed (gloo here — with one GPU per
+process it is nccl = RCCL, the calls are the same). Results must equal the single-process reference loop with rounds
+of 2 x 2 targets, and the replicas' hash tables must be bit-identical."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import _driver
+import _orc
+from mbgc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LIM = 3_000_000
+
+
+def collection(n, length, div, seed):
+    base = synth.base_codes(length, seed)
+    return [synth.genome(base, i, div) for i in range(n)]
+
+
+def _worker(rank, world, port, outdir, div, n):
+    import torch
+    import torch.distributed as dist
+    from mbgc_amd import binding
+    from mbgc_amd.rounds import RoundRunner, round_schedule
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    gs = collection(n, 80_000, div, seed=23)
+    h = binding.SlidingWindowSparseEMMatcher(LIM, device=0)
+    h.set_sliding_window_size(16)
+    h.load_ref(gs[0], load_rc=True)
+    runner = RoundRunner(h, rank, world, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1))
+    runner.start()
+    for rnd in round_schedule(len(gs) - 1, 2, world):
+        mine = [gs[1 + t] for t in rnd[rank]]
+        buf = torch.from_numpy(np.concatenate(mine)).to("cuda:0")
+        offs = np.zeros(len(mine) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([c.size for c in mine])
+        torch.cuda.synchronize()
+        runner.run_round(buf, offs)
+    runner.flush()
+    np.save(os.path.join(outdir, "ht%d.npy" % rank), h.ht())
+    open(os.path.join(outdir, "pregathers%d" % rank), "w").write("%d %d" % tuple(runner.pregathers))
+    if rank == 0:
+        for k, v in runner.streams.items():
+            open(os.path.join(outdir, k), "wb").write(bytes(v))
+        open(os.path.join(outdir, "locks"), "wb").write(bytes(runner.locks_stream))
+        open(os.path.join(outdir, "refext"), "wb").write(bytes(runner.ref_ext_sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+    h.close()
+
+
+@pytest.mark.parametrize("div,n", [(0.002, 13), (0.012, 9)])
+def test_two_replicas_on_one_gpu_equal_the_reference_loop(tmp_path, div, n):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), div, n), nprocs=2, join=True)
+    gs = collection(n, 80_000, div, seed=23)
+    o = _orc.OracleMatcher(LIM)
+    res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], 4)
+    for k, v in res["streams"].items():
+        assert (tmp_path / k).read_bytes() == v, k
+    assert (tmp_path / "locks").read_bytes() == res["locks"]
+    assert (tmp_path / "refext").read_bytes() == res["refExtSize"]
+    h0, h1 = np.load(tmp_path / "ht0.npy"), np.load(tmp_path / "ht1.npy")
+    assert np.array_equal(h0, o.ht()) and np.array_equal(h1, o.ht())
+    pg = [(tmp_path / ("pregathers%d" % r)).read_text() for r in range(2)]
+    assert pg[0] == pg[1]
+    if div < 0.005:
+        assert int(pg[0].split()[1]) >= 1, pg          # the extension all-gather started ahead of a round was used
+    o.close()
