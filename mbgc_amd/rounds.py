@@ -96,8 +96,16 @@ class RoundRunner:
         dist.all_gather_into_tensor(out, pad, group=self.group)
         return [out[r * mx: r * mx + sizes[r]] for r in range(self.world)]
 
-    def _allgather_ints(self, vals):
+    def _allgather_ints(self, vals, fixed=False):
+        """fixed: every rank is known to pass the same number of values (one collective instead of sizes + data)"""
         t = torch.tensor(list(vals), dtype=torch.int64, device=self.device)
+        if fixed and self.world > 1:
+            import torch.distributed as dist
+            out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(out, t, group=self.group)
+            flat = out.tolist()
+            k = t.numel()
+            return [flat[r * k: (r + 1) * k] for r in range(self.world)]
         parts = self._allgather_bytes(t.view(torch.uint8))
         return [p.view(torch.int64).tolist() for p in parts]
 
@@ -198,7 +206,7 @@ class RoundRunner:
             # the first target (global order) holding a dissimilar contig cuts the round (MGMP.cpp:382-388:
             # "discard, wait until the earlier targets are loaded, retry")
             first_skip_local = min([self.rank * T + targets[c] for c in skipped_local], default=ntot)
-            first_skip = min(x[0] for x in self._allgather_ints([first_skip_local])) if self.world > 1 else first_skip_local
+            first_skip = min(x[0] for x in self._allgather_ints([first_skip_local], fixed=True)) if self.world > 1 else first_skip_local
             upto = first_skip                       # targets [finalized, upto) are complete on every rank
             if last is not None and first_skip < ntot:
                 packs.append(self._pack(*last))     # a retry follows: it reuses the emission's buffers, take the streams now
@@ -328,7 +336,8 @@ class RoundRunner:
         whole = (lo == 0 and hi == T * self.world and len(pieces) == T and
                  all(x[2] is None and x[1] > 0 for x in pieces) and sum(x[1] for x in pieces) == qbuf.numel() and
                  all(pieces[i][3] + pieces[i][1] == pieces[i + 1][3] for i in range(len(pieces) - 1)) and pieces[0][3] == 0)
-        all_lens = self._allgather_ints([x[1] for x in pieces] + [1 if whole else 0, -1])   # (-1 keeps the tensor non-empty)
+        all_lens = self._allgather_ints([x[1] for x in pieces] + [1 if whole else 0, -1],   # (-1 keeps the tensor non-empty)
+                                        fixed=(lo == 0 and hi == T * self.world))         # the whole round: T targets on every rank
         flags = [l[-2] for l in all_lens]
         all_lens = [l[:-2] + [-1] for l in all_lens]
         pre, self._pre = self._pre, None
