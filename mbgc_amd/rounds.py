@@ -72,6 +72,7 @@ class RoundRunner:
         self._gpred = False                          # several ranks: last round every target on every rank was loaded whole, without RC
         self._pre = None                             # extension all-gather started ahead under that prediction (see _pregather)
         self.pregathers = [0, 0]                     # started / used (diagnostics)
+        self._gathers = []                           # stream gathers still running (work, output, input)
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -240,11 +241,18 @@ class RoundRunner:
         self.targets_done += ntot
         return counts
 
+    def _wait_gathers(self):
+        for work, _, _ in self._gathers:
+            work.wait()
+        self._gathers = []
+
     def flush(self, previous=False):
         """waits for the emission whose streams are still to be collected (if any) and merges them; call after
         the last round. previous: a newer emission has been begun since (run_round's own call)."""
         d, self._deferred = self._deferred, None
         if d is None:
+            if not previous:
+                self._wait_gathers()
             return
         packs, last, targets, T, offsets, _ = d
         if last is not None:
@@ -254,6 +262,8 @@ class RoundRunner:
             if previous:
                 self.m.emit_select(False)
         self._collect_streams(packs, targets, T, offsets)
+        if not previous:
+            self._wait_gathers()
 
     def _match(self, qbuf, spans, locks, min_len):
         """match contigs given as byte spans of qbuf. match_batch_dev takes offsets of back-to-back
@@ -444,8 +454,25 @@ class RoundRunner:
             local = packs[0]["buf"][: int(packs[0]["starts"][-1])]     # one emission, nothing dropped: already packed in order
         else:
             local = torch.cat(chunks) if chunks else torch.empty(0, dtype=torch.uint8, device=self.device)
-        all_bytes = self._allgather_bytes(local) if self.world > 1 else [local]
-        all_meta = self._allgather_ints(meta + [-1]) if self.world > 1 else [meta + [-1]]
+        if self.world > 1:
+            # one exchange of the per-contig sizes, which also carries the byte count the big gather needs; the gather
+            # itself is asynchronous unless this rank wants the bytes now (it is waited for at the next collection)
+            import torch.distributed as dist
+            all_meta = self._allgather_ints(meta + [int(local.numel()), -1])
+            sizes = [m_[-2] for m_ in all_meta]
+            all_meta = [m_[:-2] + [-1] for m_ in all_meta]
+            self._wait_gathers()
+            mx = max(max(sizes), 1)
+            pad = torch.zeros(mx, dtype=torch.uint8, device=self.device)
+            pad[: local.numel()] = local
+            out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
+            want_now = self.rank == 0 and self.keep_streams
+            work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=not want_now)
+            if not want_now:
+                self._gathers.append((work, out, pad))
+            all_bytes = [out[r * mx: r * mx + sizes[r]] for r in range(self.world)]
+        else:
+            all_bytes, all_meta = [local], [meta + [-1]]
         self.stream_bytes += sum(int(b.numel()) for b in all_bytes)
         if self.rank != 0 or not self.keep_streams:
             return
