@@ -73,6 +73,9 @@ class RoundRunner:
         self._pre = None                             # extension all-gather started ahead under that prediction (see _pregather)
         self.pregathers = [0, 0]                     # started / used (diagnostics)
         self._gathers = []                           # stream gathers still running (work, output, input)
+        self._next_announce = -1                     # bytes of the next round's query buffer (run_round's next_batch), -1: unknown
+        self._next_key = None
+        self._next_sizes = None                      # every rank's announcement, once exchanged (rides on a round's length exchange)
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -117,29 +120,39 @@ class RoundRunner:
         asynchronously, and runs beside match-finding instead of after it; _finalize_range uses its result if this
         round's decisions come out the same on every rank, and falls back to the ordinary exchange otherwise."""
         self._pre = None
+        announced, self._next_sizes = self._next_sizes, None           # (valid for this round only)
         if self.world == 1 or not self._gpred or self.p is None:
             return
         ncont = len(offsets) - 1
         usable = not (int(offsets[0]) != 0 or int(offsets[-1]) != qbuf.numel() or
                       any(targets[c] > targets[c + 1] for c in range(ncont - 1)))
         import torch.distributed as dist
-        # (whether this rank's buffer has the expected layout is local knowledge: it travels with the sizes, so that
-        # every rank enters the big collective or none does)
-        n = torch.tensor([qbuf.numel() if usable else -1], dtype=torch.int64, device=self.device)
-        sizes = [torch.zeros_like(n) for _ in range(self.world)]
-        dist.all_gather(sizes, n, group=self.group)
-        sizes = [int(x.item()) for x in sizes]
-        if min(sizes) < 0:
-            return
+        poisoned = False
+        if announced is not None:
+            # every rank told the others last round how many bytes its next buffer holds: no exchange (and no wait for
+            # the device) at the top of the round. A rank whose buffer is not the announced one still takes part in the
+            # collective — the others will — and says so in the length exchange, which sends everybody down the ordinary path.
+            sizes = announced
+            poisoned = not usable or self._next_key != (qbuf.data_ptr(), qbuf.numel()) or qbuf.numel() != sizes[self.rank]
+        else:
+            # (whether this rank's buffer has the expected layout is local knowledge: it travels with the sizes, so that
+            # every rank enters the big collective or none does)
+            n = torch.tensor([qbuf.numel() if usable else -1], dtype=torch.int64, device=self.device)
+            sizes = [torch.zeros_like(n) for _ in range(self.world)]
+            dist.all_gather(sizes, n, group=self.group)
+            sizes = [int(x.item()) for x in sizes]
+            if min(sizes) < 0:
+                return
         mx = max(max(sizes), 1)
-        if qbuf.numel() == mx:
+        if qbuf.numel() == mx and not poisoned:
             pad = qbuf
         else:
             pad = torch.zeros(mx, dtype=torch.uint8, device=self.device)
-            pad[: qbuf.numel()] = qbuf
+            if not poisoned:
+                pad[: qbuf.numel()] = qbuf
         out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
         work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
-        self._pre = dict(work=work, out=out, pad=pad, mx=mx, sizes=sizes)
+        self._pre = dict(work=work, out=out, pad=pad, mx=mx, sizes=sizes, poisoned=poisoned)
         self.pregathers[0] += 1
 
     # ---- one round ----------------------------------------------------------------------------
@@ -158,6 +171,11 @@ class RoundRunner:
         first = self.targets_done                   # global index of the round's first target
         locks = [m.acquire_lock() for _ in range(ntot)]                     # MGMP.cpp:353-358
         self._pregather(qbuf, offsets, targets, T)
+        self._next_announce, self._next_key = -1, None
+        if next_batch is not None and self.world > 1:
+            nb, no = next_batch
+            if int(no[0]) == 0 and int(no[-1]) == nb.numel():
+                self._next_announce, self._next_key = int(nb.numel()), (nb.data_ptr(), nb.numel())
         lock_of = [locks[self.rank * T + targets[c]] for c in range(ncont)]
         pending = list(range(ncont))                # contigs still to be matched + emitted
         counts = np.zeros(ncont, dtype=np.uint64)
@@ -346,11 +364,16 @@ class RoundRunner:
         whole = (lo == 0 and hi == T * self.world and len(pieces) == T and
                  all(x[2] is None and x[1] > 0 for x in pieces) and sum(x[1] for x in pieces) == qbuf.numel() and
                  all(pieces[i][3] + pieces[i][1] == pieces[i + 1][3] for i in range(len(pieces) - 1)) and pieces[0][3] == 0)
-        all_lens = self._allgather_ints([x[1] for x in pieces] + [1 if whole else 0, -1],   # (-1 keeps the tensor non-empty)
-                                        fixed=(lo == 0 and hi == T * self.world))         # the whole round: T targets on every rank
-        flags = [l[-2] for l in all_lens]
-        all_lens = [l[:-2] + [-1] for l in all_lens]
         pre, self._pre = self._pre, None
+        if pre is not None and pre.get("poisoned"):
+            whole = False
+        whole_round = lo == 0 and hi == T * self.world                                     # then: T targets on every rank
+        all_lens = self._allgather_ints([x[1] for x in pieces] + [self._next_announce if whole_round else -1, 1 if whole else 0, -1],
+                                        fixed=whole_round)                                 # (-1 keeps the tensor non-empty)
+        flags = [l[-2] for l in all_lens]
+        nxt = [l[-3] for l in all_lens]
+        all_lens = [l[:-3] + [-1] for l in all_lens]
+        self._next_sizes = nxt if whole_round and min(nxt) >= 0 else None
         self._gpred = all(flags) and lo == 0 and hi == T * self.world
         if pre is not None:
             pre["work"].wait()                       # (always: the collective was entered by every rank)

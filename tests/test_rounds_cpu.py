@@ -35,12 +35,15 @@ def split(g, k):
     return [g[cuts[i]:cuts[i + 1]] for i in range(k)]
 
 
-def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None):
+def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None, announce=0):
+    """announce: 0 = rounds are passed one by one; 1 = every round names the next one's buffer (next_batch), so the ranks
+    tell each other its size ahead; 2 = rank 1 then passes a different buffer than it named (the others must cope)"""
     m = _orc_backend.OracleDeviceMatcher(LIM)
     m.set_sliding_window_size(16)
     m.load_ref(gs[0], load_rc=True)
     runner = RoundRunner(m, rank, world, group, "cpu", lazy=True, emit_params=_orc.emit_params(1))
     runner.start()
+    rounds = []
     for rnd in round_schedule(len(gs) - 1, per_rank, world):
         mine = rnd[rank]
         contigs, tg = [], []
@@ -51,7 +54,12 @@ def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None):
         buf = torch.from_numpy(np.concatenate(contigs).copy())
         offs = np.zeros(len(contigs) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum([c.size for c in contigs])
-        runner.run_round(buf, offs, tg)
+        rounds.append((buf, offs, tg))
+    for i, (buf, offs, tg) in enumerate(rounds):
+        nxt = (rounds[i + 1][0], rounds[i + 1][1]) if announce and i + 1 < len(rounds) else None
+        if announce == 2 and rank == 1 and i > 0:
+            buf = buf.clone()                           # not the buffer named in the round before
+        runner.run_round(buf, offs, tg, next_batch=nxt)
     runner.flush()
     return runner, m
 
@@ -68,11 +76,11 @@ def test_single_process_runner_equals_reference_loop(div, cpt):
     assert m.loaded_ref_length() == loaded and np.array_equal(m.ht(), ht)
 
 
-def _worker(rank, world, port, outdir, div, cpt):
+def _worker(rank, world, port, outdir, div, cpt, announce=0, n=9):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    gs = collection(9, 60_000, div, seed=17)
-    runner, m = run_rank(rank, world, gs, 2, cpt)
+    gs = collection(n, 60_000, div, seed=17)
+    runner, m = run_rank(rank, world, gs, 2, cpt, announce=announce)
     np.save(os.path.join(outdir, "ht%d.npy" % rank), m.ht())
     open(os.path.join(outdir, "pregathers%d" % rank), "w").write("%d %d" % tuple(runner.pregathers))
     if rank == 0:
@@ -106,3 +114,31 @@ def test_world_size_2_gloo(tmp_path, div, cpt):
     assert pg[0] == pg[1]
     if div < 0.005 and cpt == 1:                       # (at 1.2 % every round of this small collection has a retry)
         assert pg[0] == "1 1", pg
+
+
+@pytest.mark.parametrize("announce", [1, 2])
+def test_world_size_2_gloo_with_announced_buffers(tmp_path, announce):
+    """the next round's buffer is named ahead (next_batch): its size rides on the round's length exchange and the
+    extension all-gather starts without an exchange of its own; a rank that then passes another buffer makes all ranks
+    fall back — same bytes either way"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), 0.002, 1, announce, 17), nprocs=2, join=True)
+    gs = collection(17, 60_000, 0.002, seed=17)
+    res, ht, _ = reference_result(gs, 4, 1)
+    for k, v in res["streams"].items():
+        assert (tmp_path / k).read_bytes() == v, k
+    assert (tmp_path / "locks").read_bytes() == res["locks"]
+    assert (tmp_path / "refext").read_bytes() == res["refExtSize"]
+    h0, h1 = np.load(tmp_path / "ht0.npy"), np.load(tmp_path / "ht1.npy")
+    assert np.array_equal(h0, ht) and np.array_equal(h1, ht)
+    pg = [(tmp_path / ("pregathers%d" % r)).read_text() for r in range(2)]
+    assert pg[0] == pg[1]
+    started, used = (int(x) for x in pg[0].split())
+    if announce == 1:
+        assert (started, used) == (3, 3)               # rounds 2..4 of 4
+    else:
+        # round 2: started, found poisoned, everybody falls back — and nobody predicts for round 3; round 4: the same again
+        assert (started, used) == (2, 0)
