@@ -115,8 +115,12 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
                                                       int np, int k1, int k1ord, int K, uint32_t mask, int fpBits,
                                                       const uint32_t *__restrict__ gate) {
     if (gate && *gate == 0) return;
-    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= first[np]) return;
+    const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g0 >= first[np]) return;
+    // The newest samples first: the table keeps the largest key of a bucket, a round's targets share most of their
+    // K-mers, and a sample that finds its bucket already holding a larger key (checked with a plain read below) has
+    // nothing to do — scattered atomics are what this kernel's time is made of (0.28 -> 0.23 ms).
+    const uint64_t g = first[np] - 1 - g0;
     int lo = 0, hi = np;                               // largest p with first[p] <= g
     while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (first[mid] <= g) lo = mid; else hi = mid; }
     const InsertPiece pc = pieces[lo];
@@ -128,6 +132,7 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
     const int nw = K / 4;
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
     const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
+    if (ht[h & mask] >= key) return;                   // (entries only grow: a stale read shows a smaller one at worst, then the atomic decides)
     atomicMax(&ht[h & mask], key);
 }
 
