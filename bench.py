@@ -41,9 +41,9 @@ ALG_BYTES = {"probe": 1.0, "resolve": 4 * 0.29 + 0.918 + 0.23, "stitch": 0.23, "
 QUERY_SCAN_BYTES = 1.0               # moves to "resolve" when no hash kernel ran
 # HBM bytes per input base each family really moves, from the PMC passes in profiles/r01_pmc_hbm_traffic.json
 # (FETCH_SIZE + WRITE_SIZE of its largest launches = rounds of 16 x 5 Mbp, / 80 M bases)
-TRAFFIC = {"probe": (41035.8 + 313186.5) * 1024 / 80e6, "resolve": (2959075.3 + 50815.4) * 1024 / 80e6,
+TRAFFIC = {"probe": (41035.8 + 313186.5) * 1024 / 80e6, "resolve": (2958811.0 + 50837.9) * 1024 / 80e6,
            "stitch": (793.8 + 101.8 + 117.8 + 111.9 + 13241.4 + 18336.5) * 1024 / 80e6, "load": (39692.8 + 78735.5) * 1024 / 80e6,
-           "insert": (40302.3 + 156256.9) * 1024 / 80e6,
+           "insert": (353604.2 + 153432.2) * 1024 / 80e6,
            "emit": (24414.1 + 8602.6 + 1492.6 + 0.0 + 17843.9 + 33364.6 + 62.0 + 1.0 + 9646.2 + 1149.9 + 25.8 + 13.8 + 12625.5 +
                     118.3 + 3.2 + 0.8 + 21404.4 + 16375.0 + 62.4 + 65.3 + 21189.8 + 127.9 + 102860.9 + 16637.0 + 136645.7 +
                     30694.6) * 1024 / 80e6}
