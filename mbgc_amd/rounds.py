@@ -225,7 +225,23 @@ class RoundRunner:
             # the first target (global order) holding a dissimilar contig cuts the round (MGMP.cpp:382-388:
             # "discard, wait until the earlier targets are loaded, retry")
             first_skip_local = min([self.rank * T + targets[c] for c in skipped_local], default=ntot)
-            first_skip = min(x[0] for x in self._allgather_ints([first_skip_local], fixed=True)) if self.world > 1 else first_skip_local
+            merged = None
+            if self.world > 1 and pending and finalized == 0 and len(pending) == ncont:
+                # first pass over the whole round: the skip index travels together with what this rank would load if
+                # nobody skips (one exchange instead of two on the path between pass 1 and the round's finalize)
+                if skipped_local:
+                    pieces, whole = None, False
+                else:
+                    pieces, whole = self._build_pieces(qbuf, offsets, targets, T, unmatched, 0, ntot)
+                got = self._allgather_ints([first_skip_local] + ([x[1] for x in pieces] if pieces is not None else [0] * T) +
+                                           [self._next_announce, 1 if whole else 0], fixed=True)
+                first_skip = min(v[0] for v in got)
+                if first_skip == ntot:
+                    merged = (pieces, [v[1: 1 + T] for v in got], [v[-2] for v in got], [v[-1] for v in got])
+            elif self.world > 1:
+                first_skip = min(x[0] for x in self._allgather_ints([first_skip_local], fixed=True))
+            else:
+                first_skip = first_skip_local
             upto = first_skip                       # targets [finalized, upto) are complete on every rank
             if last is not None and first_skip < ntot:
                 packs.append(self._pack(*last))     # a retry follows: it reuses the emission's buffers, take the streams now
@@ -238,7 +254,7 @@ class RoundRunner:
             if pending and spec_applied:            # (implies: no skip, the whole round) only the bookkeeping is left
                 self._note_finalized(locks, after, before)
             else:
-                self._finalize_range(qbuf, offsets, targets, T, locks, unmatched, finalized, upto, ext_done)
+                self._finalize_range(qbuf, offsets, targets, T, locks, unmatched, finalized, upto, ext_done, merged=merged)
             finalized = upto
             self._learn(offsets, unmatched, skipped_local)
             # the previous round's streams: the second phase of its emission ran beside everything above (two
@@ -325,18 +341,17 @@ class RoundRunner:
         pk["ks"] = [pk["ks"][i] for i in keep]
         return pk
 
-    def _finalize_range(self, qbuf, offsets, targets, T, locks, unmatched, lo, hi, ext_done):
-        """finalizeParallelProcessingOfTarget for the round's targets [lo, hi) in order (MGMP.cpp:433-468)."""
-        if hi <= lo:
-            return
+    def _build_pieces(self, qbuf, offsets, targets, T, unmatched, lo, hi):
+        """extension string of every local target in [lo, hi): contig, then its reverse complement (MGMP.cpp:389-398).
+        Returns (pieces, whole): per target (device pointer, bytes, tensor keeping them alive or None, offset in qbuf or -1);
+        whole = the extensions are exactly this rank's queries, target after target (what _pregather assumed)."""
         m = self.m
-        # extension string of every local target in range: contig, then its reverse complement (:389-398)
         my = [t for t in range(lo, hi) if t // T == self.rank] if self.world > 1 else range(lo, hi)
         by_target = {}
         for c, lt in enumerate(targets):
             by_target.setdefault(lt, []).append(c)
         base_ptr = qbuf.data_ptr()
-        pieces = []                                 # per target: (device pointer, bytes, tensor keeping them alive or None)
+        pieces = []
         for t in my:
             parts = []
             for c in by_target.get(t - self.rank * T, ()):
@@ -355,29 +370,41 @@ class RoundRunner:
             else:                                   # several strings of one target are loaded as one text
                 ext = torch.cat([x[2] if x[2] is not None else qbuf[x[3]: x[3] + x[1]] for x in parts])
                 pieces.append((ext.data_ptr(), ext.numel(), ext, -1))
+        whole = (self.world > 1 and lo == 0 and hi == T * self.world and len(pieces) == T and
+                 all(x[2] is None and x[1] > 0 for x in pieces) and sum(x[1] for x in pieces) == qbuf.numel() and
+                 all(pieces[i][3] + pieces[i][1] == pieces[i + 1][3] for i in range(len(pieces) - 1)) and pieces[0][3] == 0)
+        if self._pre is not None and self._pre.get("poisoned"):
+            whole = False
+        return pieces, whole
+
+    def _finalize_range(self, qbuf, offsets, targets, T, locks, unmatched, lo, hi, ext_done, merged=None):
+        """finalizeParallelProcessingOfTarget for the round's targets [lo, hi) in order (MGMP.cpp:433-468). merged: the
+        whole round's pieces and what every rank said about its own (run_round exchanged them together with the skip
+        index), instead of an exchange here."""
+        if hi <= lo:
+            return
+        if merged is not None:
+            pieces, all_lens, nxt, flags = merged
+        else:
+            pieces, whole = self._build_pieces(qbuf, offsets, targets, T, unmatched, lo, hi)
         # finalize_targets returns with its copies queued: their sources must outlive this function
         self._keep.extend(x[2] for x in pieces if x[2] is not None)
         if self.world == 1:
-            self._finalize_many([x[0] for x in pieces], [x[1] for x in pieces], [locks[t] for t in my])
+            self._finalize_many([x[0] for x in pieces], [x[1] for x in pieces], [locks[t] for t in range(lo, hi)])
             return
-        # this rank's extensions are exactly its queries, target after target (what _pregather assumed)?
-        whole = (lo == 0 and hi == T * self.world and len(pieces) == T and
-                 all(x[2] is None and x[1] > 0 for x in pieces) and sum(x[1] for x in pieces) == qbuf.numel() and
-                 all(pieces[i][3] + pieces[i][1] == pieces[i + 1][3] for i in range(len(pieces) - 1)) and pieces[0][3] == 0)
-        pre, self._pre = self._pre, None
-        if pre is not None and pre.get("poisoned"):
-            whole = False
         whole_round = lo == 0 and hi == T * self.world                                     # then: T targets on every rank
-        all_lens = self._allgather_ints([x[1] for x in pieces] + [self._next_announce if whole_round else -1, 1 if whole else 0, -1],
-                                        fixed=whole_round)                                 # (-1 keeps the tensor non-empty)
-        flags = [l[-2] for l in all_lens]
-        nxt = [l[-3] for l in all_lens]
-        all_lens = [l[:-3] + [-1] for l in all_lens]
+        if merged is None:
+            got = self._allgather_ints([x[1] for x in pieces] + [self._next_announce if whole_round else -1, 1 if whole else 0, -1],
+                                       fixed=whole_round)                                  # (-1 keeps the tensor non-empty)
+            flags = [l[-2] for l in got]
+            nxt = [l[-3] for l in got]
+            all_lens = [l[:-3] for l in got]
+        pre, self._pre = self._pre, None
         self._next_sizes = nxt if whole_round and min(nxt) >= 0 else None
-        self._gpred = all(flags) and lo == 0 and hi == T * self.world
+        self._gpred = all(flags) and whole_round
         if pre is not None:
             pre["work"].wait()                       # (always: the collective was entered by every rank)
-        if pre is not None and all(flags) and all(sum(l[:-1]) == pre["sizes"][r] for r, l in enumerate(all_lens)):
+        if pre is not None and all(flags) and all(sum(l) == pre["sizes"][r] for r, l in enumerate(all_lens)):
             all_ext = [pre["out"][r * pre["mx"]: r * pre["mx"] + pre["sizes"][r]] for r in range(self.world)]
             self._keep.append(pre["out"])
             self.pregathers[1] += 1
