@@ -27,7 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GENOME_LEN = 5_000_000
-MAX_REF_LEN = 1_280_000_000          # 128 files -> referenceFactor 128 -> 128 * 5e6 * 2 (MGMP.cpp:130-158)
+# 128 files -> referenceFactor 128 -> 128 * 5e6 * 2 (MGMP.cpp:130-158). MBGC_BENCH_MAX_REF (diagnostic): a smaller buffer,
+# so that the circular reference wraps inside the run
+MAX_REF_LEN = int(float(os.environ.get("MBGC_BENCH_MAX_REF", 1_280_000_000)))
 ALG_BYTES_PER_BASE = 5.5             # whole path, per input base
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
 # SURVEY.md §8(d) splits that figure by term; per kernel family (bytes per input base of a launch):

@@ -43,7 +43,8 @@ struct RefView {
     uint64_t pos1, refLength, maxRefLength;
     uint32_t mask;
     int fpBits;               // low bits of a table entry that hold the K-mer's fingerprint
-    int fpCheck;              // fingerprints may be used to reject entries (see ht_value)
+    int fpCheck;              // fingerprints may be used to reject entries (see ht_value): 0 no, 1 every entry is as hashed, 2 by epoch
+    uint32_t eCur, ePrev;     // first epoch of the current / of the previous lap of the circular buffer (fpCheck == 2)
     int K, k1ord, skipMargin;
     uint32_t minLen;
 };
@@ -79,10 +80,28 @@ __device__ __forceinline__ uint32_t hash_step(uint32_t h, uint32_t k, uint32_t j
 __device__ __forceinline__ ht_entry ht_key(uint32_t epoch, uint32_t value, uint32_t hash, int fpBits) {
     return ((ht_entry) epoch << (32 + fpBits)) | ((ht_entry) value << fpBits) | (ht_entry) (fpBits ? hash >> (32 - fpBits) : 0u);
 }
-// stored position of an entry, or 0 when the bucket is empty or holds another K-mer's fingerprint
+// stored position of an entry, or 0 when the bucket is empty or holds another K-mer's fingerprint. A fingerprint
+// mismatch only proves anything while the entry's bytes are still the bytes it was hashed from. Once the circular
+// buffer has wrapped that is decided per entry: the loader writes sequentially, so the text below the loading
+// position belongs to the current lap (epochs >= eCur) and the text above it to the previous one (epochs in
+// [ePrev, eCur)); an entry whose epoch is older than its region's lap, or whose K-mer straddles the loading
+// position, may describe overwritten text — the reference would still follow it and compare bytes (golden case
+// rounds3_wrap has such matches) — so it is passed on whatever its fingerprint. Epoch 0 marks the one entry whose
+// K-mer a separator overwrote after it had been hashed (k_mark_stale). (Positions stored after a wrap are one off
+// the sample's, .cpp quirk: the straddle test leaves a byte of margin.)
+// LAPS = false: the caller knows the buffer has not wrapped (fpCheck <= 1; the lap epochs then cost the kernel no registers).
+template <bool LAPS = true>
 __device__ __forceinline__ uint32_t ht_value(const RefView &v, ht_entry e, uint32_t hash) {
     const uint32_t fp = (uint32_t) e & ((1u << v.fpBits) - 1u);
-    if (v.fpCheck && fp != (hash >> (32 - v.fpBits))) return 0u;
+    if (v.fpCheck && fp != (hash >> (32 - v.fpBits))) {
+        const uint32_t epoch = (uint32_t) (e >> (32 + v.fpBits));
+        bool trusted = epoch != 0;
+        if (LAPS && v.fpCheck == 2 && trusted) {
+            const uint64_t p = (uint64_t) (uint32_t) (e >> v.fpBits) << v.k1ord;
+            trusted = p + (uint64_t) v.K + 1 <= v.pos1 ? epoch >= v.eCur : (p >= v.pos1 && epoch >= v.ePrev);
+        }
+        if (trusted) return 0u;
+    }
     return (uint32_t) (e >> v.fpBits);
 }
 

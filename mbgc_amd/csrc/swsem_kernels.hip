@@ -136,6 +136,17 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
     atomicMax(&ht[h & mask], key);
 }
 
+// The K-mer starting at p is about to lose its last byte to a separator (loadSeparator at the window's end, .cpp:439-451)
+// after it may have been hashed: if the table still holds its sample, the entry keeps its position — the reference
+// would still follow it — but its epoch becomes 0 = "do not trust the fingerprint" (ht_value).
+__global__ void k_mark_stale(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht, uint64_t p, int K, int k1ord, uint32_t mask, int fpBits) {
+    uint32_t h = (uint32_t) K;
+    for (int j = 0; j < K / 4; j++) h = hash_step(h, ld_u32(ref + p + 4 * j), (uint32_t) j);
+    const ht_entry e = ht[h & mask];
+    if ((uint32_t) (e >> fpBits) == (uint32_t) (p >> k1ord) && e != 0)
+        ht[h & mask] = e & ((((ht_entry) 1) << (32 + fpBits)) - 1);
+}
+
 __global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict__ ht, uint32_t *__restrict__ out, uint64_t n, int fpBits) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (uint32_t) (ht[i] >> fpBits);
@@ -618,7 +629,7 @@ __device__ __forceinline__ uint32_t window_hash(const RefView &v, const uint8_t 
     return h;
 }
 
-template <bool FLY, class Stack, class Stop = NoStop>
+template <bool FLY, bool LAPS, class Stack, class Stop = NoStop>
 __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ hashes,
                                int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
     const int32_t lane = (int32_t) (threadIdx.x & (WAVE - 1));
@@ -648,7 +659,7 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
             if constexpr (FLY) hf = window_hash(v, q, s, p1 - s < WL ? p1 - s : WL, lane);
             if (lane < WL && pos < p1) {
                 const uint32_t hv = FLY ? hf : hashes[pos];
-                e = ht_value(v, v.ht[hv & v.mask], hv);
+                e = ht_value<LAPS>(v, v.ht[hv & v.mask], hv);
                 if (e != 0) {
                     uint64_t lo, hi;
                     if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;
@@ -703,16 +714,17 @@ __device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, 
 
 // MODE: 0 = dense candidate array (SWSEM_PROBE=dense), 1 = on-demand table lookups from a hash array written ahead
 // (SWSEM_HASH=pre), 2 = on-demand lookups, the windows hash their own K-mers (default)
-template <int MODE, class Stack, class Stop = NoStop>
+// LAPS: the circular buffer has wrapped (ht_value then tells stale entries by their epochs)
+template <int MODE, bool LAPS, class Stack, class Stop = NoStop>
 __device__ __forceinline__ void chain_run(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
                                           int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
-    if constexpr (MODE != 0) run_chain_lazy<MODE == 2>(v, cg, q, cand, p0, p1, stk, ch, stop);
+    if constexpr (MODE != 0) run_chain_lazy<MODE == 2, LAPS>(v, cg, q, cand, p0, p1, stk, ch, stop);
     else run_chain(v, cg, q, cand, p0, p1, stk, ch, stop);
 }
 
 // Sequential resolution (one wave replays a whole contig): the simple form, kept as the cross-check
 // of the block-parallel path (SWSEM_RESOLVE=seq).
-template <int MODE>
+template <int MODE, bool LAPS>
 __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *__restrict__ qbuf,
                                                       const Contig *__restrict__ contigs,
                                                       const uint32_t *__restrict__ cand,
@@ -724,7 +736,7 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
     ArrayStack<Match> stk;
     stk.st = matches + cg.matchBase; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
-    chain_run<MODE>(v, cg, qbuf + cg.qoff, cand + cg.candBase, 0, npos, stk, ch);
+    chain_run<MODE, LAPS>(v, cg, qbuf + cg.qoff, cand + cg.candBase, 0, npos, stk, ch);
     if (threadIdx.x == 0) matchCount[blockIdx.x] = (uint32_t) stk.sp;
 }
 
@@ -760,7 +772,7 @@ __device__ __forceinline__ void snapshot_top(const Row *st, int sp, Match *out) 
 }
 
 // resolve block rbIdx of a contig = tiles [rbIdx*rb, (rbIdx+1)*rb) of it
-template <int MODE>
+template <int MODE, bool LAPS>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RESOLVE_SGPRS))) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ rbContig,
@@ -784,14 +796,14 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     ArrayStack<Row> stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
-    if (b) chain_run<MODE>(v, cg, q, cd, w0 - OVERLAP, w0, stk, ch);   // warm-up on the previous block's tail
+    if (b) chain_run<MODE, LAPS>(v, cg, q, cd, w0 - OVERLAP, w0, stk, ch);   // warm-up on the previous block's tail
     BlockRec r;
     r.scanB = ch.scan > w0 ? ch.scan : w0;
     r.spB = stk.sp;
     __builtin_amdgcn_s_waitcnt(0);            // the wave's own stack rows are read back below
     snapshot_top(stk.st, stk.sp, r.bTop);
     ch.minTouched = 0x7fffffff; ch.minKeep = stk.sp; ch.visited = 0;
-    chain_run<MODE>(v, cg, q, cd, w0, w1, stk, ch);
+    chain_run<MODE, LAPS>(v, cg, q, cd, w0, w1, stk, ch);
     r.scanF = ch.scan;
     r.spF = stk.sp;
     r.minTouched = ch.visited ? ch.minTouched : 0x7fffffff;
@@ -857,7 +869,7 @@ __global__ void __launch_bounds__(256) k_stitch_pre(const Contig *__restrict__ c
 // contig's match count. The walk is a dependent chain executed by a single wave, so everything in it
 // is either scalar (readfirstlane'd record fields) or one lane-parallel LDS operation: the newest
 // SNAP true rows live in LDS as 3*SNAP u64 words and are compared / rebuilt by 3*SNAP lanes at once.
-template <int MODE>
+template <int MODE, bool LAPS>
 __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__restrict__ qbuf,
                                                  const Contig *__restrict__ contigs, const uint32_t *__restrict__ cand,
                                                  Row *__restrict__ regions, Row *__restrict__ replayArea,
@@ -1017,7 +1029,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
                     (int32_t) rfl32((uint32_t) spec[sp].scanAfter) == ch.scan) { syncAt = sp; return true; }
                 return false;
             };
-            chain_run<MODE>(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch, stop);
+            chain_run<MODE, LAPS>(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch, stop);
             int n = vs.ownN;
             vs.size_ -= n; vs.ownN = 0; vs.own = nullptr;
             __builtin_amdgcn_s_waitcnt(0);

@@ -84,7 +84,8 @@ struct swsem {
     bool circular = true;
     std::deque<uint64_t> locks;            // workersSwEndPositions
     uint32_t epoch = 1;
-    bool pristine = true;                  // no byte of the buffer has been rewritten after it was hashed (no wrap yet)
+    uint32_t eCur = 0, ePrev = 0;          // first epoch of the current / previous lap (ht_value's staleness test)
+    bool pristine = true;                  // the loader has only moved forward (wraps included: told by epochs); false after swsem_set_position
     int fpBits = 0;                        // fingerprint bits of a table entry: what the bucket index leaves of the 32-bit hash, at most 8
     uint64_t hostProbes = 0;               // query positions of the batch (what the hash kernel counts when there is one)
     bool flyHash = true;                   // lazy chains hash their scan windows themselves (SWSEM_HASH=pre: a hash array written ahead)
@@ -200,7 +201,7 @@ struct swsem {
     RefView view() const {
         RefView v;
         v.ref = ref; v.ht = ht; v.pos1 = (uint64_t) pos1; v.refLength = refLength(); v.maxRefLength = maxRefLength;
-        v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? 1 : 0; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
+        v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? (laps ? 2 : 1) : 0; v.eCur = eCur; v.ePrev = ePrev; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
         return v;
     }
     // event pairs are recycled: creating events by the hundred makes the runtime grow its signal pool now and
@@ -318,7 +319,7 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
     while (len != 0) {
         if ((uint64_t) h->pos1 == h->maxRefLength && h->swEnd != h->maxRefLength) {
             h->laps++;
-            h->pristine = false;
+            h->ePrev = h->eCur; h->eCur = h->epoch;                    // (entries of older laps are told by their epochs, ht_value)
             h->pos1 = REF_SHIFT;
             h->samplingPos = REF_SHIFT;
         }
@@ -584,7 +585,10 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     }
     if ((r = zero_dev(h, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) || (r = flush_copies(h))) return r;
     const RefView v = h->view();
-    const int mode = h->lazyProbe ? (h->flyHash ? 2 : 1) : 0;       // template argument of the chain kernels (swsem_kernels.hip: chain_run)
+    const int mode = h->lazyProbe ? (h->flyHash ? 2 : 1) : 0;       // template arguments of the chain kernels (swsem_kernels.hip: chain_run)
+    const bool wrapped = v.fpCheck == 2;
+#define SWSEM_BY_MODE(L) do { if (wrapped) { if (mode == 2) L(2, true); else if (mode == 1) L(1, true); else L(0, true); } \
+                              else { if (mode == 2) L(2, false); else if (mode == 1) L(1, false); else L(0, false); } } while (0)
     // hashes announced ahead for exactly these buffers: adopt them
     const bool adopted = h->prepValid && h->lazyProbe && h->prepQ == qdev && h->prepOffsets.size() == (size_t) n + 1 &&
                          std::equal(h->prepOffsets.begin(), h->prepOffsets.end(), offsets);
@@ -600,9 +604,9 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     }
     if (h->seqResolve || tiles == 0) {
         h->mark(SWSEM_K_RESOLVE, true);
-        if (mode == 2) k_resolve_seq<2><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
-        else if (mode == 1) k_resolve_seq<1><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
-        else k_resolve_seq<0><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p);
+#define SWSEM_LAUNCH_SEQ(M, W) k_resolve_seq<M, W><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p)
+        SWSEM_BY_MODE(SWSEM_LAUNCH_SEQ);
+#undef SWSEM_LAUNCH_SEQ
         h->mark(SWSEM_K_RESOLVE, false);
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
@@ -616,22 +620,23 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if ((r = h->dDstOff.reserve(rblocks))) return r;
         if ((r = h->dPrev.reserve(rblocks))) return r;
         h->mark(SWSEM_K_RESOLVE, true);
-#define SWSEM_LAUNCH_RB(M) k_resolve_blocks<M><<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p, \
+#define SWSEM_LAUNCH_RB(M, W) k_resolve_blocks<M, W><<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p, \
                                                                                       h->dRegions.p, cap, h->rb, h->dRecs.p)
-        if (mode == 2) SWSEM_LAUNCH_RB(2); else if (mode == 1) SWSEM_LAUNCH_RB(1); else SWSEM_LAUNCH_RB(0);
+        SWSEM_BY_MODE(SWSEM_LAUNCH_RB);
 #undef SWSEM_LAUNCH_RB
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
         k_stitch_pre<<<dim3((rblocks + 255) / 256), dim3(256), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRecs.p, h->rb, rblocks, h->dFast.p);
-#define SWSEM_LAUNCH_ST(M) k_stitch<M><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, \
+#define SWSEM_LAUNCH_ST(M, W) k_stitch<M, W><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, \
                                                                       h->dRecs.p, h->dFast.p, h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p, \
                                                                       h->dMatchCount.p, h->dStats.p)
-        if (mode == 2) SWSEM_LAUNCH_ST(2); else if (mode == 1) SWSEM_LAUNCH_ST(1); else SWSEM_LAUNCH_ST(0);
+        SWSEM_BY_MODE(SWSEM_LAUNCH_ST);
 #undef SWSEM_LAUNCH_ST
         k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
                                                             h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
         h->mark(SWSEM_K_STITCH, false);
     }
+#undef SWSEM_BY_MODE
     HIPCHK(hipGetLastError());
     std::swap(h->evMatched, h->evMatchedPrev);
     HIPCHK(hipEventRecord(h->evMatched, h->stream));
@@ -895,17 +900,19 @@ int swsem_load_separator(swsem_t *h, int sep) {
     HIPCHK(hipSetDevice(h->device));
     if ((uint64_t) h->pos1 == h->maxRefLength && h->swEnd != h->maxRefLength) {
         h->laps++;
-        h->pristine = false;
+        h->ePrev = h->eCur; h->eCur = h->epoch;
         h->pos1 = REF_SHIFT;
         h->samplingPos = REF_SHIFT;
     }
     if ((uint64_t) h->pos1 == h->maxRefLength) return SWSEM_OK;
     { int g = ref_write_guard(h, (uint64_t) h->pos1 == h->swEnd ? (uint64_t) h->pos1 - 1 : (uint64_t) h->pos1); if (g) return g; }
     if ((uint64_t) h->pos1 == h->swEnd) {
-        // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was
-        h->pristine = false;
+        // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was, and so was
+        // the one sample whose K-mer ends there, if it has been inserted: its entry stops being trusted (k_mark_stale)
         if (h->specMode) return SWSEM_ESPEC;                      // an ungated write in the middle: give the speculation up
         if (h->deferInserts) { int r = flush_inserts(h); if (r) return r; }
+        if (h->pos1 >= (int64_t) h->K + REF_SHIFT)
+            k_mark_stale<<<1, 1, 0, h->stream>>>(h->ref, h->ht, (uint64_t) (h->pos1 - h->K), h->K, h->k1ord, h->mask, h->fpBits);
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1 - 1, (uint8_t) sep);
     } else if (h->deferInserts) {
         BytePiece bp; bp.off = (uint64_t) h->pos1++; bp.val = (uint64_t) (uint8_t) sep;
@@ -1256,11 +1263,11 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     // prediction — so the copies and the table insertion start the moment pass 1 ends instead of after the host's
     // round trip. The host comes to the same verdict from the values pass 1 hands back and keeps or undoes its
     // bookkeeping accordingly; when the prediction fails nothing on the device has changed.
-    struct { int64_t pos1; int laps; uint64_t samplingPos, swEnd; uint32_t epoch; bool pristine; std::deque<uint64_t> locks; } snap;
+    struct { int64_t pos1; int laps; uint64_t samplingPos, swEnd; uint32_t epoch, eCur, ePrev; bool pristine; std::deque<uint64_t> locks; } snap;
     bool queued = false;
     HT("spec begin");
     if (spec && spec->ntargets > 0) {
-        snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch;
+        snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch; snap.eCur = h->eCur; snap.ePrev = h->ePrev;
         snap.pristine = h->pristine; snap.locks = h->locks;
         k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, h->dGate.p);
         h->specMode = true;
@@ -1270,7 +1277,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (r == SWSEM_ESPEC) r = SWSEM_OK;                         // not possible this time: nothing was queued
         else if (r) return r;
         else queued = true;
-        if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch;
+        if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev;
                        h->pristine = snap.pristine; h->locks = snap.locks; }
     }
     HT("spec queued, waiting");
@@ -1286,7 +1293,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
                  (un * (uint64_t) spec->rcFactor > len) == (spec->predRC[k] != 0);
         }
         if (ok) { if (applied) *applied = 1; }
-        else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch;
+        else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev;
                h->pristine = snap.pristine; h->locks = snap.locks; }
     }
     return SWSEM_OK;
