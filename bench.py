@@ -30,6 +30,20 @@ GENOME_LEN = 5_000_000
 # 128 files -> referenceFactor 128 -> 128 * 5e6 * 2 (MGMP.cpp:130-158). MBGC_BENCH_MAX_REF (diagnostic): a smaller buffer,
 # so that the circular reference wraps inside the run
 MAX_REF_LEN = int(float(os.environ.get("MBGC_BENCH_MAX_REF", 1_280_000_000)))
+
+
+def ref_length_limit(files_count, basic_len):
+    """the reference buffer `mbgc c` derives for a collection (loadG0Ref MGMP.cpp:130-134, initMatcher :152-168; -m1, RC
+    in the reference, circular): 129 files of 5 Mbp give configs[1]'s 1.28e9 bytes; the larger collections of the
+    weak-scaling runs (N x 128 targets) get what the tool would give them (2.56e9 for 257..2048 files)."""
+    clz = 32 - int(files_count).bit_length()
+    factor = 1 << min(12, max(5, 15 - clz // 3))
+    lim = factor * max(basic_len, 1 << 21) * 2
+    if lim > (0xFFFFFFFF << 8):
+        lim = 0xFFFFFFFF << 8
+    if lim > 0xFFFFFFFF:
+        lim = 0xFFFFFFFF + (lim - 0xFFFFFFFF) // 16
+    return lim
 ALG_BYTES_PER_BASE = 5.5             # SURVEY.md §8(d): whole path, per input base
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
 # SURVEY.md §8(d) splits that figure by term; per kernel family (bytes per input base of a launch):
@@ -139,7 +153,8 @@ def main():
     R, steps, warm = args.round, args.steps, args.warmup
     n_targets = (steps + warm) * R * world
     base = synth.base_codes(args.length)
-    m = binding.SlidingWindowSparseEMMatcher(MAX_REF_LEN, device=local_rank)
+    max_ref = MAX_REF_LEN if world == 1 or "MBGC_BENCH_MAX_REF" in os.environ else ref_length_limit(1 + n_targets, args.length)
+    m = binding.SlidingWindowSparseEMMatcher(max_ref, device=local_rank)
     stream = torch.cuda.current_stream()
     m.set_stream(stream.cuda_stream)
     m.set_sliding_window_size(16)
@@ -249,10 +264,10 @@ def main():
             "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[1]: 128 synthetic 5 Mbp genomes @99%% identity, 1.28e9-byte reference; step = "
+            "config": {"workload": ("configs[1]: %d synthetic 5 Mbp genomes @99%% identity, %.3g-byte reference; step = "
                                     "matchTexts%s + loadRef of one round of %d targets/GPU") %
-                                   (" + processMatches (six streams, gathered to rank 0)" if emit else "", R),
-                       "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": MAX_REF_LEN,
+                                   (128 * world, float(max_ref), " + processMatches (six streams, gathered to rank 0)" if emit else "", R),
+                       "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": max_ref,
                        "hash_entries": m.hash_size(), "sharding": "file-per-GPU, all-gather of extensions"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
