@@ -63,7 +63,7 @@ TRAFFIC = {"probe": (41035.8 + 313186.5) * 1024 / 80e6, "resolve": (2958811.0 + 
            "emit": (24414.1 + 8602.6 + 1492.6 + 0.0 + 17843.9 + 33364.6 + 62.0 + 1.0 + 9646.2 + 1149.9 + 25.8 + 13.8 + 12625.5 +
                     118.3 + 3.2 + 0.8 + 21404.4 + 16375.0 + 62.4 + 65.3 + 21189.8 + 127.9 + 102860.9 + 16637.0 + 136645.7 +
                     30694.6) * 1024 / 80e6}
-KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query, SWSEM_HASH=pre only)", "resolve": "k_resolve_blocks<2>",
+KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query, SWSEM_HASH=pre only)", "resolve": "k_resolve_blocks<2, false>",
              "stitch": "k_stitch_pre + k_stitch + k_gather", "load": "k_copy_multi", "insert": "k_insert_multi",
              "emit": "k_emit_* (13 launches)"}
 
