@@ -201,6 +201,8 @@ int swsem_dev_copy(swsem_t *h, void *dst_dev, const void *src_dev, uint64_t byte
 
 /* ---- test / measurement hooks (not part of the reference surface) */
 int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out);      /* getRef() bytes, .h:104 */
+/* overwrites n reference bytes from `from` (tests: what an emission must not depend on is filled with garbage) */
+int swsem_debug_write_ref(swsem_t *h, uint64_t from, uint64_t n, const uint8_t *in);
 int swsem_debug_copy_ht(swsem_t *h, uint32_t *out /* [hash_size] 32-bit image as on the CPU */);
 enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2, SWSEM_K_EMIT2 = 3, SWSEM_K_RESOLVE = 4,
        SWSEM_K_STITCH = 5, SWSEM_K_EMIT = 6, SWSEM_K_COUNT = 7 };

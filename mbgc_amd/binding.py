@@ -21,7 +21,7 @@ swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circula
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_hash_batch_dev swsem_batch_counts swsem_batch_matches
-swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_copy_ht
+swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_write_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_copy""".split()
 
 
@@ -116,6 +116,7 @@ def lib():
         L.swsem_emit_pack_dev.argtypes = [vp, vp, u64, pu64, pu64]
         L.swsem_emit_unmatched.argtypes = [vp, pu64]
         L.swsem_debug_copy_ref.argtypes = [vp, u64, u64, vp]
+        L.swsem_debug_write_ref.argtypes = [vp, u64, u64, vp]
         L.swsem_debug_copy_ht.argtypes = [vp, vp]
         L.swsem_profile_enable.argtypes = [vp, ci]
         L.swsem_profile_get.argtypes = [vp, C.POINTER(C.c_double), pu64]
@@ -331,6 +332,10 @@ class SlidingWindowSparseEMMatcher:
         out = np.zeros(n, dtype=np.uint8)
         _chk(lib().swsem_debug_copy_ref(self.h, start, n, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def write_ref(self, start, data):
+        a = np.ascontiguousarray(data, dtype=np.uint8)
+        _chk(lib().swsem_debug_write_ref(self.h, start, a.size, a.ctypes.data_as(C.c_void_p)))
 
     def ht(self):
         out = np.zeros(self.hash_size(), dtype=np.uint32)

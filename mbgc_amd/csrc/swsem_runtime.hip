@@ -146,6 +146,8 @@ struct swsem {
         hipEvent_t evDone = nullptr;
         bool outstanding = false, refGuarded = false;
         uint64_t emitPos1 = 0;               // loading position the emission started at
+        uint64_t lockMin = UINT64_MAX;       // lowest matching-lock position of its contigs (UINT64_MAX: some contig had none)
+        int emitLaps = 0;                    // laps of the buffer when it started
         int emitN = 0;
         uint8_t *pinE = nullptr; size_t pinECap = 0;
         std::vector<uint8_t> hostStreams;
@@ -300,17 +302,30 @@ int insert_samples(swsem *h) {
     return SWSEM_OK;
 }
 
-// An emission whose second phase is still running reads reference bytes next to its matches, all of them
-// below the loading position it started at. While the buffer has never wrapped, a load that only appends
-// (first byte written >= that position) cannot touch them, so finalize may run beside the emission; a
-// write below it (the separator that replaces the last loaded byte when the loader reaches the window's
-// end) or any write after a wrap (old text is overwritten) waits for the emission instead.
-int ref_write_guard(swsem *h, uint64_t firstByte) {
-    for (auto &E : h->slot)
-        if (E.outstanding && (h->laps > 0 || firstByte < E.emitPos1) && !E.refGuarded) {
+// An emission whose second phase is still running reads reference bytes next to its matches. It never reads inside
+// its own lock window [loading position it started at, its matching-lock position): candidates there were refused
+// at match time (.cpp:212-220), pairs do not span the lock (TextMatchers.h:46-50), the right extension stops at the
+// loading position and the left one at the lock (ENC.cpp:318-335, :379-384) — that window exists so that the
+// reference's loader can write while its workers read, and loadRef never writes beyond it (.cpp:408-414). So a write
+// that stays inside an emission's window runs beside it, wrap or not (tests/test_gpu_lock_window.py fills the window
+// with garbage and emits again: same bytes); any other write — the separator that replaces the last loaded byte at
+// the window's end, a write outside the window of an older emission, contigs without a lock — waits for the emission.
+int ref_write_guard(swsem *h, uint64_t firstByte, uint64_t lastByte) {
+    for (auto &E : h->slot) {
+        if (!E.outstanding || E.refGuarded) continue;
+        bool inside = false;
+        if (E.lockMin != UINT64_MAX && firstByte >= REF_SHIFT && lastByte >= firstByte) {
+            if (E.lockMin > E.emitPos1)                              // window [emitPos1, lockMin)
+                inside = h->laps == E.emitLaps && firstByte >= E.emitPos1 && lastByte < E.lockMin;
+            else                                                     // it wraps: [emitPos1, end) and, a lap later, [1, lockMin)
+                inside = (h->laps == E.emitLaps && firstByte >= E.emitPos1) || (h->laps == E.emitLaps + 1 && lastByte < E.lockMin);
+        }
+        const bool appendOnly = h->laps == 0 && firstByte >= E.emitPos1;   // nothing was ever written there: nothing to read
+        if (!inside && !appendOnly) {
             HIPCHK(hipStreamWaitEvent(h->stream, E.evDone, 0));
             E.refGuarded = true;
         }
+    }
     return SWSEM_OK;
 }
 
@@ -323,12 +338,17 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
             h->pos1 = REF_SHIFT;
             h->samplingPos = REF_SHIFT;
         }
-        int g = ref_write_guard(h, (uint64_t) h->pos1 < h->swEnd ? (uint64_t) h->pos1 : h->swEnd - 1);
-        if (g) return g;
         const uint64_t tmpEnd = h->swEnd;
         uint64_t tmpLength = len;
         const uint64_t tmpMax = tmpEnd < (uint64_t) h->pos1 ? h->maxRefLength : tmpEnd;
         if ((uint64_t) h->pos1 + tmpLength > tmpMax) tmpLength = tmpMax - (uint64_t) h->pos1;
+        {
+            // bytes this step writes: the copy, and the separator at the window's end when the copy reaches it
+            const uint64_t first = (uint64_t) h->pos1 < h->swEnd ? (uint64_t) h->pos1 : h->swEnd - 1;
+            const uint64_t last = tmpLength ? (uint64_t) h->pos1 + tmpLength - 1 : first;
+            int g = ref_write_guard(h, first, last);
+            if (g) return g;
+        }
         if (tmpLength && !rc && h->deferInserts) {                  // (nothing is launched here: no profiling bracket)
             CopyPiece cp; cp.dst = (uint64_t) h->pos1; cp.src = text; cp.len = tmpLength;
             h->pendingCopies.push_back(cp);
@@ -367,11 +387,13 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     const size_t np = h->pendingPieces.size(), nc = h->pendingCopies.size(), nb = h->pendingBytes.size();
     if (!np && !nc && !nb) return SWSEM_OK;
     {
-        uint64_t lowest = UINT64_MAX;
-        for (auto &c : h->pendingCopies) lowest = std::min(lowest, c.dst);
-        for (auto &b : h->pendingBytes) lowest = std::min(lowest, b.off);
-        int g = ref_write_guard(h, lowest);
-        if (g) return g;
+        uint64_t lowest = UINT64_MAX, highest = 0;
+        for (auto &c : h->pendingCopies) { lowest = std::min(lowest, c.dst); highest = std::max(highest, c.dst + c.len - 1); }
+        for (auto &b : h->pendingBytes) { lowest = std::min(lowest, b.off); highest = std::max(highest, b.off); }
+        if (lowest != UINT64_MAX) {
+            int g = ref_write_guard(h, lowest, highest);
+            if (g) return g;
+        }
     }
     constexpr uint64_t CHUNK = 256 * 16;                 // bytes per copy block
     const size_t wPieces = np * (sizeof(InsertPiece) / 8), wCopies = nc * (sizeof(CopyPiece) / 8), wBytes = nb * (sizeof(BytePiece) / 8);
@@ -905,7 +927,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
         h->samplingPos = REF_SHIFT;
     }
     if ((uint64_t) h->pos1 == h->maxRefLength) return SWSEM_OK;
-    { int g = ref_write_guard(h, (uint64_t) h->pos1 == h->swEnd ? (uint64_t) h->pos1 - 1 : (uint64_t) h->pos1); if (g) return g; }
+    { const uint64_t at = (uint64_t) h->pos1 == h->swEnd ? (uint64_t) h->pos1 - 1 : (uint64_t) h->pos1; int g = ref_write_guard(h, at, at); if (g) return g; }
     if ((uint64_t) h->pos1 == h->swEnd) {
         // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was, and so was
         // the one sample whose K-mer ends there, if it has been inserted: its entry stops being trusted (k_mark_stale)
@@ -1049,6 +1071,14 @@ int swsem_revcomp_dev(swsem_t *h, const uint8_t *src_dev, uint64_t n, uint8_t *d
 int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->ref + from, n, hipMemcpyDeviceToHost));
+    return SWSEM_OK;
+}
+
+int swsem_debug_write_ref(swsem_t *h, uint64_t from, uint64_t n, const uint8_t *in) {
+    if (from + n > h->maxRefLength) return fail(SWSEM_EINVAL, "swsem_debug_write_ref: beyond the buffer");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    HIPCHK(hipMemcpy(h->ref + from, in, n, hipMemcpyHostToDevice));
     return SWSEM_OK;
 }
 
@@ -1257,6 +1287,13 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     HIPCHK(hipEventRecord(E.evDone, h->stream2));
     h->latest = si; h->selected = -1;
     E.outstanding = true; E.refGuarded = false; E.emitN = n; E.emitPos1 = (uint64_t) h->pos1;
+    E.emitLaps = h->laps;
+    E.lockMin = UINT64_MAX;
+    {
+        uint64_t lm = UINT64_MAX; bool all = true;
+        for (int k = 0; k < n; k++) { if (E.ecg[k].lock == UINT64_MAX) all = false; else lm = std::min(lm, E.ecg[k].lock); }
+        if (all) E.lockMin = lm;
+    }
     E.packedBytes = 0; E.hostStreamsValid = false;
     // Speculative finalize: the round's loadRef / loadSeparator / lock releases are worked out on the host now, under
     // the caller's prediction of every contig's extension decision, and queued behind a device-side check of that
