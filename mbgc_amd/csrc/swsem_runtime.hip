@@ -85,6 +85,11 @@ struct swsem {
     std::deque<uint64_t> locks;            // workersSwEndPositions
     uint32_t epoch = 1;
     uint32_t eCur = 0, ePrev = 0;          // first epoch of the current / previous lap (ht_value's staleness test)
+    // the separator at the window's end (the byte before the loading position, when the loader stands at the window's
+    // end) has been written with this value at this position in this lap: writing it again changes nothing
+    int64_t sepEndPos = -1; int sepEndLaps = -1, sepEndVal = -1;
+    bool sep_end_done(int sep) const { return pos1 == sepEndPos && laps == sepEndLaps && sep == sepEndVal; }
+    void sep_end_set(int64_t at, int sep) { sepEndPos = at; sepEndLaps = laps; sepEndVal = sep; }
     bool pristine = true;                  // the loader has only moved forward (wraps included: told by epochs); false after swsem_set_position
     int fpBits = 0;                        // fingerprint bits of a table entry: what the bucket index leaves of the 32-bit hash, at most 8
     uint64_t hostProbes = 0;               // query positions of the batch (what the hash kernel counts when there is one)
@@ -362,9 +367,11 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
                 HIPCHK(hipMemcpyAsync(h->ref + h->pos1, text, tmpLength, hipMemcpyDeviceToDevice, h->stream));
             h->mark(SWSEM_K_LOAD, false);
         }
-        if (addSep && (uint64_t) h->pos1 + tmpLength == h->swEnd) {
+        if (addSep && (uint64_t) h->pos1 + tmpLength == h->swEnd && !(tmpLength == 0 && h->sep_end_done(sep))) {
+            // (with the window full every target of a round comes by here and through loadSeparator's same case: once is enough)
             if (h->deferInserts) { BytePiece bp; bp.off = h->swEnd - 1; bp.val = (uint64_t) (uint8_t) sep; h->pendingBytes.push_back(bp); }
             else k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->swEnd - 1, (uint8_t) sep);
+            h->sep_end_set((int64_t) h->swEnd, sep);
         }
         h->pos1 += (int64_t) tmpLength;
         int r = insert_samples(h);
@@ -927,6 +934,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
         h->samplingPos = REF_SHIFT;
     }
     if ((uint64_t) h->pos1 == h->maxRefLength) return SWSEM_OK;
+    if ((uint64_t) h->pos1 == h->swEnd && h->sep_end_done(sep)) return SWSEM_OK;    // that byte already is this separator
     { const uint64_t at = (uint64_t) h->pos1 == h->swEnd ? (uint64_t) h->pos1 - 1 : (uint64_t) h->pos1; int g = ref_write_guard(h, at, at); if (g) return g; }
     if ((uint64_t) h->pos1 == h->swEnd) {
         // this overwrites the last byte already loaded: insertion phases still pending hashed it as it was, and so was
@@ -936,6 +944,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
         if (h->pos1 >= (int64_t) h->K + REF_SHIFT)
             k_mark_stale<<<1, 1, 0, h->stream>>>(h->ref, h->ht, (uint64_t) (h->pos1 - h->K), h->K, h->k1ord, h->mask, h->fpBits);
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1 - 1, (uint8_t) sep);
+        h->sep_end_set(h->pos1, sep);
     } else if (h->deferInserts) {
         BytePiece bp; bp.off = (uint64_t) h->pos1++; bp.val = (uint64_t) (uint8_t) sep;
         h->pendingBytes.push_back(bp);
@@ -1300,11 +1309,11 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     // prediction — so the copies and the table insertion start the moment pass 1 ends instead of after the host's
     // round trip. The host comes to the same verdict from the values pass 1 hands back and keeps or undoes its
     // bookkeeping accordingly; when the prediction fails nothing on the device has changed.
-    struct { int64_t pos1; int laps; uint64_t samplingPos, swEnd; uint32_t epoch, eCur, ePrev; bool pristine; std::deque<uint64_t> locks; } snap;
+    struct { int64_t pos1, sepEndPos; int laps, sepEndLaps, sepEndVal; uint64_t samplingPos, swEnd; uint32_t epoch, eCur, ePrev; bool pristine; std::deque<uint64_t> locks; } snap;
     bool queued = false;
     HT("spec begin");
     if (spec && spec->ntargets > 0) {
-        snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch; snap.eCur = h->eCur; snap.ePrev = h->ePrev;
+        snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch; snap.eCur = h->eCur; snap.ePrev = h->ePrev; snap.sepEndPos = h->sepEndPos; snap.sepEndLaps = h->sepEndLaps; snap.sepEndVal = h->sepEndVal;
         snap.pristine = h->pristine; snap.locks = h->locks;
         k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, h->dGate.p);
         h->specMode = true;
@@ -1314,7 +1323,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (r == SWSEM_ESPEC) r = SWSEM_OK;                         // not possible this time: nothing was queued
         else if (r) return r;
         else queued = true;
-        if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev;
+        if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
                        h->pristine = snap.pristine; h->locks = snap.locks; }
     }
     HT("spec queued, waiting");
@@ -1330,7 +1339,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
                  (un * (uint64_t) spec->rcFactor > len) == (spec->predRC[k] != 0);
         }
         if (ok) { if (applied) *applied = 1; }
-        else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev;
+        else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
                h->pristine = snap.pristine; h->locks = snap.locks; }
     }
     return SWSEM_OK;
