@@ -45,6 +45,7 @@ struct RefView {
     int fpBits;               // low bits of a table entry that hold the K-mer's fingerprint
     int fpCheck;              // fingerprints may be used to reject entries (see ht_value): 0 no, 1 every entry is as hashed, 2 by epoch
     uint32_t eCur, ePrev;     // first epoch of the current / of the previous lap of the circular buffer (fpCheck == 2)
+    uint32_t curMax, prevMin; // entry values (position >> k1ord) up to curMax lie wholly below the loading position, from prevMin on at or above it
     int K, k1ord, skipMargin;
     uint32_t minLen;
 };
@@ -97,8 +98,8 @@ __device__ __forceinline__ uint32_t ht_value(const RefView &v, ht_entry e, uint3
         const uint32_t epoch = (uint32_t) (e >> (32 + v.fpBits));
         bool trusted = epoch != 0;
         if (LAPS && v.fpCheck == 2 && trusted) {
-            const uint64_t p = (uint64_t) (uint32_t) (e >> v.fpBits) << v.k1ord;
-            trusted = p + (uint64_t) v.K + 1 <= v.pos1 ? epoch >= v.eCur : (p >= v.pos1 && epoch >= v.ePrev);
+            const uint32_t val = (uint32_t) (e >> v.fpBits);
+            trusted = val <= v.curMax ? epoch >= v.eCur : (val >= v.prevMin && epoch >= v.ePrev);
         }
         if (trusted) return 0u;
     }

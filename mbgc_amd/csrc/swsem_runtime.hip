@@ -208,7 +208,10 @@ struct swsem {
     RefView view() const {
         RefView v;
         v.ref = ref; v.ht = ht; v.pos1 = (uint64_t) pos1; v.refLength = refLength(); v.maxRefLength = maxRefLength;
-        v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? (laps ? 2 : 1) : 0; v.eCur = eCur; v.ePrev = ePrev; v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
+        v.mask = mask; v.fpBits = fpBits; v.fpCheck = (fpBits && pristine) ? (laps ? 2 : 1) : 0; v.eCur = eCur; v.ePrev = ePrev;
+        // (position << k1ord) + K + 1 <= pos1  <=>  value <= curMax;   (position << k1ord) >= pos1  <=>  value >= prevMin
+        v.curMax = pos1 >= (int64_t) K + 1 ? (uint32_t) (((uint64_t) pos1 - K - 1) >> k1ord) : 0u;
+        v.prevMin = (uint32_t) ((((uint64_t) pos1) + (1ull << k1ord) - 1) >> k1ord); v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
         return v;
     }
     // event pairs are recycled: creating events by the hundred makes the runtime grow its signal pool now and
