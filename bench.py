@@ -153,7 +153,8 @@ def main():
     R, steps, warm = args.round, args.steps, args.warmup
     n_targets = (steps + warm) * R * world
     base = synth.base_codes(args.length)
-    max_ref = MAX_REF_LEN if world == 1 or "MBGC_BENCH_MAX_REF" in os.environ else ref_length_limit(1 + n_targets, args.length)
+    # the buffer `mbgc c` would give this collection (129 files at the defaults: configs[1]'s 1.28e9 bytes)
+    max_ref = MAX_REF_LEN if "MBGC_BENCH_MAX_REF" in os.environ else ref_length_limit(1 + n_targets, args.length)
     m = binding.SlidingWindowSparseEMMatcher(max_ref, device=local_rank)
     stream = torch.cuda.current_stream()
     m.set_stream(stream.cuda_stream)
@@ -197,7 +198,7 @@ def main():
         runner.run_round(*bufs[s], next_batch=bufs[s + 1] if s + 1 < len(bufs) else None)
         runner.flush()
         if args.check and s == 0 and rank == 0 and world == 1:
-            check_against_oracle(runner, base, sched[0][0], args.length, emit)
+            check_against_oracle(runner, base, sched[0][0], args.length, emit, max_ref)
         runner.keep_streams = False
     m.profile_enable(True)
     barrier()
@@ -266,7 +267,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("configs[1]: %d synthetic 5 Mbp genomes @99%% identity, %.3g-byte reference; step = "
                                     "matchTexts%s + loadRef of one round of %d targets/GPU") %
-                                   (128 * world, float(max_ref), " + processMatches (six streams, gathered to rank 0)" if emit else "", R),
+                                   (n_targets, float(max_ref), " + processMatches (six streams, gathered to rank 0)" if emit else "", R),
                        "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": max_ref,
                        "hash_entries": m.hash_size(), "sharding": "file-per-GPU, all-gather of extensions"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
@@ -288,14 +289,14 @@ def main():
         dist.destroy_process_group()
 
 
-def check_against_oracle(runner, base, targets, length, emit):
+def check_against_oracle(runner, base, targets, length, emit, max_ref):
     """first round: the six streams (or, matcher only, the hash-table image) against the oracle driven
     through the reference's target loop (tests/_driver.py)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _driver
     import _orc
     from mbgc_amd import synth
-    o = _orc.OracleMatcher(MAX_REF_LEN)
+    o = _orc.OracleMatcher(max_ref)
     if emit:
         res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [synth.genome(base, 0)],
                                     [[synth.genome(base, 1 + t)] for t in targets], len(targets))
