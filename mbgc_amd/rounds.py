@@ -10,6 +10,8 @@ the all-gather of the extension bytes and the gather of the emitted stream bytes
 feeds the (unchanged, host-side) PPMd/LZMA backend: RCCL over xGMI on GPUs, gloo in the CPU tests.
 
 PyTorch is plumbing only: device buffers, the process group and the collectives."""
+import os
+
 import numpy as np
 import torch
 
@@ -121,7 +123,7 @@ class RoundRunner:
         round's decisions come out the same on every rank, and falls back to the ordinary exchange otherwise."""
         self._pre = None
         announced, self._next_sizes = self._next_sizes, None           # (valid for this round only)
-        if self.world == 1 or not self._gpred or self.p is None:
+        if self.world == 1 or not self._gpred or self.p is None or os.environ.get("MBGC_ROUNDS_PREGATHER", "1") == "0":
             return
         ncont = len(offsets) - 1
         usable = not (int(offsets[0]) != 0 or int(offsets[-1]) != qbuf.numel() or
