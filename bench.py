@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: input Gbases/s of the MI355X match-finding path (BASELINE.json `metric`).
 
-Workload (BASELINE.json configs[1]): 128 synthetic 5 Mbp genomes at 99 % identity matched by the
-SlidingWindowSparseEMMatcher path against the growing reference (G0 + reverse complement preloaded,
-1.28e9-byte circular buffer, 2^27-entry table: the sizes `mbgc c` derives for 128 files,
-MGMP.cpp:130-168). A *step* is one round: every GPU matches `--round` targets (default 16) against its
-frozen replica, then every replica loads the round's extensions in target order (hash insertion
-included). With N > 1 the targets are sharded file-per-GPU and the extension bytes are all-gathered
-over RCCL; per-GPU work is fixed, so scaling is weak. Inputs are resident in HBM before the timed
-region. One JSON line is printed by rank 0.
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1000 synthetic 5 Mbp genomes at
+99 % identity per GPU, matched against the growing circular reference `mbgc c` sizes for that collection (G0 +
+reverse complement preloaded; 2.56e9 bytes and a 2^28-entry table for 1001 files, MGMP.cpp:130-168). A *step* is
+one round: every GPU matches `--round` targets (default: 1000 / (steps + warmup) = 40 under the driver's
+`--steps 20 --warmup 5`) against its frozen replica — matchTexts + processMatches, six streams — then every replica
+loads the round's extensions in target order (loadRef, hash insertion included). The run goes THROUGH the wrap of
+the circular buffer (near target 510); step times before and after it are reported separately. With N > 1 the
+targets are sharded file-per-GPU (N x 1000 genomes, per-GPU work fixed: weak scaling), the extension bytes are
+all-gathered over RCCL and the streams gathered to rank 0. Inputs are resident in HBM before the timed region.
+One JSON line is printed by rank 0.
+
+`python bench.py --gpus N` starts its own N ranks (children, before anything in this process touches a GPU);
+under `python -m torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
 
 Diagnostics (never the headline): --no-emit (matcher only), --from-host (queries cross PCIe inside the timed region),
---check (first round against the oracle); environment: MBGC_BENCH_BLOCK_STATS / MBGC_BENCH_BLOCK_DUMP (per-block clocks
-of the last resolve launch), MBGC_BENCH_NO_LOOKAHEAD, MBGC_BENCH_ONE_DEVICE + MBGC_BENCH_BACKEND=gloo (several ranks
-on one GPU, a rehearsal of the N > 1 protocol), and the library's own switches (SWSEM_RB, SWSEM_PROBE, SWSEM_HASH,
-SWSEM_RESOLVE, SWSEM_PROF_FAMS; see mbgc_amd/csrc/swsem_runtime.hip: swsem_create)."""
+--check (first round against the oracle); environment: MBGC_BENCH_MAX_REF (another buffer size), MBGC_BENCH_BLOCK_STATS
+/ MBGC_BENCH_BLOCK_DUMP (per-block clocks of the last resolve launch), MBGC_BENCH_ONE_DEVICE + MBGC_BENCH_BACKEND=gloo
+(several ranks on one GPU, a rehearsal of the N > 1 protocol), and the library's own switches (SWSEM_ORDER, SWSEM_RB,
+SWSEM_PROBE, SWSEM_HASH, SWSEM_RESOLVE, SWSEM_PROF_FAMS; see mbgc_amd/csrc/swsem_runtime.hip: swsem_create)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,15 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GENOME_LEN = 5_000_000
-# 128 files -> referenceFactor 128 -> 128 * 5e6 * 2 (MGMP.cpp:130-158). MBGC_BENCH_MAX_REF (diagnostic): a smaller buffer,
-# so that the circular reference wraps inside the run
-MAX_REF_LEN = int(float(os.environ.get("MBGC_BENCH_MAX_REF", 1_280_000_000)))
+COLLECTION = 1000                    # targets per GPU of configs[2]
 
 
 def ref_length_limit(files_count, basic_len):
     """the reference buffer `mbgc c` derives for a collection (loadG0Ref MGMP.cpp:130-134, initMatcher :152-168; -m1, RC
-    in the reference, circular): 129 files of 5 Mbp give configs[1]'s 1.28e9 bytes; the larger collections of the
-    weak-scaling runs (N x 128 targets) get what the tool would give them (2.56e9 for 257..2048 files)."""
+    in the reference, circular): 1001 files of 5 Mbp give 2.56e9 bytes; above 2048 files the rule asks for 5.12e9,
+    which initMatcher squeezes to 2^32 - 1 + the excess / 16 and addresses with 40-bit offsets (mapOff5th)."""
     clz = 32 - int(files_count).bit_length()
     factor = 1 << min(12, max(5, 15 - clz // 3))
     lim = factor * max(basic_len, 1 << 21) * 2
@@ -44,35 +49,54 @@ def ref_length_limit(files_count, basic_len):
     if lim > 0xFFFFFFFF:
         lim = 0xFFFFFFFF + (lim - 0xFFFFFFFF) // 16
     return lim
+
+
 ALG_BYTES_PER_BASE = 5.5             # whole path, per input base
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
 # SURVEY.md §8(d) splits that figure by term; per kernel family (bytes per input base of a launch):
 #   resolve k_resolve_blocks: the query scan (1 B: the scan windows hash their K-mers from the query bytes; with
 #           SWSEM_HASH=pre that byte belongs to the "probe" family, k_probe<true>, instead), the table probes the
 #           sequential loop performs (0.29 x 4 B), the reference bytes it compares (0.918 B) and the match rows it
-#           writes (24 B x 766 k rows / 80 M bases)
+#           writes (24 B x 9.6 k rows / 1 M bases)
 #   load    extension copy, read + write (2 B);  insert  one 4-B table entry per 16 bases
 #   emit    the six streams (0.14 B)
 ALG_BYTES = {"probe": 1.0, "resolve": 4 * 0.29 + 0.918 + 0.23, "stitch": 0.23, "load": 2.0, "insert": 0.25, "emit": 0.14}
 QUERY_SCAN_BYTES = 1.0               # moves to "resolve" when no hash kernel ran
-# HBM bytes per input base each family really moves, from the PMC passes in profiles/r01_pmc_hbm_traffic.json
-# (FETCH_SIZE + WRITE_SIZE of its largest launches = rounds of 16 x 5 Mbp, / 80 M bases)
-TRAFFIC = {"probe": (41035.8 + 313186.5) * 1024 / 80e6, "resolve": (2958811.0 + 50837.9) * 1024 / 80e6,
-           "stitch": (793.8 + 101.8 + 117.8 + 111.9 + 13241.4 + 18336.5) * 1024 / 80e6, "load": (39692.8 + 78735.5) * 1024 / 80e6,
-           "insert": (353604.2 + 153432.2) * 1024 / 80e6,
-           "emit": (24414.1 + 8602.6 + 1492.6 + 0.0 + 17843.9 + 33364.6 + 62.0 + 1.0 + 9646.2 + 1149.9 + 25.8 + 13.8 + 12625.5 +
-                    118.3 + 3.2 + 0.8 + 21404.4 + 16375.0 + 62.4 + 65.3 + 21189.8 + 127.9 + 102860.9 + 16637.0 + 136645.7 +
-                    30694.6) * 1024 / 80e6}
-KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query, SWSEM_HASH=pre only)", "resolve": "k_resolve_blocks<2, false>",
+KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query, SWSEM_HASH=pre only)", "resolve": "k_resolve_blocks",
              "stitch": "k_stitch_pre + k_stitch + k_gather", "load": "k_copy_multi", "insert": "k_insert_multi",
              "emit": "k_emit_* (13 launches)"}
+# HBM-side bytes per launch of each kernel, from the PMC passes over THIS command (profiles/pmc_summary.py writes the
+# file from rocprofv3's FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes); absent = null
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
-def cpu_baseline(sample_targets, length, emit):
-    """Time the CPU path on a bounded sample of the same workload (rank 0, N = 1): G0(+RC) preloaded,
-    then `sample_targets` targets matched (matchTexts), emitted (processMatches) and appended (loadRef)
-    one after another on one core. Uses the reference's own code (oracle/_ref, prebuilt from
-    /root/reference) when it is loadable, else the C restatement."""
+def measured_traffic(kernel_prefix, targets_per_launch):
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        k = t["kernels"][kernel_prefix]
+        if t.get("targets_per_launch") != targets_per_launch:
+            return None
+        return int(k["bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_single_thread(sample_targets, length, emit, max_ref):
+    """G0(+RC) preloaded, then `sample_targets` targets matched (matchTexts), emitted (processMatches) and appended
+    (loadRef) one after another on one core. Uses the reference's own code (oracle/_ref, prebuilt from /root/reference)
+    when it is loadable, else the C restatement."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from mbgc_amd import synth
     import _orc
@@ -86,7 +110,7 @@ def cpu_baseline(sample_targets, length, emit):
     except Exception:
         pass
     base = synth.base_codes(length)
-    m = refh.RefMatcher(MAX_REF_LEN) if refh else _orc.OracleMatcher(MAX_REF_LEN)
+    m = refh.RefMatcher(max_ref) if refh else _orc.OracleMatcher(max_ref)
     m.disable_sliding_window()
     m.load_ref(synth.genome(base, 0), load_rc=True)
     em = None
@@ -107,19 +131,103 @@ def cpu_baseline(sample_targets, length, emit):
         t += time.perf_counter() - t0
     m.close()
     what = "matchTexts + processMatches + loadRef" if emit else "matchTexts + loadRef"
-    return dict(value=sample_targets * length / t / 1e9, unit="Gbases/s", cores=1, kind=kind,
-                sample="G0+RC preloaded, first %d of the 128 targets (%.0f Mbases), %s, 1 thread"
+    return dict(value=round(sample_targets * length / t / 1e9, 5), unit="Gbases/s", cores=1, kind=kind,
+                sample="G0+RC preloaded, first %d targets of the collection (%.0f Mbases), %s, 1 thread"
                        % (sample_targets, sample_targets * length / 1e6, what))
+
+
+def cpu_all_cores(sample_targets, length):
+    """The reference's own parallel path (MGMP.cpp:520-555: worker threads + finalizer) as `mbgc c -m1` runs it: the
+    tool built from /root/reference (oracle/_ref/mbgc) compresses G0 + `sample_targets` FASTA files with every core
+    of this host; the matching phase is what the tool itself reports between "processed reference dataset" and
+    "matching finished" (file reading and kseq parsing included, backend compression excluded)."""
+    import re
+    import shutil
+    import tempfile
+    from mbgc_amd import synth
+    tool = os.path.join(ROOT, "oracle", "_ref", "mbgc")
+    if not os.access(tool, os.X_OK):
+        return None
+    cores = os.cpu_count() or 1
+    d = tempfile.mkdtemp(prefix="mbgc_cpub_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        base = synth.base_codes(length)
+        lst = os.path.join(d, "list.txt")
+        with open(lst, "w") as l:
+            for i in range(sample_targets + 1):
+                fn = os.path.join(d, "s%05d.fa" % i)
+                with open(fn, "wb") as f:
+                    f.write(synth.fasta_bytes(synth.genome(base, i), i))
+                l.write(fn + "\n")
+        t0 = time.perf_counter()
+        p = subprocess.run([tool, "c", "-m1", "-f", "-t", str(cores), "-T", str(cores), lst, os.path.join(d, "out.mbgc")],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return None
+        a = re.search(r"processed reference dataset - (\d+) \[ms\]", p.stdout)
+        b = re.search(r"matching finished - (\d+) \[ms\]", p.stdout)
+        ratio = re.search(r"compressed (\d+) bytes to (\d+)", p.stdout)
+        if not (a and b):
+            return None
+        match_s = (int(b.group(1)) - int(a.group(1))) / 1e3
+        out = dict(value=round(sample_targets * length / match_s / 1e9, 5), unit="Gbases/s", cores=cores, kind="reference",
+                   sample="`mbgc c -m1 -t %d -T %d` (oracle/_ref, the reference's own OpenMP path) on G0 + the first %d targets "
+                          "(%.0f Mbases): matching phase %.2f s, whole run %.2f s wall" %
+                          (cores, cores, sample_targets, sample_targets * length / 1e6, match_s, wall),
+                   whole_run_value=round(sample_targets * length / wall / 1e9, 5), cpu_model=cpu_model(), nproc=cores)
+        if ratio:
+            out["archive_bytes"] = int(ratio.group(2))
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def cpu_baseline(sample_targets, length, emit, max_ref):
+    """the CPU path on a bounded sample of the same workload, on this host (rank 0, N = 1): the reference's all-core
+    path (the headline `value`, cores stated) and the one-thread harness beside it."""
+    one = cpu_single_thread(min(sample_targets, 24), length, emit, max_ref)
+    allc = cpu_all_cores(sample_targets, length) if emit else None
+    if allc is None:
+        one["cpu_model"], one["nproc"] = cpu_model(), os.cpu_count()
+        return one
+    allc["single_thread"] = one
+    return allc
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script as children (this process has not
+    touched a GPU and never does), relay rank 0's JSON line, exit with the worst return code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=7)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--round", type=int, default=16, help="targets per GPU per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--round", type=int, default=0, help="targets per GPU per step (default: 1000 / (steps + warmup), at most 40)")
     ap.add_argument("--length", type=int, default=GENOME_LEN)
-    ap.add_argument("--cpu-sample", type=int, default=24, help="targets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="targets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--check", action="store_true", help="compare the first step's matches with the oracle")
     ap.add_argument("--no-emit", action="store_true", help="matcher only (no stream emission) inside the step")
     ap.add_argument("--from-host", action="store_true",
@@ -127,13 +235,39 @@ def main():
                          "inside the timed region (double-buffered on a copy stream); reported under its own metric name")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    from mbgc_amd import synth
+    from mbgc_amd.rounds import round_schedule
+    steps, warm = args.steps, args.warmup
+    R = args.round if args.round > 0 else max(1, min(40, COLLECTION // (steps + warm)))
+    n_targets = (steps + warm) * R * world
+    # synthetic collection (SURVEY.md §8d recipe), generated by forked workers BEFORE this process touches the GPU:
+    # this rank's targets of every round, one host array per round
+    base = synth.base_codes(args.length)
+    sched = round_schedule(n_targets, R, world)
+    mine_all = [1 + t for rnd in sched for t in rnd[rank]]
+    t_gen = time.perf_counter()
+    gens = synth.genomes(base, mine_all, workers=max(1, min(16, (os.cpu_count() or 1) // world)))
+    host_rounds, k = [], 0
+    for rnd in sched:
+        cnt = len(rnd[rank])
+        host_rounds.append(np.concatenate(gens[k: k + cnt]))
+        for j in range(k, k + cnt):
+            gens[j] = None
+        k += cnt
+    del gens
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
+    import torch.distributed as dist
     # rehearsal hooks (one-GPU box): MBGC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, MBGC_BENCH_BACKEND=gloo
     # replaces RCCL (which refuses two ranks on one device). The driver's runs use neither.
     if os.environ.get("MBGC_BENCH_ONE_DEVICE") == "1":
@@ -147,14 +281,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from mbgc_amd import binding, synth
-    from mbgc_amd.rounds import RoundRunner, round_schedule
+    from mbgc_amd import binding
+    from mbgc_amd.rounds import RoundRunner
 
-    R, steps, warm = args.round, args.steps, args.warmup
-    n_targets = (steps + warm) * R * world
-    base = synth.base_codes(args.length)
-    # the buffer `mbgc c` would give this collection (129 files at the defaults: configs[1]'s 1.28e9 bytes)
-    max_ref = MAX_REF_LEN if "MBGC_BENCH_MAX_REF" in os.environ else ref_length_limit(1 + n_targets, args.length)
+    # the buffer `mbgc c` gives the whole collection of configs[2] (N x 1000 targets + G0), whatever part of it this run matches
+    coll = max(COLLECTION * world, n_targets)
+    max_ref = int(float(os.environ["MBGC_BENCH_MAX_REF"])) if "MBGC_BENCH_MAX_REF" in os.environ else ref_length_limit(1 + coll, args.length)
+    bit40 = max_ref > 0xFFFFFFFF
     m = binding.SlidingWindowSparseEMMatcher(max_ref, device=local_rank)
     stream = torch.cuda.current_stream()
     m.set_stream(stream.cuda_stream)
@@ -163,14 +296,12 @@ def main():
     torch.cuda.synchronize()
     m.load_ref_dev(g0.data_ptr(), g0.numel(), True, True, 0)
 
-    # this rank's targets of every round, resident in HBM before the clock starts
-    sched = round_schedule(n_targets, R, world)
+    # resident in HBM before the clock starts
     bufs = []
-    for rnd in sched:
-        mine = rnd[rank]
-        arr = np.concatenate([synth.genome(base, 1 + t) for t in mine])
-        offs = np.arange(len(mine) + 1, dtype=np.uint64) * args.length
-        bufs.append((torch.from_numpy(arr).to(dev), offs))
+    for ri, rnd in enumerate(sched):
+        offs = np.arange(len(rnd[rank]) + 1, dtype=np.uint64) * args.length
+        bufs.append((torch.from_numpy(host_rounds[ri]).to(dev), offs))
+        host_rounds[ri] = None
     torch.cuda.synchronize()
     hostbufs, copy_stream, slots, copied = None, None, None, None
     if args.from_host:
@@ -182,8 +313,8 @@ def main():
         copied = [torch.cuda.Event() for _ in range(3)]
 
     emit = not args.no_emit
-    runner = RoundRunner(m, rank, world, None, dev, lazy=True, emit_params=binding.emit_params(1) if emit else None,
-                         keep_streams=False)
+    ep = binding.emit_params(1, enable40bitReference=1 if bit40 else 0) if emit else None
+    runner = RoundRunner(m, rank, world, None, dev, lazy=True, emit_params=ep, keep_streams=False)
     runner.start()
     tot_matches = 0
 
@@ -201,8 +332,11 @@ def main():
             check_against_oracle(runner, base, sched[0][0], args.length, emit, max_ref)
         runner.keep_streams = False
     m.profile_enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # step boundaries on the main stream
+    laps_at = []                                                                   # laps of the circular buffer after each step
     barrier()
     t0 = time.perf_counter()
+    marks[0].record()
     replayed = 0
     def stage(r):                                        # host -> device copy of round r's queries, on the copy stream
         with torch.cuda.stream(copy_stream):
@@ -219,15 +353,19 @@ def main():
                 stage(s + 1)
             tot_matches += int(runner.run_round(*cur).sum())
             replayed += m.batch_stats()["replayed_blocks"]
+            marks[s - warm + 1].record()
+            laps_at.append(m.ref_length() == m.max_ref_length())
     for s in range(warm, warm + steps) if not args.from_host else ():
-        # every timed step also hashes a following round's queries (the last one a round that is not matched here)
-        tot_matches += int(runner.run_round(*bufs[s], next_batch=None if os.environ.get('MBGC_BENCH_NO_LOOKAHEAD') else bufs[(s + 1) % len(bufs)]).sum())
+        tot_matches += int(runner.run_round(*bufs[s], next_batch=bufs[s + 1] if s + 1 < len(bufs) else None).sum())
         replayed += m.batch_stats()["replayed_blocks"]
+        marks[s - warm + 1].record()
+        laps_at.append(m.ref_length() == m.max_ref_length())
     runner.flush()                                     # the last round's emission (its second phase runs beside the next round)
     barrier()
     dt = time.perf_counter() - t0
     prof = m.profile_get()
     m.profile_enable(False)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if os.environ.get("MBGC_BENCH_BLOCK_STATS"):          # diagnostics of the last round's resolve blocks, to stderr
         import ctypes as C
         from mbgc_amd import binding as _b
@@ -258,6 +396,10 @@ def main():
         if prof["probe"][1] == 0:                          # no hash kernel ran: the chains read the query themselves
             alg["resolve"] += QUERY_SCAN_BYTES
         ach = alg[dom] * launch_bases / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+        traffic = measured_traffic(KERNEL_OF[dom].split()[0], R)
+        pre = [t for t, w in zip(step_ms, laps_at) if not w]
+        post = [t for t, w in zip(step_ms, laps_at) if w]
+        first_coll = 1 + warm * R * world
         out = {
             "metric": ("input Gbases/s (compress hot path, -m1: match-finding + stream emission)" if emit else
                        "input Gbases/s (compress path, SlidingWindowSparseEMMatcher only)") +
@@ -265,25 +407,33 @@ def main():
             "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[1]: %d synthetic 5 Mbp genomes @99%% identity, %.3g-byte reference; step = "
-                                    "matchTexts%s + loadRef of one round of %d targets/GPU") %
-                                   (n_targets, float(max_ref), " + processMatches (six streams, gathered to rank 0)" if emit else "", R),
+            "config": {"workload": ("configs[2]: %d synthetic 5 Mbp genomes @99%% identity%s, %.4g-byte circular reference "
+                                    "(the buffer `mbgc c` gives %d files); step = matchTexts%s + loadRef of one round of %d "
+                                    "targets/GPU; timed: targets %d..%d of the collection, through the buffer's wrap") %
+                                   (n_targets, " (%d per GPU, file-per-GPU)" % (n_targets // world) if world > 1 else "", float(max_ref),
+                                    1 + coll, " + processMatches (six streams, %s)" %
+                                    ("gathered to rank 0 over RCCL" if world > 1 else "left packed in HBM for the host backend") if emit else "",
+                                    R, first_coll, n_targets),
                        "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": max_ref,
-                       "hash_entries": m.hash_size(), "sharding": "file-per-GPU, all-gather of extensions"},
+                       "hash_entries": m.hash_size(), "offsets_40bit": bit40,
+                       "sharding": "file-per-GPU, all-gather of extensions" if world > 1 else "one GPU"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "traffic": round(TRAFFIC[dom] * launch_bases),
-                         "traffic_GBs": round(TRAFFIC[dom] * launch_bases / (dom_ms * 1e-3) / 1e9, 1) if dom_ms else 0.0,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_GBs": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms else None,
                          "alg_bytes_per_base": round(alg[dom], 3), "avg_launch_ms": round(dom_ms, 4),
                          "whole_step_frac": round(ALG_BYTES_PER_BASE * value / world / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items()},
             "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof}, "dominant_kernel": dom,
-            "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps, "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
+            "ms_per_step_before_wrap": round(float(np.mean(pre)), 4) if pre else None, "steps_before_wrap": len(pre),
+            "ms_per_step_after_wrap": round(float(np.mean(post)), 4) if post else None, "steps_after_wrap": len(post),
+            "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps,
+            "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
         }
         if world > 1:
+            out["rccl_ranks_seen"] = dist.get_world_size()
             out["extension_allgathers_started_ahead"] = {"started": runner.pregathers[0], "used": runner.pregathers[1]}
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit, max_ref)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

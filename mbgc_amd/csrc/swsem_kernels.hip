@@ -776,11 +776,15 @@ template <int MODE, bool LAPS>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RESOLVE_SGPRS))) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ rbContig,
+                                                         const uint32_t *__restrict__ order,
                                                          const uint32_t *__restrict__ cand,
                                                          Row *__restrict__ regions, uint32_t cap, uint32_t rb,
                                                          BlockRec *__restrict__ recs) {
     __shared__ uint2 ring[RING];
-    const uint32_t g = blockIdx.x;
+    // launch slot -> block (run_batch: blocks that scan the same offsets of different contigs sit in slots that are
+    // equal mod 8, i.e. on one XCD, next to each other; 0xFFFFFFFF pads the lists of the eight XCDs to one length)
+    const uint32_t g = order[blockIdx.x];
+    if (g == 0xFFFFFFFFu) return;
     const Contig cg = contigs[rbContig[g]];
     const uint32_t b = g - cg.rb0;
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;

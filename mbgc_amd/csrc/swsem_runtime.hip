@@ -110,7 +110,9 @@ struct swsem {
     // --- per-round scratch
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
-    DevBuf<uint32_t> dTileContig, dMatchCount, dRbContig, dCand;
+    DevBuf<uint32_t> dTileContig, dMatchCount, dRbContig, dRbOrder, dCand;
+    std::vector<uint32_t> rbOrderHost, rbOrderKey;   // the table on the device is kept while the batches keep their shape (rbOrderKey)
+    int orderMode = 1;                     // launch order of the resolve blocks: 0 contig-major, 1 offset-major on one XCD (SWSEM_ORDER)
     // K-mer hashes of a batch announced ahead (swsem_hash_batch_dev): computed on a third stream into the other
     // hash buffer while the current batch is still being matched; swsem_match_batch_dev on the same buffers adopts them
     DevBuf<uint32_t> dCandNext, dPrepTileContig;
@@ -552,6 +554,56 @@ int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n
     return SWSEM_OK;
 }
 
+// Launch order of the resolve blocks (h->contigs filled in). The genomes of a collection resemble each other, so the
+// blocks that scan the same offsets of a round's contigs look up the same buckets and compare against the same
+// reference windows. Workgroups are dealt round-robin over the eight XCDs (slot s -> XCD s mod 8, MI355X_MICROARCH.md
+// "Workgroup dispatch": observed, for speed only) and each XCD has its own L2: such a group of blocks is given
+// consecutive slots of ONE XCD, so one of them fetches a sector from HBM and the others find it in that L2. Groups
+// larger than 64 blocks are cut (a batch of many one-block contigs must still spread over the chip), every piece goes
+// to the XCD with the shortest list so far, and the lists are padded to one length with empty slots.
+bool build_resolve_order(swsem *h, uint32_t rblocks) {
+    std::vector<uint32_t> key;
+    key.reserve(h->contigs.size() + 2);
+    key.push_back((uint32_t) h->orderMode); key.push_back(rblocks);
+    for (auto &cg : h->contigs) key.push_back(cg.nrb);
+    if (key == h->rbOrderKey && !h->rbOrderHost.empty()) return false;       // same shape as the last batch: the device table stands
+    h->rbOrderKey.swap(key);
+    std::vector<uint32_t> &order = h->rbOrderHost;
+    order.clear();
+    if (h->orderMode == 0) {
+        order.resize(rblocks);
+        for (uint32_t g = 0; g < rblocks; g++) order[g] = g;
+        return true;
+    }
+    uint32_t maxNrb = 0;
+    for (auto &cg : h->contigs) maxNrb = std::max(maxNrb, cg.nrb);
+    // contigs by descending block count would let every group be a prefix; a plain pass per offset over the contigs that
+    // still have a block there is O(blocks) as well once contigs are bucketed by nrb
+    std::vector<uint32_t> byLen(h->contigs.size());
+    for (uint32_t c = 0; c < byLen.size(); c++) byLen[c] = c;
+    std::stable_sort(byLen.begin(), byLen.end(), [&](uint32_t a, uint32_t b) { return h->contigs[a].nrb > h->contigs[b].nrb; });
+    std::vector<uint32_t> lists[8];
+    std::vector<uint32_t> grp;
+    size_t alive = byLen.size();
+    for (uint32_t b = 0; b < maxNrb; b++) {
+        while (alive && h->contigs[byLen[alive - 1]].nrb <= b) alive--;
+        grp.assign(byLen.begin(), byLen.begin() + alive);
+        std::sort(grp.begin(), grp.end());                               // contig order inside a group
+        for (size_t i = 0; i < grp.size(); i += 64) {
+            int best = 0;
+            for (int x = 1; x < 8; x++) if (lists[x].size() < lists[best].size()) best = x;
+            const size_t e = std::min(grp.size(), i + 64);
+            for (size_t k = i; k < e; k++) lists[best].push_back(h->contigs[grp[k]].rb0 + b);
+        }
+    }
+    size_t len = 0;
+    for (auto &l : lists) len = std::max(len, l.size());
+    order.assign(len * 8, 0xFFFFFFFFu);
+    for (int x = 0; x < 8; x++)
+        for (size_t j = 0; j < lists[x].size(); j++) order[j * 8 + x] = lists[x][j];
+    return true;
+}
+
 int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {
     HT("run_batch enter");
     if (n <= 0) return fail(SWSEM_EINVAL, "empty batch");
@@ -610,9 +662,16 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if ((r = h->dMatches.reserve(matchRows))) return r;
     if ((r = upload(h, h->dContigs.p, h->contigs.data(), n * sizeof(Contig), h->stream))) return r;
     if ((r = h->dRbContig.reserve(std::max<uint32_t>(rblocks, 1)))) return r;
+    uint32_t rslots = 0;
     if (tiles) {
+        const uint32_t *had = h->dRbOrder.p;
+        const bool fresh = build_resolve_order(h, rblocks);
+        rslots = (uint32_t) h->rbOrderHost.size();
+        if ((r = h->dRbOrder.reserve(rslots + rslots / 4 + 64))) return r;
         if ((r = upload(h, h->dTileContig.p, tileContig.data(), tiles * sizeof(uint32_t), h->stream)) ||
             (r = upload(h, h->dRbContig.p, rbContig.data(), rblocks * sizeof(uint32_t), h->stream)))
+            return r;
+        if ((fresh || had != h->dRbOrder.p) && (r = upload(h, h->dRbOrder.p, h->rbOrderHost.data(), rslots * sizeof(uint32_t), h->stream)))
             return r;
     }
     if ((r = zero_dev(h, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) || (r = flush_copies(h))) return r;
@@ -652,7 +711,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if ((r = h->dDstOff.reserve(rblocks))) return r;
         if ((r = h->dPrev.reserve(rblocks))) return r;
         h->mark(SWSEM_K_RESOLVE, true);
-#define SWSEM_LAUNCH_RB(M, W) k_resolve_blocks<M, W><<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dCand.p, \
+#define SWSEM_LAUNCH_RB(M, W) k_resolve_blocks<M, W><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dCand.p, \
                                                                                       h->dRegions.p, cap, h->rb, h->dRecs.p)
         SWSEM_BY_MODE(SWSEM_LAUNCH_RB);
 #undef SWSEM_LAUNCH_RB
@@ -800,6 +859,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_HASH")) h->flyHash = strcmp(e, "pre") != 0;
     if (h->K > 128) h->flyHash = false;                               // (a window's bytes must fit one dword per lane)
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
+    if (const char *e = getenv("SWSEM_ORDER")) h->orderMode = strcmp(e, "contig") == 0 ? 0 : 1;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
@@ -837,7 +897,7 @@ void swsem_destroy(swsem_t *h) {
     h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release(); h->dCandNext.release(); h->dPrepTileContig.release(); h->dPrepContigs.release(); h->dPrepStats.release();
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dFast.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
-    h->dPrev.release(); h->dRbContig.release();
+    h->dPrev.release(); h->dRbContig.release(); h->dRbOrder.release();
     for (auto &E : h->slot) E.release();
     h->dTables.release(); h->dGate.release(); h->dPred.release();
     if (h->pin) { hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }

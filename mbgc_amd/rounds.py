@@ -186,6 +186,7 @@ class RoundRunner:
         finalized = 0                               # targets of the round already loaded into the reference
         emitted_here = False                        # an emission of THIS round has been begun (the deferred one is then "previous")
         ext_done = {}
+        first_pass = True                           # rank-invariant: every rank is in its first pass over the whole round
         while True:
             if pending:
                 self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
@@ -228,7 +229,7 @@ class RoundRunner:
             # "discard, wait until the earlier targets are loaded, retry")
             first_skip_local = min([self.rank * T + targets[c] for c in skipped_local], default=ntot)
             merged = None
-            if self.world > 1 and pending and finalized == 0 and len(pending) == ncont:
+            if self.world > 1 and first_pass:
                 # first pass over the whole round: the skip index travels together with what this rank would load if
                 # nobody skips (one exchange instead of two on the path between pass 1 and the round's finalize)
                 if skipped_local:
@@ -244,6 +245,7 @@ class RoundRunner:
                 first_skip = min(x[0] for x in self._allgather_ints([first_skip_local], fixed=True))
             else:
                 first_skip = first_skip_local
+            first_pass = False
             upto = first_skip                       # targets [finalized, upto) are complete on every rank
             if last is not None and first_skip < ntot:
                 packs.append(self._pack(*last))     # a retry follows: it reuses the emission's buffers, take the streams now
@@ -501,7 +503,7 @@ class RoundRunner:
         for c, pk, k in items:
             s0, s1 = int(pk["starts"][k * 6]), int(pk["starts"][k * 6 + 6])
             chunks.append(pk["buf"][s0:s1])
-            meta.extend([c] + [int(x) for x in pk["sizes"][k]])
+            meta.extend([c, targets[c]] + [int(x) for x in pk["sizes"][k]])      # contig, ITS rank's local target, six sizes
         if len(packs) == 1 and len(items) == len(packs[0]["starts"]) // 6 and all(k == j for j, (_, _, k) in enumerate(items)):
             local = packs[0]["buf"][: int(packs[0]["starts"][-1])]     # one emission, nothing dropped: already packed in order
         else:
@@ -517,29 +519,33 @@ class RoundRunner:
             mx = max(max(sizes), 1)
             pad = torch.zeros(mx, dtype=torch.uint8, device=self.device)
             pad[: local.numel()] = local
-            out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
+            # a gather towards the rank that feeds the host backend (MBGC_Encoder.cpp:542-564): nobody else needs the bytes
+            outs = [torch.empty(mx, dtype=torch.uint8, device=self.device) for _ in range(self.world)] if self.rank == 0 else None
             want_now = self.rank == 0 and self.keep_streams
-            work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=not want_now)
+            work = dist.gather(pad, outs, dst=0, group=self.group, async_op=not want_now)
             if not want_now:
-                self._gathers.append((work, out, pad))
-            all_bytes = [out[r * mx: r * mx + sizes[r]] for r in range(self.world)]
+                self._gathers.append((work, outs, pad))
+            all_bytes = [outs[r][: sizes[r]] for r in range(self.world)] if self.rank == 0 else []
+            self.stream_bytes += sum(sizes)
+            if self.rank != 0 or not self.keep_streams:
+                return
         else:
             all_bytes, all_meta = [local], [meta + [-1]]
-        self.stream_bytes += sum(int(b.numel()) for b in all_bytes)
-        if self.rank != 0 or not self.keep_streams:
-            return
+            self.stream_bytes += int(local.numel())
+            if not self.keep_streams:
+                return
         for r in range(self.world):
             host = all_bytes[r].cpu().numpy().tobytes()
             mt = all_meta[r][:-1]
             pos = 0
             per_target = {}
-            for i in range(0, len(mt), 7):
-                c, sizes = mt[i], mt[i + 1: i + 7]
+            for i in range(0, len(mt), 8):
+                lt_of_c, sizes = mt[i + 1], mt[i + 2: i + 8]           # (contig indices and layouts are local to rank r)
                 st = {}
                 for name, sz in zip(STREAMS, sizes):
                     st[name] = host[pos: pos + sz]
                     pos += sz
-                per_target.setdefault(targets[c], []).append(st)
+                per_target.setdefault(lt_of_c, []).append(st)
             for lt in range(T):
                 for st in per_target.get(lt, []):
                     for name in STREAMS:

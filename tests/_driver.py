@@ -87,9 +87,14 @@ def encode_sequential(matcher, emitter, files, policy=None, lazy=True):
     return dict(locks=locks, refExtSize=ref_ext, matches=all_matches, loaded=loaded)
 
 
-def encode_rounds(matcher, make_emitter, g0, targets, round_size, policy=None, lazy=True, sw_factor=16):
+def encode_rounds(matcher, make_emitter, g0, targets, round_size, policy=None, lazy=True, sw_factor=16, threads=1,
+                  keep_matches=True):
     """g0: list of contigs of the first file (reference only). targets: list of lists of contigs.
-    make_emitter() -> fresh per-target emitter. Returns per-target streams merged in target order."""
+    make_emitter() -> fresh per-target emitter. Returns per-target streams merged in target order.
+    threads > 1: the targets of a round are matched + emitted by a thread pool first (the reference is frozen during a
+    round and the backends release the GIL: same results, the wall time of a full-size run divided by the cores); a
+    round in which some contig is skipped as dissimilar is redone by the sequential loop below, which alone defines
+    the schedule. keep_matches=False drops the match rows of finished targets (a 1000-genome run holds 48 M of them)."""
     pol = policy or Policy()
     matcher.set_sliding_window_size(sw_factor)                         # MGMP.cpp:179-180
     g0cat = np.concatenate(g0)
@@ -117,14 +122,36 @@ def encode_rounds(matcher, make_emitter, g0, targets, round_size, policy=None, l
         matcher.release_lock(lock[t])
         state["processed"] += 1
 
+    pool = None
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(threads)
+
+    def ahead(t, processed, loaded_now):                               # one target against the frozen reference
+        em, out = make_emitter(), []
+        for contig in targets[t]:
+            m = matcher.match(contig, 32, lock[t])
+            out.append((m, em.process(m, contig, lock[t], pol.factor, processed, t, loaded_now)))
+            em.put(0, bytes([SEQ_SEPARATOR]))
+        em.put(5, bytes([FILE_SEPARATOR]))
+        return em, out
+
     for r0 in range(0, len(targets), round_size):
         rnd = list(range(r0, min(r0 + round_size, len(targets))))
         for t in rnd:
             lock[t] = matcher.acquire_lock()                           # :353-358, same pos1 for the round
+        pre = None
+        if pool is not None:
+            got = list(pool.map(lambda t: ahead(t, state["processed"], list(loaded)), rnd))
+            if all(u != SKIPPED for _, out in got for _, u in out):
+                pre = dict(zip(rnd, got))
         for t in rnd:
-            ems[t], exts[t] = make_emitter(), []
-            for contig in targets[t]:
+            ems[t], exts[t] = (pre[t][0] if pre else make_emitter()), []
+            for ci, contig in enumerate(targets[t]):
                 while True:
+                    if pre:
+                        m, unmatched = pre[t][1][ci]
+                        break
                     m = matcher.match(contig, 32, lock[t])
                     unmatched = ems[t].process(m, contig, lock[t], pol.factor, state["processed"], t, loaded)
                     if unmatched != SKIPPED:
@@ -134,16 +161,23 @@ def encode_rounds(matcher, make_emitter, g0, targets, round_size, policy=None, l
                     # with the lock position this target already holds.
                     while state["processed"] < t:
                         finalize(state["processed"])
-                all_matches.append(m)
+                all_matches.append(m if keep_matches else len(m))
                 unm.append(unmatched)
                 if pol.proper_for_ext(contig.size, unmatched):
                     exts[t].append(("fw", contig))
                 if pol.proper_for_rc_ext(contig.size, unmatched):
                     exts[t].append(("rc", contig))
-                ems[t].put(0, bytes([SEQ_SEPARATOR]))
-            ems[t].put(5, bytes([FILE_SEPARATOR]))
+                if not pre:
+                    ems[t].put(0, bytes([SEQ_SEPARATOR]))
+            if not pre:
+                ems[t].put(5, bytes([FILE_SEPARATOR]))
         while state["processed"] <= rnd[-1]:
             finalize(state["processed"])
+        if not keep_matches:
+            for t in rnd:
+                ems.pop(t, None), exts.pop(t, None)
+    if pool is not None:
+        pool.shutdown()
     locks_stream, ref_ext = state["locks"], state["ref_ext"]
     return dict(streams=merged, locks=locks_stream, refExtSize=ref_ext, matches=all_matches, unmatched=unm)
 

@@ -187,9 +187,10 @@ class OracleEmitter:
     def process(self, matches, dest, lock=NO_LOCK, factor=128, processed=0, target_idx=0, loaded=None):
         a, p = _bytes_ptr(dest)
         n = len(matches)
-        arr = (OrcMatch * max(n, 1))()
-        for i in range(n):
-            arr[i].posSrcText, arr[i].length, arr[i].posDestText = (int(x) for x in matches[i])
+        rows = np.zeros((max(n, 1), 4), dtype=np.uint64)                 # OrcMatch rows (the fourth field is filled by pass 1)
+        if n:
+            rows[:n, :3] = np.asarray(matches, dtype=np.uint64).reshape(n, 3)
+        arr = C.cast(rows.ctypes.data_as(C.c_void_p), C.POINTER(OrcMatch))
         nn = C.c_uint64(n)
         ld = np.ascontiguousarray(loaded if loaded is not None else [0], dtype=np.uint64)
         r = lib().orc_process_matches(self.m.h, C.byref(self.p), arr, C.byref(nn), p, a.size, lock, factor,

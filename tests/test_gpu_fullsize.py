@@ -74,6 +74,61 @@ def test_configs1_all_rounds_equal_oracle():
     assert sum(len(v) for v in exp["streams"].values()) > 50_000_000      # ~0.14 B per base of 635 Mbases
 
 
+def test_configs2_all_rounds_through_the_wrap_equal_oracle():
+    """BASELINE.json configs[2] as bench.py runs it: 1000 synthetic 5 Mbp genomes in 25 rounds of 40 against the
+    2.56e9-byte circular reference and 2^28-bucket table `mbgc c` derives for 1001 files (MGMP.cpp:130-168), THROUGH the
+    buffer's wrap near target 510 (SlidingWindowSparseEMMatcher.cpp:402-437: laps, the samplingPos = 1 restart, stale
+    table entries told by epochs, extensions clipped at the sliding window's end once 40 x 5 MB exceed its 160 MB).
+    Every byte of the six streams, the lock and refExtSize streams, the loading position and the final hash-table
+    image against the oracle driven through the reference's target loop with the same round schedule."""
+    import os
+    import torch
+    from mbgc_amd import binding
+    from mbgc_amd.rounds import RoundRunner
+    NT, RR, MAXREF = 1000, 40, 2_560_000_000
+    assert _driver.ref_length_limit(NT + 1, L) == (MAXREF, False)
+    base = synth.base_codes(L)
+    gs = synth.genomes(base, range(NT + 1), fork=False)
+    o = _orc.OracleMatcher(MAXREF)
+    assert o.hash_size() == 1 << 28
+    exp = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], RR,
+                                threads=min(16, os.cpu_count() or 1), keep_matches=False)
+    assert o.ref_length() == MAXREF                                  # the oracle's buffer has wrapped
+    h = binding.SlidingWindowSparseEMMatcher(MAXREF)
+    h.set_sliding_window_size(16)
+    g0 = torch.from_numpy(gs[0]).to("cuda:0")
+    torch.cuda.synchronize()
+    h.load_ref_dev(g0.data_ptr(), g0.numel(), True, True, 0)
+    runner = RoundRunner(h, 0, 1, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1), keep_streams=True)
+    runner.start()
+    bufs = []
+    for r0 in range(1, NT + 1, RR):
+        chunk = gs[r0:r0 + RR]
+        offs = np.zeros(len(chunk) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([c.size for c in chunk])
+        bufs.append((torch.from_numpy(np.concatenate(chunk)).to("cuda:0"), offs))
+    torch.cuda.synchronize()
+    got_counts, wrapped_at = [], None
+    for i, (buf, offs) in enumerate(bufs):
+        got_counts += [int(x) for x in runner.run_round(buf, offs, next_batch=bufs[i + 1] if i + 1 < len(bufs) else None)]
+        if wrapped_at is None and h.ref_length() == MAXREF:
+            wrapped_at = i
+    runner.flush()
+    assert wrapped_at is not None and 10 <= wrapped_at <= 14         # target ~510 of 1000: rounds on both sides of the wrap
+    bad = [i for i, (a, b) in enumerate(zip(got_counts, exp["matches"])) if a != b]
+    assert not bad, "match counts differ first at target %d (round %d): %s" % (bad[0] + 1, bad[0] // RR, [(got_counts[i], exp["matches"][i]) for i in bad[:5]])
+    for k, v in exp["streams"].items():
+        got = bytes(runner.streams[k])
+        if got != v:
+            n = min(len(got), len(v))
+            j = next((x for x in range(n) if got[x] != v[x]), n)
+            raise AssertionError("stream %s differs at byte %d of %d/%d" % (k, j, len(got), len(v)))
+    assert bytes(runner.locks_stream) == exp["locks"] and bytes(runner.ref_ext_sizes) == exp["refExtSize"]
+    assert h.loading_position() == o.loading_position() and h.loaded_ref_length() == o.loaded_ref_length()
+    assert np.array_equal(h.ht(), o.ht())
+    assert sum(len(v) for v in exp["streams"].values()) > 500_000_000     # ~0.14 B per base of 5 Gbases
+
+
 def test_configs1_round_trip_through_the_decoder():
     """size-independent property at full size, with no encoder oracle in the loop: rounds of 16 x 5 Mbp against the
     1.28e9-byte reference; every contig's six streams, decoded by the decoder's automaton (oracle/decode_oracle.c,

@@ -25,9 +25,15 @@ def collection(n, length, div, seed):
 
 def reference_result(gs, round_size, contigs_per_target=1):
     o = _orc.OracleMatcher(LIM)
-    targets = [split(g, contigs_per_target) for g in gs[1:]]
+    targets = [split(g, _cpt(contigs_per_target, t)) for t, g in enumerate(gs[1:])]
     res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], targets, round_size)
     return res, o.ht(), o.loaded_ref_length()
+
+
+def _cpt(contigs_per_target, t):
+    """contigs of target t: a number, or "ragged" = 1, 2, 3, 1, 3, 2 ... by target (the ranks of a round then hold
+    different contig layouts — contig indices are local to a rank)"""
+    return (1, 2, 3, 1, 3, 2, 2)[t % 7] if contigs_per_target == "ragged" else contigs_per_target
 
 
 def split(g, k):
@@ -48,7 +54,7 @@ def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None, announce
         mine = rnd[rank]
         contigs, tg = [], []
         for lt, t in enumerate(mine):
-            for c in split(gs[1 + t], contigs_per_target):
+            for c in split(gs[1 + t], _cpt(contigs_per_target, t)):
                 contigs.append(c)
                 tg.append(lt)
         buf = torch.from_numpy(np.concatenate(contigs).copy())
@@ -64,7 +70,7 @@ def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None, announce
     return runner, m
 
 
-@pytest.mark.parametrize("div,cpt", [(0.012, 1), (0.012, 3), (0.06, 2)])
+@pytest.mark.parametrize("div,cpt", [(0.012, 1), (0.012, 3), (0.06, 2), (0.012, "ragged")])
 def test_single_process_runner_equals_reference_loop(div, cpt):
     gs = collection(9, 60_000, div, seed=17)      # 6 % divergence forces dissimilar-contig retries
     runner, m = run_rank(0, 1, gs, 4, cpt)
@@ -92,7 +98,7 @@ def _worker(rank, world, port, outdir, div, cpt, announce=0, n=9):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("div,cpt", [(0.012, 1), (0.06, 2), (0.002, 1)])
+@pytest.mark.parametrize("div,cpt", [(0.012, 1), (0.06, 2), (0.002, 1), (0.002, "ragged"), (0.06, "ragged")])
 def test_world_size_2_gloo(tmp_path, div, cpt):
     """2 ranks x 2 targets per round == one process with rounds of 4; replicas bit-identical"""
     import torch.multiprocessing as mp
