@@ -255,7 +255,8 @@ def main():
     sched = round_schedule(n_targets, R, world)
     mine_all = [1 + t for rnd in sched for t in rnd[rank]]
     t_gen = time.perf_counter()
-    gens = synth.genomes(base, mine_all, workers=max(1, min(16, (os.cpu_count() or 1) // world)))
+    gens = synth.genomes(base, mine_all, workers=max(1, min(16, (os.cpu_count() or 1) // world)),
+                         fork=os.environ.get("MBGC_BENCH_GEN", "fork") != "thread")   # (threads under a profiler that has already opened the GPU)
     host_rounds, k = [], 0
     for rnd in sched:
         cnt = len(rnd[rank])
@@ -376,6 +377,15 @@ def main():
         t = buf[: 3 * nb.value].reshape(-1, 3).astype(np.float64)
         print("resolve blocks %d: ticks mean %.0f max %.0f (100 MHz), visits %d (mean %.0f/block), rows %d" %
               (nb.value, t[:, 0].mean(), t[:, 0].max(), t[:, 1].sum(), t[:, 1].mean(), t[:, 2].sum()), file=sys.stderr)
+        if hasattr(_b.lib(), "swsem_debug_phases"):       # diagnostics build (-DSWSEM_DIAG_PHASES) only
+            ph = np.zeros(8, dtype=np.uint64)
+            _b.lib().swsem_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            _b.lib().swsem_debug_phases(m.h, ph.ctypes.data_as(C.POINTER(C.c_uint64)))
+            tot, tr, tv, nr, nv, tl, nl, nbk = [float(x) for x in ph]
+            print("phases over %d block runs: total %.0f ticks/block; table-gather wait %.1f%% (%.0f refills/block, %.0f ticks each); "
+                  "visit-load wait %.1f%% (%.0f visits/block, %.0f ticks each); run continuation %.1f%% (%.1f/block, %.0f ticks each); rest %.1f%%" %
+                  (nbk, tot / nbk, 100 * tr / tot, nr / nbk, tr / max(nr, 1), 100 * tv / tot, nv / nbk, tv / max(nv, 1),
+                   100 * tl / tot, nl / nbk, tl / max(nl, 1), 100 * (tot - tr - tv - tl) / tot), file=sys.stderr)
         if os.environ.get("MBGC_BENCH_BLOCK_DUMP"):
             np.save(os.environ["MBGC_BENCH_BLOCK_DUMP"], buf[: 3 * nb.value].reshape(-1, 3))
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)

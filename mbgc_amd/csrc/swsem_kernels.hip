@@ -253,7 +253,14 @@ struct Chain {
     int32_t visited;       // hits visited since the last reset
     uint32_t cands;        // candidates fetched (diagnostics)
     bool emitted;          // set by an emission (cleared by whoever watches for it)
+#ifdef SWSEM_DIAG_PHASES
+    uint64_t tRefill, tVisit, tLcp;   // shader-clock ticks between issuing a window's table gathers / a visit's loads / a run continuation and having the data
+    uint32_t nRefill, nLcp;
+#endif
 };
+#ifdef SWSEM_DIAG_PHASES
+__device__ unsigned long long g_diag[8];   // sums over the blocks of a launch: total, refill wait, visit wait, refills, visits, lcp wait, lcp steps, blocks
+#endif
 
 constexpr int RING = 64;
 
@@ -454,7 +461,13 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
             const uint64_t d = c - lo;
             const uint32_t jmax = (uint64_t) i < d ? (uint32_t) i : (uint32_t) d;
             bool more;
+#ifdef SWSEM_DIAG_PHASES
+            const uint64_t dl0 = __builtin_amdgcn_s_memtime();
+#endif
             ell = (int32_t) wave_lcp_bwd(v.ref + c, q + i, (uint32_t) ell, jmax, 0, more);
+#ifdef SWSEM_DIAG_PHASES
+            ch.tLcp += __builtin_amdgcn_s_memtime() - dl0; ch.nLcp++;
+#endif
             flags &= ~HIT_CAPL;
         }
     };
@@ -504,7 +517,13 @@ __device__ bool process_hit(const RefView &v, const Contig &cg, const uint8_t *q
             const uint64_t a = hi - (c + K);
             const uint32_t b = (uint32_t) cg.n - (uint32_t) (i + K);
             bool more;
+#ifdef SWSEM_DIAG_PHASES
+            const uint64_t dl0 = __builtin_amdgcn_s_memtime();
+#endif
             rext = (int32_t) wave_lcp_fwd(v.ref + c + K, q + i + K, (uint32_t) rext, a < b ? (uint32_t) a : b, 0, more);
+#ifdef SWSEM_DIAG_PHASES
+            ch.tLcp += __builtin_amdgcn_s_memtime() - dl0; ch.nLcp++;
+#endif
             flags &= ~HIT_CAPR;
         }
         if (K + rext + s > (int32_t) v.minLen) {
@@ -554,8 +573,14 @@ __device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stac
     const int32_t rel = 4 * lane - LEFTW;                             // first byte of the lane's dword, relative to the candidate
     const bool full = lane < LL ? -rel <= limL : rel + 4 <= K + limR; // the dword lies inside its run's limit
     uint32_t x = 0;
+#ifdef SWSEM_DIAG_PHASES
+    const uint64_t dv0 = __builtin_amdgcn_s_memtime();
+#endif
     if (full) x = ld_u32(r0 + rel) ^ ld_u32(q0 + rel);
     const unsigned long long stopAll = __ballot(!full || x != 0);
+#ifdef SWSEM_DIAG_PHASES
+    ch.tVisit += __builtin_amdgcn_s_memtime() - dv0;
+#endif
     const unsigned long long fwd = stopAll >> LL;                     // bit t: lane LL + t
     if (fwd & ((1ull << (K / 4)) - 1)) { ch.scan = i + 1; return; }   // K-mer differs (its lanes are always inside the limits)
     const unsigned long long fullAll = __ballot(full);
@@ -653,6 +678,9 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
                 default: __builtin_amdgcn_s_setprio(3); break;
             }
             wb = s;
+#ifdef SWSEM_DIAG_PHASES
+            const uint64_t dt0 = __builtin_amdgcn_s_memtime();
+#endif
             const int32_t pos = s + lane;
             uint32_t e = 0;
             uint32_t hf = 0;
@@ -667,6 +695,9 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
             }
             w = e;
             m = __ballot(w != 0);
+#ifdef SWSEM_DIAG_PHASES
+            ch.tRefill += __builtin_amdgcn_s_memtime() - dt0; ch.nRefill++;
+#endif
         }
         const unsigned long long mk = m & ~((1ull << (s - wb)) - 1);
         if (!mk) { ch.scan = wb + WL < p1 ? wb + WL : p1; continue; }
@@ -793,6 +824,9 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     const uint32_t *cd = cand + cg.candBase;
     Chain ch;
     ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
+#ifdef SWSEM_DIAG_PHASES
+    ch.tRefill = ch.tVisit = ch.tLcp = 0; ch.nRefill = ch.nLcp = 0;
+#endif
     const uint64_t tstart = __builtin_amdgcn_s_memtime();
 #ifdef SWSEM_DIAG_T0
     const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
@@ -821,6 +855,14 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     r.emits = (uint32_t) __builtin_amdgcn_s_memrealtime();
 #endif
     if (threadIdx.x == 0) recs[g] = r;
+#ifdef SWSEM_DIAG_PHASES
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_diag[0], (unsigned long long) r.cycles); atomicAdd(&g_diag[1], (unsigned long long) ch.tRefill);
+        atomicAdd(&g_diag[2], (unsigned long long) ch.tVisit); atomicAdd(&g_diag[3], (unsigned long long) ch.nRefill);
+        atomicAdd(&g_diag[4], (unsigned long long) ch.cands); atomicAdd(&g_diag[5], (unsigned long long) ch.tLcp);
+        atomicAdd(&g_diag[6], (unsigned long long) ch.nLcp); atomicAdd(&g_diag[7], 1ull);
+    }
+#endif
 }
 
 __device__ __forceinline__ bool same_match(const Match &a, const Match &b) {

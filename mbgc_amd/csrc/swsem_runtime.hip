@@ -1178,6 +1178,17 @@ int swsem_debug_block_times(swsem_t *h, uint64_t *out, uint64_t cap, uint64_t *n
     return SWSEM_OK;
 }
 
+#ifdef SWSEM_DIAG_PHASES
+// diagnostics build only: phase sums of every resolve launch since the last call (g_diag), then reset
+int swsem_debug_phases(swsem_t *h, uint64_t *out) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long z[8] = {0};
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(swk::g_diag), sizeof z));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(swk::g_diag), z, sizeof z));
+    return SWSEM_OK;
+}
+#endif
+
 // diagnostics: one raw 64-bit table entry
 int swsem_debug_ht_entry(swsem_t *h, uint64_t bucket, uint64_t *out) {
     HIPCHK(hipStreamSynchronize(h->stream));
