@@ -254,6 +254,8 @@ def main():
     base = synth.base_codes(args.length)
     sched = round_schedule(n_targets, R, world)
     mine_all = [1 + t for rnd in sched for t in rnd[rank]]
+    if os.environ.get("MBGC_BENCH_SAME"):               # experiment: every target of a round is the same genome (perfect inter-target locality)
+        mine_all = [1 + rnd[rank][0] for rnd in sched for t in rnd[rank]]
     t_gen = time.perf_counter()
     gens = synth.genomes(base, mine_all, workers=max(1, min(16, (os.cpu_count() or 1) // world)),
                          fork=os.environ.get("MBGC_BENCH_GEN", "fork") != "thread")   # (threads under a profiler that has already opened the GPU)

@@ -6,7 +6,8 @@
 namespace swk {
 
 constexpr int WAVE = 64;
-constexpr int TILE = 4096;            // query positions per probe tile (= one resolve block)
+constexpr int TILE = 4096;            // query positions per probe tile (dense probe / hash-ahead kernels)
+constexpr int RBU = 1024;             // unit of a resolve block's length: a block scans rb * RBU query positions
 constexpr int PROBE_THREADS = 256;
 constexpr int POS_PER_THREAD = TILE / PROBE_THREADS;
 constexpr int OVERLAP_MATCH_MAX_LENGTH = 1 << 13;   // SlidingWindowSparseEMMatcher.h:18
@@ -33,7 +34,7 @@ struct Contig {
     uint32_t tile0;    // first tile of this contig
     uint32_t ntiles;
     uint32_t rb0;      // first resolve block of this contig
-    uint32_t nrb;      // resolve blocks (= ceil(ntiles / tiles per resolve block))
+    uint32_t nrb;      // resolve blocks (= ceil(positions / (rb * RBU)))
 };
 
 // frozen matcher state seen by the kernels of one round

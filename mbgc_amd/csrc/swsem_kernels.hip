@@ -819,8 +819,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     const Contig cg = contigs[rbContig[g]];
     const uint32_t b = g - cg.rb0;
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
-    const int32_t w0 = (int32_t) (b * rb * TILE);
-    const int32_t w1 = w0 + (int32_t) (rb * TILE) < npos ? w0 + (int32_t) (rb * TILE) : npos;
+    const int32_t w0 = (int32_t) (b * rb * RBU);
+    const int32_t w1 = w0 + (int32_t) (rb * RBU) < npos ? w0 + (int32_t) (rb * RBU) : npos;
     const uint32_t *cd = cand + cg.candBase;
     Chain ch;
     ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(256) k_stitch_pre(const Contig *__restrict__ c
         if (visited) f.popB = 0;                                      // started from the true (empty) state: spB = minKeep = 0
     } else if (visited && cur.minTouched >= 0) {
         const BlockRec &prv = recs[g - 1];
-        const int32_t span = (int32_t) (rb * TILE), w0 = (int32_t) b * span;
+        const int32_t span = (int32_t) (rb * RBU), w0 = (int32_t) b * span;
         const int32_t pScanF = (int32_t) prv.scanF;
         const int cmp = cur.spB - cur.minTouched;
         const int prevPush = prv.spF - prv.minKeep;
@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     int known = 0;                     // rows of ptop that are valid
     uint32_t replayed = 0;
     const BlockRec *rc = recs + cg.rb0;
-    const int32_t span = (int32_t) (rb * TILE);
+    const int32_t span = (int32_t) (rb * RBU);
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
     __shared__ uint4 srec[sizeof(BlockRec) / 16];
     bool prevPlain = true;             // the block before was accepted as speculated (block 0: the empty state is what it assumed)

@@ -4,6 +4,7 @@
 // the hash table and every per-round intermediate live in HBM.
 #include "../../include/mbgc_swsem.h"
 #include "swsem_kernels.hip"
+#include "swsem_resolve4.hip"
 #include "swsem_emit.hip"
 
 #include <algorithm>
@@ -113,6 +114,8 @@ struct swsem {
     DevBuf<uint32_t> dTileContig, dMatchCount, dRbContig, dRbOrder, dCand;
     std::vector<uint32_t> rbOrderHost, rbOrderKey;   // the table on the device is kept while the batches keep their shape (rbOrderKey)
     int orderMode = 1;                     // launch order of the resolve blocks: 0 contig-major, 1 offset-major on one XCD (SWSEM_ORDER)
+    bool simt = true;                      // four chains per wave (k_resolve_blocks4); SWSEM_CHAINS=1: one chain per wave (k_resolve_blocks)
+    uint32_t chainsPerWave = 1;            // of the last batch
     // K-mer hashes of a batch announced ahead (swsem_hash_batch_dev): computed on a third stream into the other
     // hash buffer while the current batch is still being matched; swsem_match_batch_dev on the same buffers adopts them
     DevBuf<uint32_t> dCandNext, dPrepTileContig;
@@ -185,7 +188,7 @@ struct swsem {
     hipEvent_t evP1 = nullptr;
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
-    uint32_t rb = 4;                       // probe tiles per resolve block: chosen per batch (run_batch) unless SWSEM_RB fixes it
+    uint32_t rb = 8;                       // length of a resolve block in units of RBU positions: chosen per batch (run_batch) unless SWSEM_RB fixes it
     uint32_t rbFixed = 0;
     uint32_t waveSlots = 256 * 4 * RESOLVE_WAVES_PER_SIMD;   // resolve waves the device holds at once (CUs x SIMDs x waves)
     std::vector<Contig> contigs;
@@ -561,46 +564,48 @@ int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n
 // consecutive slots of ONE XCD, so one of them fetches a sector from HBM and the others find it in that L2. Groups
 // larger than 64 blocks are cut (a batch of many one-block contigs must still spread over the chip), every piece goes
 // to the XCD with the shortest list so far, and the lists are padded to one length with empty slots.
-bool build_resolve_order(swsem *h, uint32_t rblocks) {
+bool build_resolve_order(swsem *h, uint32_t rblocks, uint32_t per) {
     std::vector<uint32_t> key;
-    key.reserve(h->contigs.size() + 2);
-    key.push_back((uint32_t) h->orderMode); key.push_back(rblocks);
+    key.reserve(h->contigs.size() + 3);
+    key.push_back((uint32_t) h->orderMode); key.push_back(rblocks); key.push_back(per);
     for (auto &cg : h->contigs) key.push_back(cg.nrb);
     if (key == h->rbOrderKey && !h->rbOrderHost.empty()) return false;       // same shape as the last batch: the device table stands
     h->rbOrderKey.swap(key);
     std::vector<uint32_t> &order = h->rbOrderHost;
     order.clear();
-    if (h->orderMode == 0) {
-        order.resize(rblocks);
+    if (h->orderMode == 0) {                                                 // contig-major: blocks in their canonical order
+        order.assign((size_t) ((rblocks + per - 1) / per) * per, 0xFFFFFFFFu);
         for (uint32_t g = 0; g < rblocks; g++) order[g] = g;
         return true;
     }
     uint32_t maxNrb = 0;
     for (auto &cg : h->contigs) maxNrb = std::max(maxNrb, cg.nrb);
-    // contigs by descending block count would let every group be a prefix; a plain pass per offset over the contigs that
-    // still have a block there is O(blocks) as well once contigs are bucketed by nrb
+    // contigs by descending block count: the contigs that still have a block at offset b are a prefix
     std::vector<uint32_t> byLen(h->contigs.size());
     for (uint32_t c = 0; c < byLen.size(); c++) byLen[c] = c;
     std::stable_sort(byLen.begin(), byLen.end(), [&](uint32_t a, uint32_t b) { return h->contigs[a].nrb > h->contigs[b].nrb; });
-    std::vector<uint32_t> lists[8];
+    std::vector<uint32_t> lists[8];                                          // wave slots (per block ids each) of every XCD
     std::vector<uint32_t> grp;
     size_t alive = byLen.size();
+    const size_t piece = 64;                                                 // blocks of one offset kept together on an XCD
     for (uint32_t b = 0; b < maxNrb; b++) {
         while (alive && h->contigs[byLen[alive - 1]].nrb <= b) alive--;
         grp.assign(byLen.begin(), byLen.begin() + alive);
-        std::sort(grp.begin(), grp.end());                               // contig order inside a group
-        for (size_t i = 0; i < grp.size(); i += 64) {
+        if (!std::is_sorted(grp.begin(), grp.end())) std::sort(grp.begin(), grp.end());   // contig order inside a group
+        for (size_t i = 0; i < grp.size(); i += piece) {
             int best = 0;
             for (int x = 1; x < 8; x++) if (lists[x].size() < lists[best].size()) best = x;
-            const size_t e = std::min(grp.size(), i + 64);
+            const size_t e = std::min(grp.size(), i + piece);
             for (size_t k = i; k < e; k++) lists[best].push_back(h->contigs[grp[k]].rb0 + b);
+            while (lists[best].size() % per) lists[best].push_back(0xFFFFFFFFu);          // the last wave of the piece may run fewer chains
         }
     }
     size_t len = 0;
-    for (auto &l : lists) len = std::max(len, l.size());
-    order.assign(len * 8, 0xFFFFFFFFu);
+    for (auto &l : lists) len = std::max(len, l.size() / per);
+    order.assign(len * 8 * per, 0xFFFFFFFFu);
     for (int x = 0; x < 8; x++)
-        for (size_t j = 0; j < lists[x].size(); j++) order[j * 8 + x] = lists[x][j];
+        for (size_t j = 0; j < lists[x].size() / per; j++)
+            for (uint32_t k = 0; k < per; k++) order[(j * 8 + x) * per + k] = lists[x][j * per + k];
     return true;
 }
 
@@ -621,14 +626,16 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         // Block chains are latency-bound and a launch lasts as long as its slowest wave: the blocks are sized so
         // that all of them are resident at once (one wave each, RESOLVE_WAVES_PER_SIMD per SIMD) and there are as many as that allows.
         // Fewer, longer blocks leave wave slots empty; more of them run in two generations and lengthen the
-        // sequential stitch. At least two tiles, so that the warm-up stays a small part of a block.
-        uint64_t allTiles = 0;
+        // sequential stitch. At least 8 units (8192 positions), so that the warm-up stays a small part of a block.
+        uint64_t allTiles = 0;                          // in units of RBU positions
         for (int c = 0; c < n; c++) {
             const uint64_t len = offsets[c + 1] - offsets[c];
-            allTiles += len >= (uint64_t) h->K ? (len - h->K + 1 + TILE - 1) / TILE : 0;
+            allTiles += len >= (uint64_t) h->K ? (len - h->K + 1 + RBU - 1) / RBU : 0;
         }
-        const uint64_t slots = std::max<uint64_t>(1, (uint64_t) h->waveSlots * 19 / 20);
-        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(16, std::max<uint64_t>(2, (allTiles + slots - 1) / slots));
+        h->chainsPerWave = (h->simt && h->lazyProbe && h->flyHash && !h->seqResolve && h->K <= K_MAX4) ? (uint32_t) GC : 1u;
+        const uint64_t waves = h->chainsPerWave > 1 ? (uint64_t) h->waveSlots / RESOLVE_WAVES_PER_SIMD * RESOLVE4_WAVES_PER_SIMD : h->waveSlots;
+        const uint64_t slots = std::max<uint64_t>(1, waves * h->chainsPerWave * 19 / 20);
+        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(64, std::max<uint64_t>(8, (allTiles + slots - 1) / slots));
     }
     for (int c = 0; c < n; c++) {
         Contig &cg = h->contigs[c];
@@ -645,7 +652,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         cg.matchBase = matchRows;
         matchRows += cg.n / minLen + 2;
         cg.rb0 = rblocks;
-        cg.nrb = (cg.ntiles + h->rb - 1) / h->rb;
+        cg.nrb = (uint32_t) ((npos + (uint64_t) h->rb * RBU - 1) / ((uint64_t) h->rb * RBU));
         for (uint32_t t = 0; t < cg.ntiles; t++) tileContig.push_back((uint32_t) c);
         for (uint32_t t = 0; t < cg.nrb; t++) rbContig.push_back((uint32_t) c);
         tiles += cg.ntiles;
@@ -665,13 +672,13 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     uint32_t rslots = 0;
     if (tiles) {
         const uint32_t *had = h->dRbOrder.p;
-        const bool fresh = build_resolve_order(h, rblocks);
-        rslots = (uint32_t) h->rbOrderHost.size();
-        if ((r = h->dRbOrder.reserve(rslots + rslots / 4 + 64))) return r;
+        const bool fresh = build_resolve_order(h, rblocks, h->chainsPerWave);
+        rslots = (uint32_t) (h->rbOrderHost.size() / h->chainsPerWave);
+        if ((r = h->dRbOrder.reserve(h->rbOrderHost.size() + h->rbOrderHost.size() / 4 + 64))) return r;
         if ((r = upload(h, h->dTileContig.p, tileContig.data(), tiles * sizeof(uint32_t), h->stream)) ||
             (r = upload(h, h->dRbContig.p, rbContig.data(), rblocks * sizeof(uint32_t), h->stream)))
             return r;
-        if ((fresh || had != h->dRbOrder.p) && (r = upload(h, h->dRbOrder.p, h->rbOrderHost.data(), rslots * sizeof(uint32_t), h->stream)))
+        if ((fresh || had != h->dRbOrder.p) && (r = upload(h, h->dRbOrder.p, h->rbOrderHost.data(), h->rbOrderHost.size() * sizeof(uint32_t), h->stream)))
             return r;
     }
     if ((r = zero_dev(h, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) || (r = flush_copies(h))) return r;
@@ -701,7 +708,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         h->mark(SWSEM_K_RESOLVE, false);
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
-        const uint32_t cap = (uint32_t) ((h->rb * TILE + OVERLAP + h->K) / h->K + 8);
+        const uint32_t cap = (uint32_t) ((h->rb * RBU + OVERLAP + h->K) / h->K + 8);
         if ((r = h->dRegions.reserve((size_t) rblocks * cap))) return r;
         if ((r = h->dReplay.reserve((size_t) n * cap))) return r;
         if ((r = h->dRecs.reserve(rblocks))) return r;
@@ -713,7 +720,11 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         h->mark(SWSEM_K_RESOLVE, true);
 #define SWSEM_LAUNCH_RB(M, W) k_resolve_blocks<M, W><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dCand.p, \
                                                                                       h->dRegions.p, cap, h->rb, h->dRecs.p)
-        SWSEM_BY_MODE(SWSEM_LAUNCH_RB);
+        if (h->chainsPerWave == (uint32_t) GC) {
+            if (wrapped) k_resolve_blocks4<true><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
+            else k_resolve_blocks4<false><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
+        } else
+            SWSEM_BY_MODE(SWSEM_LAUNCH_RB);
 #undef SWSEM_LAUNCH_RB
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
@@ -859,8 +870,9 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_HASH")) h->flyHash = strcmp(e, "pre") != 0;
     if (h->K > 128) h->flyHash = false;                               // (a window's bytes must fit one dword per lane)
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
+    if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_ORDER")) h->orderMode = strcmp(e, "contig") == 0 ? 0 : 1;
-    if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 64) h->rbFixed = (uint32_t) x; }
+    if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
         hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
