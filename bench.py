@@ -460,7 +460,8 @@ def check_against_oracle(runner, base, targets, length, emit, max_ref):
     from mbgc_amd import synth
     o = _orc.OracleMatcher(max_ref)
     if emit:
-        res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [synth.genome(base, 0)],
+        op = _orc.emit_params(1, enable40bitReference=1 if max_ref > 0xFFFFFFFF else 0)
+        res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o, op), [synth.genome(base, 0)],
                                     [[synth.genome(base, 1 + t)] for t in targets], len(targets))
         for k, v in res["streams"].items():
             assert bytes(runner.streams[k]) == v, "stream %s differs from the oracle" % k

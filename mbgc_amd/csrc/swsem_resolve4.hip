@@ -149,6 +149,13 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
     int32_t wb = -0x40000000;                      // scan window [wb, wb + GL)
     uint32_t went = 0, m16 = 0;                    // this lane's table value in the window / the group's candidate lanes
     int32_t qb0 = 0, qlo = 0, qhi = 0;             // query cache: first byte position of the buffer, valid positions [qlo, qhi)
+#ifndef SWSEM_SYNC_SPAN
+#define SWSEM_SYNC_SPAN 0
+#endif
+    // The four chains of a wave scan the same offsets of four contigs; kept within SWSEM_SYNC_SPAN positions of each
+    // other (a chain that has run ahead waits at the next multiple) their lookups keep falling into the same sectors.
+    int32_t syncRel = SWSEM_SYNC_SPAN;             // wave-uniform: no window is opened at or beyond this offset from the chain's first position
+    const int32_t start0 = scan;
 
     while (true) {
         // ---- leaving a range: the block boundary (snapshot), then the block's end (record)
@@ -186,7 +193,8 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
         if (__ballot(phase != 2) == 0) break;
         // One iteration: the chains that have left their window look the next 16 positions up (doR), then every chain
         // with a candidate at or after its scan position visits it (doV) — the chains that just looked up included.
-        const bool doR = phase != 2 && (scan < wb || scan >= wb + GL);
+        if (SWSEM_SYNC_SPAN && __ballot(phase != 2 && scan - start0 < syncRel) == 0) syncRel += SWSEM_SYNC_SPAN;
+        const bool doR = phase != 2 && (scan < wb || scan >= wb + GL) && (!SWSEM_SYNC_SPAN || scan - start0 < syncRel);
 
         // ---- doR, issue: K-mer hashes of the window (run_chain_lazy's refill), then the table gather
         int32_t cnt = 0;
@@ -255,7 +263,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
 
         // ---- first candidate at or after the scan position; a window without one is left behind
         uint32_t mk = 0;
-        if (phase != 2) {
+        if (phase != 2 && scan >= wb && scan < wb + GL) {              // (a chain waiting for the others stands outside its window)
             mk = m16 & (0xFFFFu << (uint32_t) (scan - wb)) & 0xFFFFu;
             if (!mk) scan = wb + GL < p1 ? wb + GL : p1;
         }

@@ -27,6 +27,11 @@ CASES = {
     "seq_m2": (5, 50_000, 0.02, 102, 0, 1, 0, 2),
     "rounds3_wrap": (11, 50_000, 0.015, 103, 400_000, 2, 3, 1),
     "rounds4_divergent": (9, 40_000, 0.06, 104, 2_000_000, 1, 4, 1),
+    # 40-bit reference offsets (MGMP.cpp:159-166, MBGC_Encoder.cpp:229-234): a buffer longer than 2^32 bytes, the loader
+    # stood just below 2^32 (setPosition, SlidingWindowSparseEMMatcher.h:110-113) so that the collection's later genomes
+    # lie beyond it — their matches carry a fifth offset byte (mapOff5th). Two more fields: start position, 40-bit flag.
+    "seq_bit40": (6, 200_000, 0.012, 105, (1 << 32) + 6_000_000, 2, 0, 1, (1 << 32) - 500_000, 1),
+    "rounds3_bit40": (8, 150_000, 0.012, 106, (1 << 32) + 6_000_000, 1, 3, 1, (1 << 32) - 400_000, 1),
 }
 
 
@@ -36,12 +41,17 @@ def split(g, k):
 
 
 def inputs(case):
-    n, length, div, seed, lim, cpt, rs, mode = CASES[case]
+    n, length, div, seed, lim, cpt, rs, mode = CASES[case][:8]
     base = synth.base_codes(length, seed)
     gs = [synth.genome(base, i, div) for i in range(n)]
     if not lim:
         lim, _ = _driver.ref_length_limit(n, length)
     return gs, lim, cpt, rs, mode
+
+
+def extras(case):
+    c = CASES[case]
+    return (int(c[8]), bool(c[9])) if len(c) > 8 else (0, False)
 
 
 def ht_digest(ht):
@@ -56,10 +66,13 @@ def run_reference(case):
     gs, lim, cpt, rs, mode = inputs(case)
     margin = 24 if mode >= 2 else 16
     r = _refh.RefMatcher(lim, skip_margin=margin)
+    start, bit40 = extras(case)
+    if start:
+        r.set_position(start, 0)
     pol = _driver.Policy(mode)
     if rs == 0:
         files = [split(g, cpt) for g in gs]
-        ad = RefEmitAdapter(_refh, r, 1, mode)
+        ad = RefEmitAdapter(_refh, r, 1, mode, bit40=bit40)
 
         class E:
             def process(s, *a): return ad.view(0).process(*a)
@@ -70,7 +83,7 @@ def run_reference(case):
         streams = em.streams()
     else:
         targets = [split(g, cpt) for g in gs[1:]]
-        ad = RefEmitAdapter(_refh, r, n_targets=len(targets), mode=mode)
+        ad = RefEmitAdapter(_refh, r, n_targets=len(targets), mode=mode, bit40=bit40)
         cnt = {"t": 0}
 
         def make():
@@ -89,13 +102,13 @@ def run_reference(case):
     out["match_counts"] = np.array([len(m) for m in res["matches"]], dtype=np.uint64)
     out["ht_sha256"] = np.array(ht_digest(r.ht()))
     out["loaded_ref_length"] = np.array(r.loaded_ref_length(), dtype=np.uint64)
-    out["case"] = np.array(list(CASES[case]), dtype=np.float64)
+    out["case"] = np.array(list(CASES[case]), dtype=np.float64)      # (2^32-sized values are exact in float64)
     return out
 
 
 if __name__ == "__main__":
     assert _refh.available(), "build oracle/_ref first (make -C oracle ref)"
-    for case in CASES:
+    for case in (sys.argv[1:] or CASES):
         out = run_reference(case)
         np.savez_compressed(os.path.join(HERE, case + ".npz"), **out)
         print(case, "matches", len(out["matches"]), "literals", out["stream_literals"].size, "flags", out["stream_flags"].size)

@@ -10,7 +10,7 @@ import _driver
 import _orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["seq_m1", "seq_m2", "rounds3_wrap", "rounds4_divergent"]
+CASES = ["seq_m1", "seq_m2", "rounds3_wrap", "rounds4_divergent", "seq_bit40", "rounds3_bit40"]
 
 
 def load(case):
@@ -19,13 +19,19 @@ def load(case):
     # only the input recipe is needed (no reference import on this host): restate it here
     from mbgc_amd import synth
     d = np.load(os.path.join(GOLDEN, case + ".npz"))
-    n, length, div, seed, lim, cpt, rs, mode = d["case"]
+    n, length, div, seed, lim, cpt, rs, mode = d["case"][:8]
     n, length, seed, lim, cpt, rs, mode = int(n), int(length), int(seed), int(lim), int(cpt), int(rs), int(mode)
     base = synth.base_codes(length, seed)
     gs = [synth.genome(base, i, float(div)) for i in range(n)]
     if not lim:
         lim, _ = _driver.ref_length_limit(n, length)
     return d, gs, lim, cpt, rs, mode
+
+
+def extras(d):
+    """(loader position to start from, 40-bit offsets) of the cases that have them"""
+    c = d["case"]
+    return (int(c[8]), bool(c[9])) if len(c) > 8 else (0, False)
 
 
 def split(g, k):
@@ -44,6 +50,9 @@ def ht_digest(ht):
 def run_case(case, matcher, make_emitter):
     d, gs, lim, cpt, rs, mode = load(case)
     pol = _driver.Policy(mode)
+    start, bit40 = extras(d)
+    if start:
+        matcher.set_position(start, 0)
     if rs == 0:
         em = make_emitter()
         res = _driver.encode_sequential(matcher, em, [split(g, cpt) for g in gs], pol)
@@ -58,6 +67,8 @@ def run_case(case, matcher, make_emitter):
     assert res["locks"] == d["locks"].tobytes() and res["refExtSize"] == d["refExtSize"].tobytes()
     assert matcher.loaded_ref_length() == int(d["loaded_ref_length"])
     assert ht_digest(matcher.ht()) == str(d["ht_sha256"])
+    if bit40:                                         # the fifth offset byte is in use: some match lies beyond 2^32
+        assert len(streams["mapOff5th"]) > 0 and max(streams["mapOff5th"]) == 1 and int(d["matches"][:, 0].max()) >= 1 << 32
 
 
 def margin(case):
@@ -68,7 +79,7 @@ def margin(case):
 def test_oracle_reproduces_reference_fixtures(case):
     d, gs, lim, cpt, rs, mode = load(case)
     o = _orc.OracleMatcher(lim, skip_margin=margin(case))
-    run_case(case, o, lambda: _orc.OracleEmitter(o, _orc.emit_params(mode)))
+    run_case(case, o, lambda: _orc.OracleEmitter(o, _orc.emit_params(mode, enable40bitReference=int(extras(d)[1]))))
 
 
 @pytest.mark.gpu
@@ -78,7 +89,7 @@ def test_hip_reproduces_reference_fixtures(case):
     from test_gpu_emit import HipEmitter
     d, gs, lim, cpt, rs, mode = load(case)
     h = binding.SlidingWindowSparseEMMatcher(lim, skip_margin=margin(case))
-    run_case(case, h, lambda: HipEmitter(binding, h, binding.emit_params(mode)))
+    run_case(case, h, lambda: HipEmitter(binding, h, binding.emit_params(mode, enable40bitReference=int(extras(d)[1]))))
 
 
 def test_listeria_fingerprints_recorded():

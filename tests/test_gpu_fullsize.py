@@ -129,6 +129,55 @@ def test_configs2_all_rounds_through_the_wrap_equal_oracle():
     assert sum(len(v) for v in exp["streams"].values()) > 500_000_000     # ~0.14 B per base of 5 Gbases
 
 
+def test_offsets_beyond_4g_rounds_equal_oracle():
+    """40-bit reference offsets at full genome size (what bench.py --gpus >= 3 runs: the 4.35e9-byte buffer `mbgc c` gives
+    2049..8192 files, 2^29 buckets, enable40bitReference, MGMP.cpp:159-166): the loader is stood 20 MB below 2^32
+    (setPosition), so the rounds' genomes are loaded across and beyond it and later rounds match there — the six streams
+    (mapOff5th among them), locks, refExtSize and the table image against the oracle on the same schedule."""
+    import os
+    import torch
+    from mbgc_amd import binding
+    from mbgc_amd.rounds import RoundRunner
+    NT, RR = 24, 8
+    MAXREF, bit40 = _driver.ref_length_limit(8001, L)
+    assert MAXREF > 1 << 32 and bit40
+    START = (1 << 32) - 20_000_000
+    base = synth.base_codes(L)
+    gs = synth.genomes(base, range(NT + 1), fork=False)
+    o = _orc.OracleMatcher(MAXREF)
+    o.set_position(START, 0)
+    op = _orc.emit_params(1, enable40bitReference=1)
+    exp = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o, op), [gs[0]], [[g] for g in gs[1:]], RR,
+                                threads=min(16, os.cpu_count() or 1), keep_matches=False)
+    assert len(exp["streams"]["mapOff5th"]) > 0 and max(exp["streams"]["mapOff5th"]) == 1
+    h = binding.SlidingWindowSparseEMMatcher(MAXREF)
+    assert h.hash_size() == 1 << 29
+    h.set_position(START, 0)
+    h.set_sliding_window_size(16)
+    g0 = torch.from_numpy(gs[0]).to("cuda:0")
+    torch.cuda.synchronize()
+    h.load_ref_dev(g0.data_ptr(), g0.numel(), True, True, 0)
+    runner = RoundRunner(h, 0, 1, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1, enable40bitReference=1), keep_streams=True)
+    runner.start()
+    bufs = []
+    for r0 in range(1, NT + 1, RR):
+        chunk = gs[r0:r0 + RR]
+        offs = np.zeros(len(chunk) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([c.size for c in chunk])
+        bufs.append((torch.from_numpy(np.concatenate(chunk)).to("cuda:0"), offs))
+    torch.cuda.synchronize()
+    got_counts = []
+    for i, (buf, offs) in enumerate(bufs):
+        got_counts += [int(x) for x in runner.run_round(buf, offs, next_batch=bufs[i + 1] if i + 1 < len(bufs) else None)]
+    runner.flush()
+    assert got_counts == list(exp["matches"])
+    for k, v in exp["streams"].items():
+        assert bytes(runner.streams[k]) == v, "stream %s differs (%d vs %d bytes)" % (k, len(runner.streams[k]), len(v))
+    assert bytes(runner.locks_stream) == exp["locks"] and bytes(runner.ref_ext_sizes) == exp["refExtSize"]
+    assert h.loading_position() == o.loading_position() and h.ref_length() == o.ref_length() == MAXREF   # (and the buffer has wrapped beyond 2^32)
+    assert np.array_equal(h.ht(), o.ht())
+
+
 def test_configs1_round_trip_through_the_decoder():
     """size-independent property at full size, with no encoder oracle in the loop: rounds of 16 x 5 Mbp against the
     1.28e9-byte reference; every contig's six streams, decoded by the decoder's automaton (oracle/decode_oracle.c,

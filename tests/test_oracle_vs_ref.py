@@ -145,8 +145,8 @@ def test_prefilter_is_result_neutral():
 class RefEmitAdapter:
     """Gives the reference encoder harness the emitter interface of _driver."""
 
-    def __init__(self, refh, matcher, n_targets=1, mode=1, lazy=True):
-        self.e = refh.RefEmitter(matcher, mode=mode, lazy=lazy, n_targets=n_targets)
+    def __init__(self, refh, matcher, n_targets=1, mode=1, lazy=True, bit40=False):
+        self.e = refh.RefEmitter(matcher, mode=mode, lazy=lazy, bit40=bit40, n_targets=n_targets)
         self.pushed = 1
         self.extra = {}
 
