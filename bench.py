@@ -148,7 +148,7 @@ def cpu_all_cores(sample_targets, length):
     tool = os.path.join(ROOT, "oracle", "_ref", "mbgc")
     if not os.access(tool, os.X_OK):
         return None
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the cores this process may use
     d = tempfile.mkdtemp(prefix="mbgc_cpub_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
         base = synth.base_codes(length)
@@ -227,7 +227,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--round", type=int, default=0, help="targets per GPU per step (default: 1000 / (steps + warmup), at most 40)")
     ap.add_argument("--length", type=int, default=GENOME_LEN)
-    ap.add_argument("--cpu-sample", type=int, default=64, help="targets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="targets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--check", action="store_true", help="compare the first step's matches with the oracle")
     ap.add_argument("--no-emit", action="store_true", help="matcher only (no stream emission) inside the step")
     ap.add_argument("--from-host", action="store_true",

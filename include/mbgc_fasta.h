@@ -48,6 +48,14 @@ int mbgc_fasta_parse_batch_dev(mbgc_fasta_t *p, const uint8_t *files_dev, const 
                                mbgc_fasta_record_t *records, uint64_t recCap, uint64_t *recBase,
                                uint64_t *dnaLineLen, int *status);
 
+/* One file that sits in host memory and whose contigs the host needs as bytes — the first file of the list, whose
+ * sequences become the initial reference and the head of the literal stream (loadG0Ref, MGMP.cpp:66-150): uploaded,
+ * parsed by the same kernels, downloaded. seq_out_host has capacity n; records/recCap as above; *nrec, *seqBytes,
+ * *dnaLineLen, *status as the batch call reports them for its single file. */
+int mbgc_fasta_parse_host(mbgc_fasta_t *p, const uint8_t *file_host, uint64_t n, int uppercaseDNA, uint8_t *seq_out_host,
+                          uint64_t *seqBytes, mbgc_fasta_record_t *records, uint64_t recCap, uint64_t *nrec,
+                          uint64_t *dnaLineLen, int *status);
+
 #ifdef __cplusplus
 }
 #endif

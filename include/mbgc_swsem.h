@@ -197,6 +197,7 @@ int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *si
 int swsem_dev_malloc(swsem_t *h, uint64_t bytes, void **out_dev);
 int swsem_dev_free(swsem_t *h, void *p_dev);
 int swsem_dev_upload(swsem_t *h, void *dst_dev, const void *src_host, uint64_t bytes);   /* synchronous */
+int swsem_dev_download(swsem_t *h, void *dst_host, const void *src_dev, uint64_t bytes); /* synchronous */
 int swsem_dev_copy(swsem_t *h, void *dst_dev, const void *src_dev, uint64_t bytes);      /* on the handle's stream */
 
 /* ---- test / measurement hooks (not part of the reference surface) */

@@ -356,6 +356,7 @@ struct mbgc_fasta {
     fa::Buf<fa::FileOut> dOut;
     fa::Buf<uint64_t> dBases;
     fa::Buf<mbgc_fasta_record_t> dRecs;
+    fa::Buf<uint8_t> dHostIn, dHostOut;         // mbgc_fasta_parse_host: the file and its sequences on the device
 };
 
 extern "C" {
@@ -379,7 +380,7 @@ void mbgc_fasta_destroy(mbgc_fasta_t *p) {
     if (!p) return;
     (void) hipSetDevice(p->device);
     if (p->stream) { (void) hipStreamSynchronize(p->stream); (void) hipStreamDestroy(p->stream); }
-    p->dFiles.release(); p->dOwner.release(); p->dSums.release(); p->dIns.release(); p->dOut.release(); p->dBases.release(); p->dRecs.release();
+    p->dFiles.release(); p->dOwner.release(); p->dSums.release(); p->dIns.release(); p->dOut.release(); p->dBases.release(); p->dRecs.release(); p->dHostIn.release(); p->dHostOut.release();
     delete p;
 }
 
@@ -443,6 +444,25 @@ int mbgc_fasta_parse_batch_dev(mbgc_fasta_t *p, const uint8_t *files_dev, const 
         dnaLineLen[i] = st == MBGC_FASTA_OK ? L : 0;
     }
     seqBase[nf] = sb[nf]; recBase[nf] = rb[nf];
+    return 0;
+}
+
+int mbgc_fasta_parse_host(mbgc_fasta_t *p, const uint8_t *file_host, uint64_t n, int uppercaseDNA, uint8_t *seq_out_host,
+                          uint64_t *seqBytes, mbgc_fasta_record_t *records, uint64_t recCap, uint64_t *nrec,
+                          uint64_t *dnaLineLen, int *status) {
+    using namespace fa;
+    FCHK(hipSetDevice(p->device));
+    int r;
+    if ((r = p->dHostIn.reserve(std::max<uint64_t>(n, 1))) || (r = p->dHostOut.reserve(std::max<uint64_t>(n, 1)))) return r;
+    if (n) FCHK(hipMemcpy(p->dHostIn.p, file_host, n, hipMemcpyHostToDevice));
+    const uint64_t off[2] = {0, n};
+    uint64_t sb[2] = {0, 0}, rb[2] = {0, 0};
+    *nrec = 0; *seqBytes = 0;
+    if (n == 0) { *status = MBGC_FASTA_OK; *dnaLineLen = 0; return 0; }
+    r = mbgc_fasta_parse_batch_dev(p, p->dHostIn.p, off, 1, uppercaseDNA, p->dHostOut.p, n, sb, records, recCap, rb, dnaLineLen, status);
+    if (r) { *nrec = rb[1]; return r; }
+    *nrec = rb[1]; *seqBytes = sb[1];
+    if (sb[1]) FCHK(hipMemcpy(seq_out_host, p->dHostOut.p, sb[1], hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -912,9 +912,9 @@ void swsem_destroy(swsem_t *h) {
     h->dPrev.release(); h->dRbContig.release(); h->dRbOrder.release();
     for (auto &E : h->slot) E.release();
     h->dTables.release(); h->dGate.release(); h->dPred.release();
-    if (h->pin) { hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
-    if (h->ring) { hipHostFree(h->ring); h->ring = nullptr; h->ringCap = 0; }
-    for (auto &t : h->hostTables) { if (t.p) hipHostFree(t.p); if (t.ev) hipEventDestroy(t.ev); t = swsem::HostTab(); }
+    if (h->pin) { (void) hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
+    if (h->ring) { (void) hipHostFree(h->ring); h->ring = nullptr; h->ringCap = 0; }
+    for (auto &t : h->hostTables) { if (t.p) (void) hipHostFree(t.p); if (t.ev) (void) hipEventDestroy(t.ev); t = swsem::HostTab(); }
     if (h->stream2) { (void) hipStreamSynchronize(h->stream2); (void) hipStreamDestroy(h->stream2); }
     h->drain_events();
     for (auto &e : h->idle) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -1129,6 +1129,12 @@ int swsem_dev_free(swsem_t *h, void *p) {
 int swsem_dev_upload(swsem_t *h, void *dst_dev, const void *src, uint64_t bytes) {
     HIPCHK(hipSetDevice(h->device));
     if (bytes) HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SWSEM_OK;
+}
+int swsem_dev_download(swsem_t *h, void *dst, const void *src_dev, uint64_t bytes) {
+    HIPCHK(hipSetDevice(h->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SWSEM_OK;
 }

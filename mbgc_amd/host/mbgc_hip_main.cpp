@@ -4,6 +4,7 @@
 // stream order of MBGC_Decoder.cpp:1085-1112): literals(13) locksPos(14) gapDelta(15) flags(16)
 // mapOff(17) mapLen(18) refExtSize(19). Entropy coding (PPMd/LZMA) is the unchanged host backend of the
 // reference and is not part of this tool.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,10 +30,13 @@ int main(int argc, char **argv) {
         else if (a == "-R" && i + 1 < argc) params.roundSize = atoi(argv[++i]);
         else if (a == "-d" && i + 1 < argc) params.device = atoi(argv[++i]);
         else if (a == "-L") params.lazyDecompressionSupport = false;             // disable lazy decompression support
+        else if (a == "-U") params.uppercaseDNA = true;                          // MBGC_Params.h: converts bases to uppercase
+        else if (a == "--bench") params.benchMode = true;                        // rounds timed with every contig resident in HBM (no streams written)
+        else if (a == "--warmup" && i + 1 < argc) params.benchWarmup = atoi(argv[++i]);
         else pos.push_back(a);
     }
     if (pos.size() != 2) {
-        fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] <sequencesListFile> <outputPrefix>\n");
+        fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--bench [--warmup rounds]] <sequencesListFile> <outputPrefix>\n");
         return EXIT_FAILURE;
     }
     std::vector<std::string> files;
@@ -47,6 +51,14 @@ int main(int argc, char **argv) {
     }
     MBGC_Encoder enc(&params);
     enc.encode(files);
+    if (params.benchMode) {
+        // the C++ host's own measurement of the hot path (BASELINE.json metric): inputs resident in HBM, rounds of -R targets
+        printf("{\"metric\": \"input Gbases/s (compress hot path, C++ host)\", \"value\": %.4f, \"unit\": \"Gbases/s\", \"rounds\": %d, "
+               "\"warmup_rounds\": %d, \"targets_per_round\": %d, \"bases\": %llu, \"seconds\": %.6f, \"ms_per_round\": %.4f}\n",
+               params.benchBases / params.benchSeconds / 1e9, params.benchRounds, params.benchWarmup, params.roundSize,
+               (unsigned long long) params.benchBases, params.benchSeconds, params.benchSeconds * 1e3 / std::max(1, params.benchRounds));
+        return 0;
+    }
     dump(pos[1], "literals", enc.literals);
     dump(pos[1], "locksPos", enc.locksPosStream);
     dump(pos[1], "gapDelta", enc.gapDeltas);

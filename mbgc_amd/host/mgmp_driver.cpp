@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <time.h>
 
 using PgTools::TextMatch;
 
@@ -38,38 +39,111 @@ static void writeUInt64Frugal(std::string &dest, uint64_t value) {
     }
 }
 
-// Whole-file read + lossless FASTA split (the role of mgmpInOpen + kseq_read_lossless_fasta, MGMP.cpp:7-14,
-// utils/kseq.h:233-274): headers without '>', sequence lines joined, line ends dropped.
-bool readFastaFile(const std::string &path, std::vector<Contig> &out, uint64_t *fileSize) {
-    std::ifstream f(path, std::ios::binary);
+// ---------------------------------------------------------------- input stage
+// mgmpInOpen / whole-file read (MGMP.cpp:7-14; gz inflate is the host's libdeflate in the reference and is not part
+// of this repo) + kseq_read_lossless_fasta on the device (include/mbgc_fasta.h), status handling of
+// validate_kseq_status (MGMP.cpp:16-35).
+static bool readWholeFile(const std::string &path, std::string &dest) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
     if (!f) return false;
-    std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    if (fileSize) *fileSize = data.size();
-    out.clear();
-    size_t p = 0;
-    const size_t n = data.size();
-    if (n && data[0] != '>') {
-        fprintf(stderr, "Error parsing file %s - expected FASTA format.\n", path.c_str());
+    const std::streamoff n = f.tellg();
+    f.seekg(0);
+    const size_t at = dest.size();
+    dest.resize(at + (size_t) n);
+    if (n) f.read(&dest[at], n);
+    return (bool) f;
+}
+
+static void validate_kseq_status(const std::string &fileName, int status) {
+    if (status == MBGC_FASTA_OK) return;
+    fprintf(stderr, "Error parsing file %s", fileName.c_str());
+    if (status == MBGC_FASTA_ENOTFASTA) fprintf(stderr, " - expected FASTA format.\n");
+    else if (status == MBGC_FASTA_ELINES) fprintf(stderr, "\nDetected inconsistent line length in sequences.\n");
+    else fprintf(stderr, " - unknown error (code %d).\n", status);
+    exit(EXIT_FAILURE);
+}
+
+MultipleGenomeMatchingProcessor::~MultipleGenomeMatchingProcessor() {
+    if (matcher && rawDev) matcher->devFree(rawDev);
+    if (fasta) mbgc_fasta_destroy(fasta);
+    delete matcher;
+}
+
+void MultipleGenomeMatchingProcessor::openInputStage() {
+    if (!fasta && mbgc_fasta_create(&fasta, device) != 0) {
+        fprintf(stderr, "input stage: %s\n", mbgc_fasta_last_error());
         exit(EXIT_FAILURE);
     }
-    while (p < n) {
+}
+
+// the first file: its contigs are needed on the host (initial reference string, head of the literal stream)
+void MultipleGenomeMatchingProcessor::readG0(const std::string &path, std::vector<Contig> &out, uint64_t *fileSize) {
+    openInputStage();
+    std::string data;
+    if (!readWholeFile(path, data)) { fprintf(stderr, "cannot open file %s\n", path.c_str()); exit(EXIT_FAILURE); }
+    if (fileSize) *fileSize = data.size();
+    std::string seq(data.size(), '\0');
+    records.resize(data.size() / 2 + 2);
+    uint64_t seqBytes = 0, nrec = 0, lineLen = 0;
+    int status = 0;
+    if (mbgc_fasta_parse_host(fasta, (const uint8_t *) data.data(), data.size(), params->uppercaseDNA, (uint8_t *) &seq[0], &seqBytes,
+                              records.data(), records.size(), &nrec, &lineLen, &status) != 0) {
+        fprintf(stderr, "input stage: %s\n", mbgc_fasta_last_error());
+        exit(EXIT_FAILURE);
+    }
+    validate_kseq_status(path, status);
+    out.clear();
+    for (uint64_t k = 0; k < nrec; k++) {
         Contig c;
-        size_t e = data.find('\n', p);
-        if (e == std::string::npos) e = n;
-        c.header = data.substr(p + 1, e - p - 1);
-        if (!c.header.empty() && c.header.back() == '\r') c.header.pop_back();
-        p = e < n ? e + 1 : n;
-        while (p < n && data[p] != '>') {
-            e = data.find('\n', p);
-            if (e == std::string::npos) e = n;
-            size_t le = e;
-            if (le > p && data[le - 1] == '\r') le--;
-            c.seq.append(data, p, le - p);
-            p = e < n ? e + 1 : n;
-        }
+        c.header.assign(data, records[k].headerOff, records[k].headerLen);
+        c.seq.assign(seq, records[k].seqOff, records[k].seqLen);
         out.push_back(std::move(c));
     }
-    return true;
+}
+
+// files [f0, f1) of the list -> their contigs back to back in B.seqDev; contig c belongs to target targetBase + (file - f0)
+void MultipleGenomeMatchingProcessor::loadRound(uint32_t f0, uint32_t f1, RoundBatch &B) {
+    openInputStage();
+    const int nf = (int) (f1 - f0);
+    rawFiles.clear();
+    std::vector<uint64_t> fileOff(1, 0);
+    for (uint32_t f = f0; f < f1; f++) {
+        if (!readWholeFile(fileNames[f], rawFiles)) { fprintf(stderr, "cannot open file %s\n", fileNames[f].c_str()); exit(EXIT_FAILURE); }
+        fileOff.push_back(rawFiles.size());
+    }
+    totalFilesLength += rawFiles.size();
+    const size_t n = rawFiles.size();
+    if (n + 64 > rawCap) {                                   // grow-only: freeing device memory waits for the whole device
+        if (rawDev) matcher->devFree(rawDev);
+        rawCap = n + n / 4 + 64;
+        rawDev = matcher->devAlloc(rawCap);
+    }
+    if (n + 64 > B.seqCap) {
+        if (B.seqDev) matcher->devFree(B.seqDev);
+        B.seqCap = n + n / 4 + 64;
+        B.seqDev = matcher->devAlloc(B.seqCap);
+    }
+    matcher->devUpload(rawDev, rawFiles.data(), n);
+    std::vector<uint64_t> seqBase(nf + 1), recBase(nf + 1), lineLen(nf);
+    std::vector<int> status(nf);
+    if (records.size() < n / 2 + 2) records.resize(n / 2 + 2);
+    if (mbgc_fasta_parse_batch_dev(fasta, rawDev, fileOff.data(), nf, params->uppercaseDNA, B.seqDev, B.seqCap, seqBase.data(),
+                                   records.data(), records.size(), recBase.data(), lineLen.data(), status.data()) != 0) {
+        fprintf(stderr, "input stage: %s\n", mbgc_fasta_last_error());
+        exit(EXIT_FAILURE);
+    }
+    B.offsets.assign(1, 0);
+    B.targetOf.clear();
+    for (int f = 0; f < nf; f++) {
+        validate_kseq_status(fileNames[f0 + f], status[f]);
+        for (uint64_t k = recBase[f]; k < recBase[f + 1]; k++) {
+            // (the contigs of a file, and the files, follow each other without gaps: seqBase[f] + seqOff == the running offset)
+            largestContigSize = std::max<uint64_t>(largestContigSize, records[k].seqLen);
+            B.offsets.push_back(seqBase[f] + records[k].seqOff + records[k].seqLen);
+            B.targetOf.push_back((uint32_t) f);
+        }
+    }
+    B.bytes = seqBase[nf];
 }
 
 // ---------------------------------------------------------------- MultipleGenomeMatchingProcessor
@@ -93,10 +167,7 @@ void MultipleGenomeMatchingProcessor::initMatcher(const char *refStr, size_t ref
 void MultipleGenomeMatchingProcessor::loadG0Ref(const std::string &refName) {
     std::vector<Contig> contigs;
     uint64_t fileSize = 0;
-    if (!readFastaFile(refName, contigs, &fileSize)) {
-        fprintf(stderr, "cannot open file %s\n", refName.c_str());
-        exit(EXIT_FAILURE);
-    }
+    readG0(refName, contigs, &fileSize);
     std::string refStr;
     initStreamsForG0Ref();
     for (const Contig &c : contigs) {                                                          // MGMP.cpp:82-105
@@ -118,145 +189,298 @@ void MultipleGenomeMatchingProcessor::loadG0Ref(const std::string &refName) {
 }
 
 void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
-    std::vector<TextMatch> resMatches;
+    RoundBatch B;
     for (uint32_t i = 0; i < filesCount; i++) {
-        std::vector<Contig> contigs;
-        uint64_t fileSize = 0;
-        if (!readFastaFile(fileNames[i], contigs, &fileSize)) { fprintf(stderr, "cannot open file %s\n", fileNames[i].c_str()); exit(EXIT_FAILURE); }
-        const size_t startPos = matcher->getLoadedRefLength();                                 // MGMP.cpp:251
+        loadRound(i, i + 1, B);                                                                 // MGMP.cpp:247-250
+        const size_t startPos = matcher->getLoadedRefLength();                                 // :251
         unmatchedFractionFactors.push_back(params->currentUnmatchedFractionFactor < 256 ? params->currentUnmatchedFractionFactor : 0);
         unmatchedFractionFactors.push_back((uint8_t) params->unmatchedFractionRCFactor);
-        totalFilesLength += fileSize;
-        for (const Contig &c : contigs) {
-            largestContigSize = std::max<uint64_t>(largestContigSize, c.seq.size());
-            const size_t bSize = c.seq.size();
-            matcher->matchTexts(resMatches, c.seq.data(), bSize, false, false, params->k);     // :274
-            resCount += resMatches.size();
+        for (size_t c = 0; c + 1 < B.offsets.size(); c++) {
+            const size_t bSize = B.offsets[c + 1] - B.offsets[c];
+            const uint8_t *seq = B.seqDev + B.offsets[c];
+            std::vector<uint64_t> counts;
+            matcher->matchRound(seq, {0, bSize}, params->k, {}, counts);                       // :274 (no lock in this mode)
+            resCount += counts[0];
             const size_t currentUnmatched = processMatches(bSize, 0, SIZE_MAX);                // :276
             const bool loadContigToRef = params->isContigProperForRefExtension(bSize, currentUnmatched, params->currentUnmatchedFractionFactor);
             const bool loadContigRCToRef = params->rcInReference &&
                                            params->isContigProperForRefRCExtension(bSize, currentUnmatched, params->unmatchedFractionRCFactor);
             // :281-287: the contig, or the (always empty in release builds) literal extension
-            matcher->loadRef(c.seq.data(), loadContigToRef ? bSize : 0, loadContigRCToRef, params->refRegionSeparators, REF_REGION_SEPARATOR);
+            matcher->loadRefDev(seq, loadContigToRef ? bSize : 0, loadContigRCToRef, params->refRegionSeparators, REF_REGION_SEPARATOR);
             processAfterSequence(0);
         }
         processAfterTargetWithParallelIO(startPos);                                            // :306
     }
+    if (B.seqDev) matcher->devFree(B.seqDev);
 }
 
+// A round whose first pass gave up a contig as dissimilar (MGMP.cpp:382-388: "discard, wait until the earlier targets
+// are loaded, retry"): the deterministic form of that wait, with blocking calls — match + emit what is pending, load
+// the targets in front of the first given-up contig, redo everything from that contig on. Locks are held by the caller.
+void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B) {
+    const std::vector<uint64_t> &offsets = B.offsets;
+    const size_t ncont = B.targetOf.size();
+    const uint32_t r0 = B.t0, r1 = B.t1;
+    auto targetOf = [&](size_t c) { return B.t0 + B.targetOf[c]; };
+    uint8_t *dev = B.seqDev;
+    std::vector<int> pending(ncont);
+    for (size_t c = 0; c < ncont; c++) pending[c] = (int) c;
+    std::vector<uint64_t> unmatched(ncont, SIZE_MAX);
+    std::vector<EmittedStreams> emitted(ncont);
+    uint32_t finalized = r0;                                                                    // == processedTargetsCount
+    while (true) {
+        int cut = (int) ncont;                                                                  // first contig that has to be retried
+        if (!pending.empty()) {
+            // contigs from the first pending one on are consecutive in the buffer (everything after a cut is redone)
+            const int c0 = pending.front();
+            std::vector<uint64_t> offs, locks, counts;
+            std::vector<int> factors;
+            std::vector<int64_t> processed, tidx;
+            for (int c : pending) {
+                offs.push_back(offsets[c] - offsets[c0]);
+                locks.push_back(matchingLocksPos[targetOf(c)]);
+                factors.push_back(unmatchedFractionFactors[2 * targetOf(c)]);
+                processed.push_back(processedTargetsCount);
+                tidx.push_back(targetOf(c));
+            }
+            offs.push_back(offsets[pending.back() + 1] - offsets[c0]);
+            matcher->matchRound(dev + offsets[c0], offs, params->k, locks, counts);            // :379
+            std::vector<EmittedStreams> out;
+            matcher->emitRound(emitParams(), locks, factors, processed, tidx, loadedPositions(), out);   // :381
+            for (size_t k = 0; k < pending.size(); k++) {
+                const int c = pending[k];
+                if (out[k].unmatchedChars == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) {   // :382-388
+                    cut = std::min(cut, c);
+                    continue;
+                }
+                if (c < cut) {
+                    unmatched[c] = out[k].unmatchedChars;
+                    resCount += counts[k];
+                    emitted[c] = std::move(out[k]);
+                }
+            }
+        }
+        // targets before the one holding the cut are complete: load their extensions in order (:433-468)
+        const uint32_t upto = cut < (int) ncont ? targetOf(cut) : r1;
+        for (uint32_t t = finalized; t < upto; t++) {
+            const size_t startPos = matcher->getLoadedRefLength();
+            size_t extLen = 0;
+            for (size_t c = 0; c < ncont; c++)
+                if (targetOf(c) == t) {
+                    const size_t len = offsets[c + 1] - offsets[c];
+                    if (params->isContigProperForRefExtension(len, unmatched[c], unmatchedFractionFactors[2 * t])) extLen += len;     // :389-392
+                    if (params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor)) extLen += len;
+                }
+            if (extLen) {
+                uint8_t *ext = matcher->devAlloc(extLen);
+                size_t pos = 0;
+                for (size_t c = 0; c < ncont; c++)
+                    if (targetOf(c) == t) {
+                        const size_t len = offsets[c + 1] - offsets[c];
+                        if (params->isContigProperForRefExtension(len, unmatched[c], unmatchedFractionFactors[2 * t])) {
+                            matcher->devCopy(ext + pos, dev + offsets[c], len);
+                            pos += len;
+                        }
+                        if (params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor)) {
+                            matcher->devRevComp(dev + offsets[c], len, ext + pos);              // :393-398
+                            pos += len;
+                        }
+                    }
+                matcher->loadRefDev(ext, extLen, false, params->refRegionSeparators, REF_REGION_SEPARATOR);   // :441-443
+                matcher->devFree(ext);
+            }
+            // the target's streams: contig by contig, then the target separator
+            for (size_t c = 0; c < ncont; c++)
+                if (targetOf(c) == t) {
+                    takeRoundStreams(t, emitted[c]);
+                    processAfterSequence(t);
+                }
+            processAfterTarget(t);
+            finalizeParallelProcessingOfTarget(t, startPos);                                    // :455
+            matcher->releaseWorkerMatchingLockPos(matchingLocksPos[t]);                         // :456
+            processedTargetsCount = t + 1;
+        }
+        finalized = upto;
+        if (cut >= (int) ncont) break;
+        pending.clear();
+        for (int c = cut; c < (int) ncont; c++) pending.push_back(c);
+    }
+}
+
+// processTarget + finalizeParallelProcessingOfTarget (MGMP.cpp:340-468) as deterministic rounds, pipelined the way the
+// reference's workers and finalizer overlap (:520-555): a round's contigs are matched and processMatches' first pass
+// returns what the extension policy needs; the round's loadRefs are queued at once — speculatively behind that first
+// pass when the last round's decisions were unanimous (swsem_emit_batch_begin_spec) — and the next round is started
+// while the stream bytes of this one are still being produced on the second stream; they are taken a round later.
 void MultipleGenomeMatchingProcessor::processTargetsRounds() {
     initParallelProcessing();
     matchingLocksPos.assign(targetsCount, SIZE_MAX);
     unmatchedFractionFactors.assign(2 * (size_t) targetsCount, 0);
-    const int R = std::max(1, params->roundSize);
-    for (uint32_t r0 = 0; r0 < targetsCount; r0 += R) {
-        const uint32_t r1 = std::min<uint32_t>(targetsCount, r0 + R);
-        // read the round's files and put their contigs back to back in HBM
-        std::vector<std::vector<Contig>> files(r1 - r0);
-        std::vector<uint64_t> offsets(1, 0);
-        std::vector<uint32_t> targetOf;
-        std::string all;
-        for (uint32_t t = r0; t < r1; t++) {
-            uint64_t fileSize = 0;
-            if (!readFastaFile(fileNames[t + 1], files[t - r0], &fileSize)) { fprintf(stderr, "cannot open file %s\n", fileNames[t + 1].c_str()); exit(EXIT_FAILURE); }
-            totalFilesLength += fileSize;
-            for (const Contig &c : files[t - r0]) {
-                largestContigSize = std::max<uint64_t>(largestContigSize, c.seq.size());
-                all.append(c.seq);
-                offsets.push_back(all.size());
-                targetOf.push_back(t);
-            }
+    const uint32_t R = (uint32_t) std::max(1, params->roundSize);
+    const uint32_t nRounds = (targetsCount + R - 1) / R;
+    const bool bench = params->benchMode;
+    // round r lives in slot r % 3: its bytes are read by the emission's second phase while round r + 1 is matched, and
+    // round r + 2 may already be arriving (bench: every round resident before the clock starts)
+    std::vector<RoundBatch> slots(bench ? nRounds : 3);
+    if (bench) matcher->setEmitHostCopy(false);
+    if (bench)
+        for (uint32_t r = 0; r < nRounds; r++) {
+            slots[r].t0 = r * R; slots[r].t1 = std::min(targetsCount, (r + 1) * R);
+            loadRound(1 + slots[r].t0, 1 + slots[r].t1, slots[r]);
+        }
+    struct Deferred { bool valid = false; RoundBatch *B = nullptr; } prev;   // emission whose streams have not been taken yet
+    uint8_t *extTmp = nullptr; size_t extCap = 0;                           // contig + reverse complement extension strings
+    int predicted = -1;                                                     // what every contig of the last round decided (-1: no prediction)
+    auto collect = [&](RoundBatch &B, bool newerBegun) {                    // per-target stream merge, ENC.cpp:542-556
+        if (newerBegun) matcher->emitSelect(true);
+        for (uint32_t t = B.t0; t < B.t1; t++) {
+            for (size_t c = 0; c < B.targetOf.size(); c++)
+                if (B.t0 + B.targetOf[c] == t) {
+                    EmittedStreams es;
+                    if (!bench) matcher->emitTake((int) c, es);             // bench: the bytes stay packed in HBM, as in bench.py
+                    takeRoundStreams(t, es);
+                    processAfterSequence(t);
+                }
+            processAfterTarget(t);
+            appendTargetStreams(t);
+        }
+        if (newerBegun) matcher->emitSelect(false);
+    };
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+    double tStart = 0;
+    for (uint32_t r = 0; r < nRounds; r++) {
+        RoundBatch &B = slots[bench ? r : r % 3];
+        if (!bench) {
+            B.t0 = r * R; B.t1 = std::min(targetsCount, (r + 1) * R);
+            loadRound(1 + B.t0, 1 + B.t1, B);
+        } else if ((int) r == params->benchWarmup) {
+            if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); prev.valid = false; }
+            matcher->synchronize();
+            tStart = now();
+        }
+        const size_t ncont = B.targetOf.size();
+        const uint32_t T = B.t1 - B.t0;
+        for (uint32_t t = B.t0; t < B.t1; t++) {
             unmatchedFractionFactors[2 * t] = params->currentUnmatchedFractionFactor < 256 ? params->currentUnmatchedFractionFactor : 0;   // :351-352
             unmatchedFractionFactors[2 * t + 1] = (uint8_t) params->unmatchedFractionRCFactor;
             matchingLocksPos[t] = matcher->acquireWorkerMatchingLockPos();                      // :353-358
         }
-        const size_t ncont = targetOf.size();
-        uint8_t *dev = matcher->devAlloc(all.size() + 64);
-        matcher->devUpload(dev, all.data(), all.size());
-        std::vector<int> pending(ncont);
-        for (size_t c = 0; c < ncont; c++) pending[c] = (int) c;
-        std::vector<uint64_t> unmatched(ncont, SIZE_MAX);
-        std::vector<EmittedStreams> emitted(ncont);
-        uint32_t finalized = r0;                                                                // == processedTargetsCount
-        while (true) {
-            int cut = (int) ncont;                                                              // first contig that has to be retried
-            if (!pending.empty()) {
-                // contigs from the first pending one on are consecutive in the buffer (everything after a cut is redone)
-                const int c0 = pending.front();
-                std::vector<uint64_t> offs, locks, counts;
-                std::vector<int> factors;
-                std::vector<int64_t> processed, tidx;
-                for (int c : pending) {
-                    offs.push_back(offsets[c] - offsets[c0]);
-                    locks.push_back(matchingLocksPos[targetOf[c]]);
-                    factors.push_back(unmatchedFractionFactors[2 * targetOf[c]]);
-                    processed.push_back(processedTargetsCount);
-                    tidx.push_back(targetOf[c]);
-                }
-                offs.push_back(offsets[pending.back() + 1] - offsets[c0]);
-                matcher->matchRound(dev + offsets[c0], offs, params->k, locks, counts);        // :379
-                std::vector<EmittedStreams> out;
-                matcher->emitRound(emitParams(), locks, factors, processed, tidx, loadedPositions(), out);   // :381
-                for (size_t k = 0; k < pending.size(); k++) {
-                    const int c = pending[k];
-                    if (out[k].unmatchedChars == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) {   // :382-388
-                        cut = std::min(cut, c);
-                        continue;
-                    }
-                    if (c < cut) {
-                        unmatched[c] = out[k].unmatchedChars;
-                        resCount += counts[k];
-                        emitted[c] = std::move(out[k]);
-                    }
-                }
-            }
-            // targets before the one holding the cut are complete: load their extensions in order (:433-468)
-            const uint32_t upto = cut < (int) ncont ? targetOf[cut] : r1;
-            for (uint32_t t = finalized; t < upto; t++) {
+        if (ncont == 0) {                                                                       // files without a record
+            for (uint32_t t = B.t0; t < B.t1; t++) {
                 const size_t startPos = matcher->getLoadedRefLength();
-                size_t extLen = 0;
-                for (size_t c = 0; c < ncont; c++)
-                    if (targetOf[c] == t) {
-                        const size_t len = offsets[c + 1] - offsets[c];
-                        if (params->isContigProperForRefExtension(len, unmatched[c], unmatchedFractionFactors[2 * t])) extLen += len;     // :389-392
-                        if (params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor)) extLen += len;
-                    }
-                if (extLen) {
-                    uint8_t *ext = matcher->devAlloc(extLen);
-                    size_t pos = 0;
-                    for (size_t c = 0; c < ncont; c++)
-                        if (targetOf[c] == t) {
-                            const size_t len = offsets[c + 1] - offsets[c];
-                            if (params->isContigProperForRefExtension(len, unmatched[c], unmatchedFractionFactors[2 * t])) {
-                                matcher->devCopy(ext + pos, dev + offsets[c], len);
-                                pos += len;
-                            }
-                            if (params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor)) {
-                                matcher->devRevComp(dev + offsets[c], len, ext + pos);          // :393-398
-                                pos += len;
-                            }
-                        }
-                    matcher->loadRefDev(ext, extLen, false, params->refRegionSeparators, REF_REGION_SEPARATOR);   // :441-443
-                    matcher->devFree(ext);
-                }
-                // the target's streams: contig by contig, then the target separator
-                for (size_t c = 0; c < ncont; c++)
-                    if (targetOf[c] == t) {
-                        takeRoundStreams(t, emitted[c]);
-                        processAfterSequence(t);
-                    }
                 processAfterTarget(t);
-                finalizeParallelProcessingOfTarget(t, startPos);                                // :455
-                matcher->releaseWorkerMatchingLockPos(matchingLocksPos[t]);                     // :456
+                finalizeParallelProcessingOfTarget(t, startPos);
+                matcher->releaseWorkerMatchingLockPos(matchingLocksPos[t]);
                 processedTargetsCount = t + 1;
             }
-            finalized = upto;
-            if (cut >= (int) ncont) break;
-            pending.clear();
-            for (int c = cut; c < (int) ncont; c++) pending.push_back(c);
+            continue;
         }
-        matcher->devFree(dev);
+        std::vector<uint64_t> locks(ncont), tlocks(T), un, counts;
+        std::vector<int> factors(ncont);
+        std::vector<int64_t> processed(ncont, processedTargetsCount), tidx(ncont);
+        for (size_t c = 0; c < ncont; c++) {
+            const uint32_t t = B.t0 + B.targetOf[c];
+            locks[c] = matchingLocksPos[t]; factors[c] = unmatchedFractionFactors[2 * t]; tidx[c] = t;
+        }
+        for (uint32_t t = 0; t < T; t++) tlocks[t] = matchingLocksPos[B.t0 + t];
+        // span of every target's contigs in the buffer (they follow each other)
+        std::vector<uint64_t> tBeg(T, 0), tEnd(T, 0);
+        std::vector<char> tHas(T, 0);
+        for (size_t c = 0; c < ncont; c++) {
+            const uint32_t lt = B.targetOf[c];
+            if (!tHas[lt]) { tBeg[lt] = B.offsets[c]; tHas[lt] = 1; }
+            tEnd[lt] = B.offsets[c + 1];
+        }
+        matcher->matchRoundBegin(B.seqDev, B.offsets, params->k, locks);                        // :379
+        // the round's finalize under the prediction "every contig decides as the last round's did"
+        std::vector<const uint8_t *> extDev(T, nullptr);
+        std::vector<uint64_t> extLen(T, 0), loadedAfter(T, 0);
+        std::vector<uint8_t> predExt(ncont, predicted == 1), predRC(ncont, 0);
+        swsem_spec_finalize_t spec;
+        const bool useSpec = predicted >= 0;
+        if (useSpec) {
+            if (predicted == 1)
+                for (uint32_t t = 0; t < T; t++)
+                    if (tHas[t] && tEnd[t] > tBeg[t]) { extDev[t] = B.seqDev + tBeg[t]; extLen[t] = tEnd[t] - tBeg[t]; }
+            spec.ntargets = (int) T; spec.ext_dev = extDev.data(); spec.ext_len = extLen.data();
+            spec.addSep = params->refRegionSeparators; spec.sep = REF_REGION_SEPARATOR; spec.lazySeparator = lazyMode();
+            spec.lockPos = tlocks.data(); spec.loadedAfter = loadedAfter.data();
+            spec.predExt = predExt.data(); spec.predRC = predRC.data();
+            spec.factor = params->currentUnmatchedFractionFactor; spec.rcFactor = params->rcInReference ? params->unmatchedFractionRCFactor : 0;
+        }
+        const size_t before = matcher->getLoadedRefLength();
+        const bool applied = matcher->emitRoundBegin(emitParams(), locks, factors, processed, tidx, loadedPositions(),
+                                                     useSpec ? &spec : nullptr, un, counts);   // :381
+        bool skipped = false;
+        for (size_t c = 0; c < ncont; c++) skipped |= un[c] == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY;
+        if (skipped) {                                                      // (nothing was applied: the library checks the same condition)
+            if (prev.valid) { collect(*prev.B, true); prev.valid = false; }
+            matcher->emitEnd();
+            predicted = -1;
+            processRoundWithRetries(B);
+            continue;
+        }
+        for (size_t c = 0; c < ncont; c++) resCount += counts[c];
+        // extension policy, :389-398
+        std::vector<char> ext(ncont), rc(ncont);
+        bool allExt = true, noneExt = true, anyRC = false;
+        for (size_t c = 0; c < ncont; c++) {
+            const uint32_t t = B.t0 + B.targetOf[c];
+            const size_t len = B.offsets[c + 1] - B.offsets[c];
+            ext[c] = params->isContigProperForRefExtension(len, un[c], unmatchedFractionFactors[2 * t]);
+            rc[c] = params->rcInReference && params->isContigProperForRefRCExtension(len, un[c], params->unmatchedFractionRCFactor);
+            allExt &= (bool) ext[c]; noneExt &= !ext[c]; anyRC |= (bool) rc[c];
+        }
+        if (!applied) {
+            // every target's extension string: its contigs (and reverse complements) that extend the reference, in order;
+            // a target loaded whole and without reverse complements is the span of its contigs in the round's buffer
+            size_t tmpNeed = 0;
+            std::vector<char> whole(T, 1);
+            for (size_t c = 0; c < ncont; c++) if (!ext[c] || rc[c]) whole[B.targetOf[c]] = 0;
+            for (size_t c = 0; c < ncont; c++)
+                if (!whole[B.targetOf[c]]) tmpNeed += (ext[c] ? 1 : 0) * (B.offsets[c + 1] - B.offsets[c]) + (rc[c] ? 1 : 0) * (B.offsets[c + 1] - B.offsets[c]);
+            if (tmpNeed > extCap) {
+                if (extTmp) matcher->devFree(extTmp);
+                extCap = tmpNeed + tmpNeed / 2 + 64;
+                extTmp = matcher->devAlloc(extCap);
+            }
+            size_t at = 0;
+            for (uint32_t t = 0; t < T; t++) {
+                extDev[t] = nullptr; extLen[t] = 0;
+                if (!tHas[t]) continue;
+                if (whole[t]) { if (tEnd[t] > tBeg[t]) { extDev[t] = B.seqDev + tBeg[t]; extLen[t] = tEnd[t] - tBeg[t]; } continue; }
+                const size_t start = at;
+                for (size_t c = 0; c < ncont; c++)
+                    if (B.targetOf[c] == t) {
+                        const size_t len = B.offsets[c + 1] - B.offsets[c];
+                        if (ext[c]) { matcher->devCopy(extTmp + at, B.seqDev + B.offsets[c], len); at += len; }
+                        if (rc[c]) { matcher->devRevComp(B.seqDev + B.offsets[c], len, extTmp + at); at += len; }    // :393-398
+                    }
+                if (at > start) { extDev[t] = extTmp + start; extLen[t] = at - start; }
+            }
+            matcher->finalizeTargets(extDev, extLen, params->refRegionSeparators, REF_REGION_SEPARATOR, lazyMode(), tlocks, loadedAfter);   // :440-457
+        }
+        size_t startPos = before;
+        for (uint32_t t = 0; t < T; t++) {
+            noteTargetLoaded(B.t0 + t, startPos, loadedAfter[t]);                               // ENC.cpp:557-563
+            startPos = loadedAfter[t];
+        }
+        processedTargetsCount = B.t1;
+        // the previous round's streams: its second phase ran beside everything above
+        if (prev.valid) collect(*prev.B, true);
+        prev.valid = true; prev.B = &B;
+        predicted = (!anyRC && (allExt || noneExt)) ? (allExt ? 1 : 0) : -1;
     }
+    if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); }
+    matcher->synchronize();
+    if (bench) {
+        params->benchSeconds = now() - tStart;
+        params->benchRounds = (int) nRounds - params->benchWarmup;
+        params->benchBases = 0;
+        for (uint32_t r = (uint32_t) params->benchWarmup; r < nRounds; r++) params->benchBases += slots[r].bytes;
+    }
+    for (auto &B : slots) if (B.seqDev) matcher->devFree(B.seqDev);
+    if (extTmp) matcher->devFree(extTmp);
 }
 
 void MultipleGenomeMatchingProcessor::performMatching() {
@@ -347,6 +571,19 @@ void MBGC_Encoder::finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t
         refExtLoadedPosArr.emplace_back(matcher->getLoadedRefLength());
     }
     locksPosStream.append((const char *) &matchingLocksPos[targetIdx], sizeof(size_t));         // :563
+}
+
+void MBGC_Encoder::noteTargetLoaded(uint32_t targetIdx, size_t matcherLoaderStartPos, size_t loadedRefLengthAfter) {
+    if (params->lazyDecompressionSupport) {                                                     // ENC.cpp:557-562 (loadSeparator: done by finalizeTargets)
+        writeUInt64Frugal(refExtSizeStream, loadedRefLengthAfter - matcherLoaderStartPos);
+        refExtLoadedPosArr.emplace_back(loadedRefLengthAfter);
+    }
+    locksPosStream.append((const char *) &matchingLocksPos[targetIdx], sizeof(size_t));         // :563
+}
+
+void MBGC_Encoder::appendTargetStreams(uint32_t targetIdx) {
+    appendStreams(*this, targetStreams[targetIdx]);                                             // ENC.cpp:543-556
+    targetStreams[targetIdx] = EmittedStreams();
 }
 
 void MBGC_Encoder::encode(const std::vector<std::string> &files) {

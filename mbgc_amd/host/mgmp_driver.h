@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "sw_matcher.h"
+#include "../../include/mbgc_fasta.h"
 
 struct MGMP_Params {                                   // matching/MGMP_Params.h (only what this path reads)
     int k = 32, k1 = 16, k2 = 1;                       // :199-202
@@ -27,6 +28,12 @@ struct MGMP_Params {                                   // matching/MGMP_Params.h
     bool rcInReference = true;                         // !isRCinReferenceDisabled(), :82-84
     bool sequentialMatching = false;                   // :218
     int roundSize = 8;                                 // targets per round (the deterministic stand-in for matcherWorkingThreads, :22)
+    bool uppercaseDNA = false;                         // :196 (-U)
+    // mbgc-hip c --bench: every round's contigs are put into HBM first, the rounds after `benchWarmup` are timed and the
+    // emitted streams stay packed in HBM (what bench.py measures, from the C++ host)
+    bool benchMode = false;
+    int benchWarmup = 0;
+    double benchSeconds = 0; uint64_t benchBases = 0; int benchRounds = 0;   // filled by processTargetsRounds
     static const uint64_t MIN_BASIC_BLOCK_SIZE = 1 << 21;                 // :48
     static const uint64_t REFERENCE_LENGTH_LIMIT = (uint64_t) UINT32_MAX << 8;   // :55
     bool isContigProperForRefExtension(uint64_t len, uint64_t unmatched, int f) const { return unmatched * f > len; }      // :179-186
@@ -43,7 +50,15 @@ struct MBGC_Params : MGMP_Params {                     // mbgccoder/MBGC_Params.
 };
 
 struct Contig { std::string header, seq; };
-bool readFastaFile(const std::string &path, std::vector<Contig> &out, uint64_t *fileSize);   // kseq_read_lossless_fasta stand-in
+// A round's files parsed by the device input stage (include/mbgc_fasta.h: kseq_read_lossless_fasta, MGMP.cpp:349-372):
+// their contigs back to back in HBM, the layout matchRound takes.
+struct RoundBatch {
+    uint8_t *seqDev = nullptr; size_t seqCap = 0;      // grow-only device buffer
+    uint64_t bytes = 0;
+    std::vector<uint64_t> offsets;                     // ncont + 1
+    std::vector<uint32_t> targetOf;                    // target index of every contig
+    uint32_t t0 = 0, t1 = 0;                           // targets [t0, t1)
+};
 
 class MultipleGenomeMatchingProcessor {
 protected:
@@ -65,6 +80,15 @@ protected:
     void performMatching();                                                             // :568-606
     void processTargetsWithParallelIO();                                                // :232-313  (-t1)
     void processTargetsRounds();                                                        // :340-468 as deterministic rounds
+    void processRoundWithRetries(RoundBatch &B);                                        // a round holding a dissimilar contig (:382-388), blocking calls
+    // input stage (MGMP.cpp:7-35,349-372 on the device parser)
+    mbgc_fasta_t *fasta = nullptr;
+    std::string rawFiles;
+    uint8_t *rawDev = nullptr; size_t rawCap = 0;
+    std::vector<mbgc_fasta_record_t> records;
+    void openInputStage();
+    void readG0(const std::string &path, std::vector<Contig> &out, uint64_t *fileSize);
+    void loadRound(uint32_t t0, uint32_t t1, RoundBatch &B);
 
     // hooks, MGMP.h:79-115
     virtual void initStreamsForG0Ref() = 0;
@@ -75,13 +99,18 @@ protected:
     virtual void processAfterTargetWithParallelIO(size_t matcherLoaderStartPos) = 0;
     virtual void initParallelProcessing() = 0;
     virtual void finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t matcherLoaderStartPos) = 0;
+    // the same in two halves, for the round pipeline: what is known when the target's extension has been queued (the
+    // bytes of refExtSize / locksPos, refExtLoadedPosArr), and the append of its streams once they have arrived
+    virtual void noteTargetLoaded(uint32_t targetIdx, size_t matcherLoaderStartPos, size_t loadedRefLengthAfter) = 0;
+    virtual void appendTargetStreams(uint32_t targetIdx) = 0;
     virtual void takeRoundStreams(uint32_t targetIdx, EmittedStreams &s) = 0;           // per-target stream append in round mode
     virtual const swsem_emit_params_t &emitParams() const = 0;
     virtual const std::vector<size_t> &loadedPositions() const = 0;
+    virtual bool lazyMode() const = 0;
 
 public:
     explicit MultipleGenomeMatchingProcessor(MGMP_Params *p) : params(p) {}
-    virtual ~MultipleGenomeMatchingProcessor() { delete matcher; }
+    virtual ~MultipleGenomeMatchingProcessor();
 };
 
 class MBGC_Encoder : public MultipleGenomeMatchingProcessor {
@@ -97,9 +126,12 @@ class MBGC_Encoder : public MultipleGenomeMatchingProcessor {
     void processAfterTargetWithParallelIO(size_t matcherLoaderStartPos) override;       // :498-509
     void initParallelProcessing() override;                                             // :516-528
     void finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t matcherLoaderStartPos) override;   // :542-564
+    void noteTargetLoaded(uint32_t targetIdx, size_t matcherLoaderStartPos, size_t loadedRefLengthAfter) override;   // :557-563
+    void appendTargetStreams(uint32_t targetIdx) override;                              // :543-556
     void takeRoundStreams(uint32_t targetIdx, EmittedStreams &s) override;
     const swsem_emit_params_t &emitParams() const override { return params->emit; }
     const std::vector<size_t> &loadedPositions() const override { return refExtLoadedPosArr; }
+    bool lazyMode() const override { return params->lazyDecompressionSupport; }
 
 public:
     // the streams the reference enrols at ENC.cpp:779-787 (+ the two it writes beside them)

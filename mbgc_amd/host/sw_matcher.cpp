@@ -108,6 +108,55 @@ void SlidingWindowSparseEMMatcher::emitRound(const swsem_emit_params_t &p, const
     }
 }
 
+void SlidingWindowSparseEMMatcher::matchRoundBegin(const uint8_t *contigsDev, const std::vector<uint64_t> &offsets, uint32_t minLen,
+                                                   const std::vector<uint64_t> &lockPos) {
+    const int n = (int) offsets.size() - 1;
+    check(swsem_match_batch_dev(h, contigsDev, offsets.data(), n, minLen, lockPos.empty() ? nullptr : lockPos.data()), "matchTexts");
+}
+
+bool SlidingWindowSparseEMMatcher::emitRoundBegin(const swsem_emit_params_t &p, const std::vector<uint64_t> &lockPos,
+                                                  const std::vector<int> &factors, const std::vector<int64_t> &processed,
+                                                  const std::vector<int64_t> &targetIdx, const std::vector<size_t> &loaded,
+                                                  const swsem_spec_finalize_t *spec, std::vector<uint64_t> &unmatched,
+                                                  std::vector<uint64_t> &counts) {
+    const int n = (int) lockPos.size();
+    std::vector<uint64_t> ld(loaded.begin(), loaded.end());
+    int applied = 0;
+    if (spec)
+        check(swsem_emit_batch_begin_spec(h, &p, n, nullptr, lockPos.data(), factors.data(), processed.data(), targetIdx.data(), ld.data(),
+                                          ld.size(), spec, &applied), "processMatches");
+    else
+        check(swsem_emit_batch_begin(h, &p, n, nullptr, lockPos.data(), factors.data(), processed.data(), targetIdx.data(), ld.data(), ld.size()),
+              "processMatches");
+    unmatched.assign(n, 0);
+    check(swsem_emit_unmatched(h, unmatched.data()), "processMatches");
+    counts.assign(n, 0);
+    check(swsem_batch_counts(h, counts.data()), "matchTexts");            // (after the emission's launches: no round trip in between)
+    return applied != 0;
+}
+
+void SlidingWindowSparseEMMatcher::setEmitHostCopy(bool on) { swsem_emit_set_host_copy(h, on ? 1 : 0); }
+void SlidingWindowSparseEMMatcher::emitSelect(bool previous) { check(swsem_emit_select(h, previous ? 1 : 0), "processMatches"); }
+
+void SlidingWindowSparseEMMatcher::emitTake(int k, EmittedStreams &out) {
+    swsem_streams_t st;
+    check(swsem_emit_result(h, k, &st), "processMatches");
+    take(st, out);
+}
+
+void SlidingWindowSparseEMMatcher::emitEnd() { check(swsem_emit_batch_end(h), "processMatches"); }
+
+void SlidingWindowSparseEMMatcher::finalizeTargets(const std::vector<const uint8_t *> &extDev, const std::vector<uint64_t> &extLen,
+                                                   bool addSep, char sep, bool lazySeparator, const std::vector<uint64_t> &lockPos,
+                                                   std::vector<uint64_t> &loadedAfter) {
+    loadedAfter.assign(extLen.size(), 0);
+    check(swsem_finalize_targets(h, (int) extLen.size(), extDev.data(), extLen.data(), addSep, (unsigned char) sep, lazySeparator,
+                                 lockPos.data(), loadedAfter.data()), "loadRef");
+}
+
+void SlidingWindowSparseEMMatcher::synchronize() { check(swsem_synchronize(h), "synchronize"); }
+void SlidingWindowSparseEMMatcher::devDownload(void *dst, const uint8_t *srcDev, size_t bytes) { check(swsem_dev_download(h, dst, srcDev, bytes), "download"); }
+
 uint8_t *SlidingWindowSparseEMMatcher::devAlloc(size_t bytes) {
     void *p = nullptr;
     check(swsem_dev_malloc(h, bytes, &p), "device allocation");

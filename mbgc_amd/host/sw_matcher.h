@@ -73,7 +73,24 @@ public:
     void emitRound(const swsem_emit_params_t &p, const std::vector<uint64_t> &lockPos, const std::vector<int> &factors,
                    const std::vector<int64_t> &processed, const std::vector<int64_t> &targetIdx,
                    const std::vector<size_t> &refExtLoadedPosArr, std::vector<EmittedStreams> &out);
+    void matchRoundBegin(const uint8_t *contigsDev, const std::vector<uint64_t> &offsets, uint32_t minMatchLength,
+                         const std::vector<uint64_t> &lockPos);          // matchRound without the wait for the counts
+    // the same in the overlapped form the round pipeline uses (include/mbgc_swsem.h: swsem_emit_batch_begin[_spec], two
+    // emissions in flight, swsem_finalize_targets): emitRoundBegin returns with processMatches' return values known and
+    // the stream bytes still being produced; spec != nullptr carries the predicted finalize (true: it has been applied)
+    bool emitRoundBegin(const swsem_emit_params_t &p, const std::vector<uint64_t> &lockPos, const std::vector<int> &factors,
+                        const std::vector<int64_t> &processed, const std::vector<int64_t> &targetIdx,
+                        const std::vector<size_t> &refExtLoadedPosArr, const swsem_spec_finalize_t *spec,
+                        std::vector<uint64_t> &unmatched, std::vector<uint64_t> &matchCounts);
+    void setEmitHostCopy(bool on);                                          // off: the streams stay in HBM until emitTake asks for them
+    void emitSelect(bool previous);
+    void emitTake(int k, EmittedStreams &out);                              // streams of contig k of the selected emission (waits for it)
+    void emitEnd();
+    void finalizeTargets(const std::vector<const uint8_t *> &extDev, const std::vector<uint64_t> &extLen, bool addSep, char sep,
+                         bool lazySeparator, const std::vector<uint64_t> &lockPos, std::vector<uint64_t> &loadedAfter);
+    void synchronize();
     void loadRefDev(const uint8_t *textDev, size_t len, bool loadRC, bool addSep, char sep);
+    void devDownload(void *dst, const uint8_t *srcDev, size_t bytes);
     uint8_t *devAlloc(size_t bytes);
     void devFree(uint8_t *p);
     void devUpload(uint8_t *dst, const void *src, size_t bytes);

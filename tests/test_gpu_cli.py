@@ -53,18 +53,39 @@ def split(g, k):
     return [g[cuts[i]:cuts[i + 1]] for i in range(k)]
 
 
-@pytest.mark.parametrize("args,rs", [(["-t1"], 0), (["-R", "3"], 3), (["-R", "8"], 8)])
-def test_synthetic_files_equal_oracle_driver(tmp_path, args, rs):
+def crlf(c):
+    """the contig as kseq_read_lossless_fasta returns it from a CRLF file: the carriage returns stay (utils/kseq.h:233-274,
+    ks_getuntil2 with loosy = false) — 80 bases, CR, 80 bases, CR ..."""
+    n = c.size
+    out = np.empty(n + (n + 79) // 80, dtype=np.uint8)
+    k = 0
+    for s0 in range(0, n, 80):
+        seg = c[s0:s0 + 80]
+        out[k:k + seg.size] = seg
+        out[k + seg.size] = 13
+        k += seg.size + 1
+    return out[:k]
+
+
+# divergence 1.5 %: every contig extends the reference (the speculative finalize applies from the second round on);
+# 0.1 %: none does; 6 %: dissimilar contigs are given up and retried (the blocking path); "crlf": CRLF line ends
+@pytest.mark.parametrize("args,rs,div", [(["-t1"], 0, 0.015), (["-R", "3"], 3, 0.015), (["-R", "8"], 8, 0.015), (["-R", "2"], 2, 0.001),
+                                         (["-R", "3"], 3, 0.06), (["-R", "3"], 3, "crlf"), (["-t1"], 0, "crlf")])
+def test_synthetic_files_equal_oracle_driver(tmp_path, args, rs, div):
     base = synth.base_codes(70_000, 55)
-    gs = [synth.genome(base, i, 0.015) for i in range(8)]
+    cr = div == "crlf"
+    gs = [synth.genome(base, i, 0.015 if cr else div) for i in range(8)]
     files = [split(g, 2) for g in gs]
     paths = []
     for i, contigs in enumerate(files):
         p = tmp_path / ("g%02d.fa" % i)
         with open(p, "wb") as f:
             for j, c in enumerate(contigs):
-                f.write(synth.fasta_bytes(c, i * 10 + j))
+                data = synth.fasta_bytes(c, i * 10 + j)
+                f.write(data.replace(b"\n", b"\r\n") if cr else data)
         paths.append(str(p))
+    if cr:
+        files = [[crlf(c) for c in contigs] for contigs in files]
     (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
     run_tool(["c"] + args + ["list.txt", "out"], str(tmp_path))
     fsize = os.path.getsize(paths[0])
@@ -86,3 +107,33 @@ def test_synthetic_files_equal_oracle_driver(tmp_path, args, rs):
     for k in ("mapOff", "mapOff5th", "mapLen", "gapDelta", "flags"):
         assert got[k] == streams[k], k
     assert got["locksPos"] == res["locks"] and got["refExtSize"] == res["refExtSize"]
+
+
+def test_malformed_fasta_is_refused(tmp_path):
+    """validate_kseq_status (MGMP.cpp:16-35): the tool prints the reference's message and exits with a failure"""
+    base = synth.base_codes(30_000, 56)
+    good = tmp_path / "a.fa"
+    good.write_bytes(synth.fasta_bytes(synth.genome(base, 0, 0.01), 0))
+    ragged = tmp_path / "b.fa"
+    ragged.write_bytes(b">x\nACGTACGT\nACG\nACGTACGT\n")               # a short line in the middle: not well-formed
+    nofasta = tmp_path / "c.fa"
+    nofasta.write_bytes(b"ACGT\n")
+    for bad, msg in ((ragged, "inconsistent line length"), (nofasta, "expected FASTA format")):
+        (tmp_path / "l.txt").write_text("%s\n%s\n" % (good, bad))
+        r = subprocess.run([TOOL, "c", "-R", "2", "l.txt", "o"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and msg in r.stderr, r.stderr
+
+
+def test_bench_mode_reports_throughput(tmp_path):
+    """mbgc-hip c --bench: every round resident in HBM, the rounds after the warm-up timed (the C++ host on the same path
+    bench.py measures through the Python driver)"""
+    base = synth.base_codes(400_000, 57)
+    paths = []
+    for i in range(13):
+        p = tmp_path / ("g%02d.fa" % i)
+        p.write_bytes(synth.fasta_bytes(synth.genome(base, i, 0.01), i))
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    out = run_tool(["c", "--bench", "--warmup", "1", "-R", "4", "list.txt", "x"], str(tmp_path))
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["rounds"] == 2 and d["bases"] == 8 * 400_000 and d["value"] > 0
