@@ -124,6 +124,17 @@ int64_t orc_decode_contig(const uint8_t *ref, const orc_emit_params *p, const ui
 void orc_write_frugal64(orc_buf *b, uint64_t v);
 void orc_buf_put(orc_buf *b, const void *p, uint64_t n);
 
+/* ---- the -m3 reverse-complement pass over the literal stream (rcmatch_oracle.c): SimpleSequenceMatcher::rcMatchSequence
+ * on CopMEMMatcher, matching/SimpleSequenceMatcher.cpp:165-176, matching/copmem/CopMEMMatcher.cpp (single-thread form) */
+uint32_t orc_hash_sparsified(const uint8_t *s, int K);                         /* maRushPrime1HashSparsified<K>, utils/Hashes.h:47-68 */
+void orc_reverse_complement(const uint8_t *src, uint64_t n, uint8_t *dst);     /* PgHelpers::reverseComplement, utils/helper.cpp:429-437 */
+uint64_t orc_rc_find_matches(const uint8_t *seq, uint64_t n, uint32_t targetMatchLength, uint32_t minMatchLength,
+                             orc_match **out, int *params, uint64_t *charExtensions);
+uint64_t orc_rc_apply_matches(uint8_t *seq, uint64_t n, orc_match *m, uint64_t nm, uint32_t targetMatchLength, uint32_t minMatchLength,
+                              orc_buf *mapOff, orc_buf *mapLen, uint64_t *stats);
+uint64_t orc_rc_match_sequence(uint8_t *seq, uint64_t n, uint32_t targetMatchLength, uint32_t minMatchLength,
+                               orc_buf *mapOff, orc_buf *mapLen, uint64_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

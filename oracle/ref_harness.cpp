@@ -37,6 +37,8 @@
 #define private public
 #define protected public
 #include "mbgccoder/MBGC_Encoder.h"
+#include "matching/SimpleSequenceMatcher.h"
+#include "matching/copmem/CopMEMMatcher.h"
 #undef private
 #undef protected
 
@@ -161,6 +163,33 @@ uint64_t refe_stream(void *h, int t, int which, char *out, uint64_t cap) {
     }
     memcpy(out, s.data(), std::min<uint64_t>(cap, s.size()));
     return s.size();
+}
+
+// ---------------------------------------------------------------- -m3 reverse-complement pass over the literal stream
+// SimpleSequenceMatcher::rcMatchSequence (matching/SimpleSequenceMatcher.cpp:165-176) as MBGC_Encoder.cpp:637-638 calls it,
+// with one thread (the multi-threaded index build fills its buckets in arrival order). seq is rewritten in place; the maps
+// are copied out (up to cap bytes each, full sizes returned through mapOffLen / mapLenLen). Returns the new length.
+uint64_t refrc_match_sequence(char *seq, uint64_t n, uint64_t targetMatchLength, uint32_t minMatchLength,
+                              char *mapOff, uint64_t *mapOffLen, char *mapLen, uint64_t *mapLenLen, uint64_t cap) {
+    quiet();
+    std::string s(seq, n), off, len;
+    PgTools::SimpleSequenceMatcher::rcMatchSequence(s, off, len, targetMatchLength, minMatchLength);
+    memcpy(seq, s.data(), s.size());
+    memcpy(mapOff, off.data(), std::min<uint64_t>(cap, off.size()));
+    memcpy(mapLen, len.data(), std::min<uint64_t>(cap, len.size()));
+    *mapOffLen = off.size(); *mapLenLen = len.size();
+    return s.size();
+}
+// the matches CopMEMMatcher::matchTexts pushes for (reverseComplement(seq), destIsSrc, revComplMatching), in push order
+uint64_t refrc_find_matches(const char *seq, uint64_t n, uint32_t targetMatchLength, uint32_t minMatchLength, uint64_t *out, uint64_t cap) {
+    quiet();
+    std::string s(seq, n);
+    CopMEMMatcher m(s.data(), s.size(), targetMatchLength, minMatchLength);
+    std::string q = PgHelpers::reverseComplement(s);
+    std::vector<TextMatch> res;
+    m.matchTexts(res, q, true, true, minMatchLength == UINT32_MAX ? targetMatchLength : minMatchLength);
+    for (size_t i = 0; i < res.size() && i < cap; i++) { out[3 * i] = res[i].posSrcText; out[3 * i + 1] = res[i].length; out[3 * i + 2] = res[i].posDestText; }
+    return res.size();
 }
 
 }  // extern "C"

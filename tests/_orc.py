@@ -248,3 +248,58 @@ def fingerprint(matches):
             fp ^= int(v)
             fp = (fp * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
     return fp
+
+
+# ---- the -m3 reverse-complement pass over the literal stream (oracle/rcmatch_oracle.c)
+def rc_find_matches(seq, target=55, min_len=0xFFFFFFFF):
+    """matches CopMEMMatcher::matchTexts pushes for the reverse-complemented sequence against itself, in push order:
+    (n, 3) uint64 rows (posSrcText, length, posDestText in the reverse-complemented text) and (K, k1, k2, log2 hash size)"""
+    a, p = _bytes_ptr(seq)
+    L = lib()
+    L.orc_rc_find_matches.restype = C.c_uint64
+    L.orc_rc_find_matches.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(OrcMatch)), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    out = C.POINTER(OrcMatch)()
+    params = (C.c_int * 4)()
+    ext = C.c_uint64()
+    n = L.orc_rc_find_matches(p, a.size, target, min_len, C.byref(out), params, C.byref(ext))
+    assert n != 2 ** 64 - 1, "the reference exits on these parameters"
+    res = np.zeros((n, 3), dtype=np.uint64)
+    if n:
+        res[:] = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(n, 4))[:, :3]
+    L.orc_free(out)
+    return res, tuple(params), ext.value
+
+
+def rc_match_sequence(seq, target=55, min_len=0xFFFFFFFF):
+    """SimpleSequenceMatcher::rcMatchSequence: -> (rewritten sequence, rcMapOff, rcMapLen, (unique matches, matched, overlapped))"""
+    a = np.array(seq, dtype=np.uint8, copy=True)
+    L = lib()
+    L.orc_rc_match_sequence.restype = C.c_uint64
+    L.orc_rc_match_sequence.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(OrcBuf), C.POINTER(OrcBuf), C.POINTER(C.c_uint64)]
+    off, ln = OrcBuf(), OrcBuf()
+    st = (C.c_uint64 * 3)()
+    n = L.orc_rc_match_sequence(a.ctypes.data_as(C.c_void_p), a.size, target, min_len, C.byref(off), C.byref(ln), st)
+    assert n != 2 ** 64 - 1
+    take = lambda b: bytes(np.ctypeslib.as_array(b.data, shape=(b.size,))) if b.size else b""
+    res = (a[:n].tobytes(), take(off), take(ln), tuple(st))
+    L.orc_free(off.data), L.orc_free(ln.data)
+    return res
+
+
+def rc_apply_matches(seq, matches, target=55, min_len=0xFFFFFFFF):
+    """the post-processing half alone (rows as rc_find_matches returns them)"""
+    a = np.array(seq, dtype=np.uint8, copy=True)
+    L = lib()
+    L.orc_rc_apply_matches.restype = C.c_uint64
+    L.orc_rc_apply_matches.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(OrcBuf), C.POINTER(OrcBuf), C.POINTER(C.c_uint64)]
+    n = len(matches)
+    rows = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    if n:
+        rows[:n, :3] = np.asarray(matches, dtype=np.uint64).reshape(n, 3)
+    off, ln = OrcBuf(), OrcBuf()
+    st = (C.c_uint64 * 3)()
+    r = L.orc_rc_apply_matches(a.ctypes.data_as(C.c_void_p), a.size, rows.ctypes.data_as(C.c_void_p), n, target, min_len, C.byref(off), C.byref(ln), st)
+    take = lambda b: bytes(np.ctypeslib.as_array(b.data, shape=(b.size,))) if b.size else b""
+    res = (a[:r].tobytes(), take(off), take(ln), tuple(st))
+    L.orc_free(off.data), L.orc_free(ln.data)
+    return res

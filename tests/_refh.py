@@ -147,3 +147,31 @@ class RefEmitter:
     def streams(self, target=0):
         names = ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags")
         return {names[i]: self.stream(i, target) for i in range(6)}
+
+
+# ---- the -m3 reverse-complement pass (ref_harness.cpp: refrc_*), the reference's SimpleSequenceMatcher / CopMEMMatcher
+def rc_find_matches(seq, target=55, min_len=0xFFFFFFFF):
+    a, p = _bytes_ptr(seq)
+    L = lib()
+    L.refrc_find_matches.restype = C.c_uint64
+    L.refrc_find_matches.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
+    cap = max(1024, a.size // 8)
+    out = np.zeros((cap, 3), dtype=np.uint64)
+    n = L.refrc_find_matches(p, a.size, target, min_len, out.ctypes.data_as(C.c_void_p), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def rc_match_sequence(seq, target=55, min_len=0xFFFFFFFF):
+    a = np.array(seq, dtype=np.uint8, copy=True)
+    L = lib()
+    L.refrc_match_sequence.restype = C.c_uint64
+    L.refrc_match_sequence.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p,
+                                       C.POINTER(C.c_uint64), C.c_uint64]
+    cap = max(4096, a.size)
+    off, ln = np.zeros(cap, dtype=np.uint8), np.zeros(cap, dtype=np.uint8)
+    no, nl = C.c_uint64(), C.c_uint64()
+    n = L.refrc_match_sequence(a.ctypes.data_as(C.c_void_p), a.size, target, min_len, off.ctypes.data_as(C.c_void_p), C.byref(no),
+                               ln.ctypes.data_as(C.c_void_p), C.byref(nl), cap)
+    assert no.value <= cap and nl.value <= cap
+    return a[:n].tobytes(), off[:no.value].tobytes(), ln[:nl.value].tobytes()
