@@ -1,0 +1,514 @@
+// The `-m3` reverse-complement pass over the literal stream on an MI355X (include/mbgc_copmem.h):
+// SimpleSequenceMatcher::rcMatchSequence on CopMEMMatcher (matching/SimpleSequenceMatcher.cpp:165-176,
+// matching/copmem/CopMEMMatcher.cpp), single-thread semantics.
+//
+//   index   every k1-th position is hashed (maRushPrime1HashSparsified<K>, utils/Hashes.h:47-68) into a bucket; a bucket keeps
+//           its first 13 positions in text order (genCumm / processRef, CopMEMMatcher.cpp:146-225). Here: one thread per sample
+//           writes (bucket, sample), a stable radix sort by bucket (rocPRIM) puts every bucket's samples in text order, a scan
+//           of the capped bucket sizes gives the CSR offsets (`cumm`), the ranks below 13 are scattered (`sampledPositions`).
+//   query   the reverse-complemented text is scanned every k2-th position in blocks of 256 samples; a sample's candidates are
+//           tried in bucket order, the first one that gives a match longer than the minimum is pushed and the scan skips
+//           K/k1 - 1 samples — within the block (processExactMatchQueryTight, :349-495). The expensive half — which candidate
+//           of a sample, if any, gives a match, and which — does not depend on what was pushed before: one thread per sample,
+//           one workgroup per block. The cheap half walks the block's samples in order with the last pushed match ("back", the
+//           only state the loop carries: a candidate on back's diagonal inside back is not tried but skipped over, :391-397).
+//           Blocks are walked with "no match carried in" first; the match really carried into a block is the last push of the
+//           nearest earlier block that pushed anything (a max-scan over block indices), and a block it reaches into is walked
+//           again with it — until nothing changes: the sequential loop's result, whatever was speculated.
+// The 4-byte pre-filter of the reference (:404-407) is result-neutral (a match longer than L covers one of its two windows)
+// and is not modelled: the K-mer is compared first, which is what rejects a colliding candidate there too (:416).
+#include "../../include/mbgc_copmem.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace cm {
+
+thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define CCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return cm::fail(-100, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+constexpr int QB = 256;                  // query samples per block: MULTI, CopMEMMatcher.cpp:352
+constexpr int TAILCAP = 2 * QB;          // the samples after the last whole block (fewer than QB + K/k2 + 2)
+constexpr uint32_t LIMIT = 12;           // HASH_COLLISIONS_PER_POSITION_LIMIT, CopMEMMatcher.h:11: a bucket holds at most LIMIT + 1 positions
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct Params {
+    int K, k1, k2, skip;                 // skip = K / k1 - 1, :367
+    uint32_t mask, minLen;
+    uint64_t N;                          // text length (= query length)
+    uint64_t nS;                         // indexed samples
+    uint64_t nMain;                      // whole query blocks
+    uint64_t tailFirst, nTail;           // first sample number / number of samples of the tail
+    uint32_t region;                     // rows reserved per block for its pushes
+};
+
+struct Row { uint64_t src, len, dest; };
+struct Back { uint64_t src, len, dest; uint32_t valid, pad; };
+
+template <typename T>
+struct Buf {
+    T *p = nullptr; size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void) hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 8 + 64;
+        if (hipMalloc((void **) &p, want * sizeof(T)) != hipSuccess) return fail(-101, "device allocation of %zu bytes failed", want * sizeof(T));
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+};
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+// maRushPrime1HashSparsified<K>, utils/Hashes.h:47-68 (the low 32 bits of the 64-bit recurrence are a 32-bit recurrence)
+__device__ __forceinline__ uint32_t hash_sparsified(const uint8_t *s, int K) {
+    uint32_t h = (uint32_t) K;
+    const int nw = K / 4;
+    for (int j = 0; j < nw; j++) {
+        const uint32_t k = (ld32(s + 4 * j) & (j < 3 ? 0x00FFFFFFu : 0x0000FFFFu)) + (uint32_t) j;
+        h = (h ^ k) * 171717u;
+    }
+    return h;
+}
+
+// ---- index -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hash_samples(const uint8_t *__restrict__ text, Params P, uint32_t *__restrict__ keys,
+                                                      uint32_t *__restrict__ vals, uint32_t *__restrict__ counts) {
+    const uint64_t s = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (s >= P.nS) return;
+    const uint32_t h = hash_sparsified(text + s * (uint64_t) P.k1, P.K) & P.mask;
+    keys[s] = h;
+    vals[s] = (uint32_t) s;
+    atomicAdd(&counts[h], 1u);
+}
+__global__ void __launch_bounds__(256) k_cap_counts(const uint32_t *__restrict__ counts, uint32_t *__restrict__ capped, uint64_t n) {
+    const uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) capped[i] = counts[i] > LIMIT + 1 ? LIMIT + 1 : counts[i];
+    else if (i == n) capped[i] = 0;
+}
+// sorted by bucket, a bucket's samples in text order: the first LIMIT + 1 of them are the bucket (genCumm's skippedList drops the rest)
+__global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ startAll,
+                                              const uint32_t *__restrict__ cumm, uint32_t *__restrict__ sampled, uint64_t nS) {
+    const uint64_t t = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (t >= nS) return;
+    const uint32_t h = keys[t];
+    const uint32_t rank = (uint32_t) t - startAll[h];
+    if (rank <= LIMIT) sampled[cumm[h] + rank] = vals[t];
+}
+// PgHelpers::reverseComplement(string), utils/helper.cpp:429-437 with complementsLUT
+__global__ void __launch_bounds__(256) k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t n, const uint8_t *__restrict__ lut) {
+    __shared__ uint8_t sl[256];
+    sl[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t) gridDim.x * 256;
+    for (uint64_t d = (uint64_t) blockIdx.x * 256 + threadIdx.x; d < n; d += stride) dst[d] = sl[src[n - 1 - d]];
+}
+
+// ---- query -------------------------------------------------------------------------------------------------------------
+// equal bytes of a[0..lim) and b[0..lim)
+__device__ __forceinline__ uint64_t lcp_fwd(const uint8_t *a, const uint8_t *b, uint64_t lim) {
+    uint64_t n = 0;
+    while (n + 8 <= lim) {
+        const uint64_t x = ld64(a + n) ^ ld64(b + n);
+        if (x) return n + ((uint64_t) __builtin_ctzll(x) >> 3);
+        n += 8;
+    }
+    while (n < lim && a[n] == b[n]) n++;
+    return n;
+}
+// equal bytes of a[-1-k] and b[-1-k], k in [0, lim)
+__device__ __forceinline__ uint64_t lcp_bwd(const uint8_t *a, const uint8_t *b, uint64_t lim) {
+    uint64_t n = 0;
+    while (n + 8 <= lim) {
+        const uint64_t x = ld64(a - n - 8) ^ ld64(b - n - 8);
+        if (x) return n + ((uint64_t) __builtin_clzll(x) >> 3);
+        n += 8;
+    }
+    while (n < lim && a[-(int64_t) n - 1] == b[-(int64_t) n - 1]) n++;
+    return n;
+}
+
+// One workgroup per query block. blockList == nullptr: block = blockIdx.x; else the listed blocks (those a carried-in match
+// reaches into). Block nMain is the tail (:439-492: the samples left over, a skip is not cut short there — it runs off the end).
+__global__ void __launch_bounds__(QB) k_query(Params P, const uint8_t *__restrict__ text, const uint8_t *__restrict__ q,
+                                              const uint32_t *__restrict__ cumm, const uint32_t *__restrict__ sampled,
+                                              const uint32_t *__restrict__ blockList, const Back *__restrict__ incoming,
+                                              Row *__restrict__ regions, Row *__restrict__ tailRegion, uint32_t *__restrict__ npush,
+                                              Back *__restrict__ last) {
+    __shared__ uint32_t sB0[TAILCAP];
+    __shared__ uint8_t sCnt[TAILCAP], sJv[TAILCAP];
+    __shared__ uint64_t sSrc[TAILCAP], sLen[TAILCAP], sDest[TAILCAP];
+    const uint32_t b = blockList ? blockList[blockIdx.x] : blockIdx.x;
+    const bool tail = b == P.nMain;
+    const uint64_t first = tail ? P.tailFirst : (uint64_t) b * QB;
+    const uint32_t nsamples = tail ? (uint32_t) P.nTail : (uint32_t) QB;
+    const int K = P.K;
+    // ---- which candidate of every sample, if any, gives a match (independent of everything pushed before)
+    for (uint32_t t = threadIdx.x; t < nsamples; t += QB) {
+        const uint64_t i = (first + t) * (uint64_t) P.k2;                      // tmpMatchDestPos
+        uint32_t b0 = 0, cnt = 0, jv = 255;
+        uint64_t mSrc = 0, mLen = 0, mDest = 0;
+        const uint32_t h = hash_sparsified(q + i, K) & P.mask;
+        b0 = cumm[h];
+        cnt = cumm[h + 1] - b0;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint64_t src = (uint64_t) sampled[b0 + j] * (uint64_t) P.k1; // tmpMatchSrcPos
+            if (P.N - src < i) continue;                                       // destIsSrc && revComplMatching, :388-390
+            const uint8_t *c1 = text + src, *c2 = q + i;
+            bool eq = true;                                                    // memcmp(curr1, curr2, K) == 0, :416
+            for (int w = 0; w < K / 4 && eq; w++) eq = ld32(c1 + 4 * w) == ld32(c2 + 4 * w);
+            if (!eq) continue;
+            const uint64_t limR = (P.N - (src + K)) < (P.N - (i + K)) ? P.N - (src + K) : P.N - (i + K);
+            const uint64_t r = (uint64_t) K + lcp_fwd(c1 + K, c2 + K, limR);   // :409-410
+            // :412-415: walks left from the K-mer's first byte while neither text's first byte has been reached
+            const uint64_t limL = src < i ? src : i;
+            const uint64_t tl = lcp_bwd(c1 + 1, c2 + 1, limL);                 // bytes at offsets 0, -1, ... (offset 0 included)
+            if (r + tl > (uint64_t) P.minLen) {                                // right - p1 > minMatchLength
+                jv = j; mSrc = src - tl + 1; mLen = r + tl - 1; mDest = i - tl + 1;
+                break;
+            }
+        }
+        sB0[t] = b0; sCnt[t] = (uint8_t) cnt; sJv[t] = (uint8_t) jv;
+        sSrc[t] = mSrc; sLen[t] = mLen; sDest[t] = mDest;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // ---- the block's samples in order, with the last pushed match
+    Back bk = incoming[b];
+    Row *out = tail ? tailRegion : regions + (uint64_t) b * P.region;
+    uint32_t np = 0;
+    uint32_t i2 = 0;
+    while (i2 < nsamples) {
+        const uint32_t cnt = sCnt[i2];
+        if (cnt == 0) { i2++; continue; }
+        const uint64_t dest = (first + i2) * (uint64_t) P.k2;
+        const uint32_t jv = sJv[i2];
+        bool acted = false, pushIt = false;
+        if (bk.valid && dest + (uint64_t) K < bk.dest + bk.len) {              // back may swallow a candidate: look at them in order, :391-397
+            const uint64_t diag = bk.dest - bk.src;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint64_t src = (uint64_t) sampled[sB0[i2] + j] * (uint64_t) P.k1;
+                if (P.N - src < dest) continue;
+                if (dest - src == diag) { acted = true; break; }
+                if (j == jv) { pushIt = true; break; }
+            }
+        } else
+            pushIt = jv != 255;
+        if (pushIt) {
+            bk.src = sSrc[i2]; bk.len = sLen[i2]; bk.dest = sDest[i2]; bk.valid = 1;
+            Row r; r.src = bk.src; r.len = bk.len; r.dest = bk.dest;
+            out[np++] = r;
+            acted = true;
+        }
+        i2 += acted ? (uint32_t) P.skip + 1u : 1u;                              // curr2 += skipK2; i2 += skip; ... curr2 += k2
+    }
+    npush[b] = np;
+    Back l; l.src = bk.src; l.len = bk.len; l.dest = bk.dest; l.valid = np ? 1u : 0u; l.pad = 0;
+    last[b] = l;                                                                // (valid: the block pushed something)
+}
+
+// what is carried into every block: the last push of the nearest earlier block that pushed anything
+__global__ void __launch_bounds__(256) k_push_index(const uint32_t *__restrict__ npush, int32_t *__restrict__ idx, uint32_t nb) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b < nb) idx[b] = npush[b] ? (int32_t) b : -1;
+}
+__global__ void __launch_bounds__(256) k_mark(Params P, const int32_t *__restrict__ from, const Back *__restrict__ last, Back *__restrict__ incoming,
+                                              uint32_t *__restrict__ dirtyList, uint32_t *__restrict__ ndirty, uint32_t nb) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+    Back in; in.src = 0; in.len = 0; in.dest = 0; in.valid = 0; in.pad = 0;
+    if (from[b] >= 0) {
+        const Back l = last[from[b]];
+        const uint64_t firstPos = (b == P.nMain ? P.tailFirst : (uint64_t) b * QB) * (uint64_t) P.k2;
+        if (firstPos + (uint64_t) P.K < l.dest + l.len) { in = l; in.valid = 1; }   // it reaches into the block (else: as good as none)
+    }
+    const Back had = incoming[b];
+    if (had.valid != in.valid || (in.valid && (had.src != in.src || had.len != in.len || had.dest != in.dest))) {
+        incoming[b] = in;
+        dirtyList[atomicAdd(ndirty, 1u)] = b;
+    }
+}
+__global__ void __launch_bounds__(64) k_gather(Params P, const Row *__restrict__ regions, const Row *__restrict__ tailRegion, const uint32_t *__restrict__ npush,
+                                               const uint32_t *__restrict__ off, Row *__restrict__ out) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = npush[b];
+    const Row *src = b == P.nMain ? tailRegion : regions + (uint64_t) b * P.region;
+    for (uint32_t k = threadIdx.x; k < n; k += 64) out[off[b] + k] = src[k];
+}
+
+struct MaxOp { __device__ __host__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
+
+}  // namespace cm
+
+struct mbgc_copmem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cm::Buf<uint8_t> dText, dQ, dLut, dTmp;
+    cm::Buf<uint32_t> dKeys, dVals, dKeys2, dVals2, dCounts, dCapped, dStartAll, dCumm, dSampled, dNpush, dOff, dDirty, dNd;
+    cm::Buf<int32_t> dIdx, dFrom;
+    cm::Buf<cm::Row> dRegions, dTail, dOut;
+    cm::Buf<cm::Back> dIncoming, dLast;
+    std::vector<mbgc_copmem_match_t> matches;
+    std::vector<uint8_t> mapOff, mapLen;
+};
+
+namespace cm {
+
+// initParams + calcCoprimes, CopMEMMatcher.cpp:68-144
+static int derive_params(Params &P, uint64_t N, uint32_t L, uint32_t ctorMinLen) {
+    int K;
+    if (L > 110) K = 56; else if (L > 62) K = 44; else if (L > 53) K = 40; else if (L > 46) K = 36; else if (L > 42) K = 32; else if (L > 32) K = 28;
+    else K = ((int) L / 4 - 1) * 4;
+    if (ctorMinLen < 24) return fail(-3, "Error: Minimal matching length too short!");
+    const int KmmL = ((int) ctorMinLen / 4 - 1) * 4;
+    if (KmmL < K) K = KmmL;
+    const int t = (int) L - K + 1;
+    if (t <= 0) return fail(-3, "L and K mismatch.");
+    int k1, k2;
+    if (t >= 20) { k1 = (int) std::pow((double) t, 0.5) + 1; k2 = k1 - 1; if (k1 * k2 > t) { --k2; --k1; } }
+    else if (t >= 15) { k1 = 5; k2 = 3; } else if (t >= 12) { k1 = 4; k2 = 3; } else if (t >= 10) { k1 = 5; k2 = 2; }
+    else if (t >= 6) { k1 = 3; k2 = 2; } else { k1 = t; k2 = 1; }
+    uint32_t hs;
+    uint8_t i = 24;
+    do { hs = ((uint32_t) 1) << (i++); } while (i <= 31 && hs < N / (uint64_t) k1);
+    P.K = K; P.k1 = k1; P.k2 = k2; P.skip = K / k1 - 1; P.mask = hs - 1; P.N = N;
+    return 0;
+}
+
+static void complements_lut(uint8_t *lut) {                              // PgHelpers::complementsLUT, utils/helper.cpp:312-361
+    for (int i = 0; i < 256; i++) lut[i] = (uint8_t) i;
+    lut[127] = 0;                                                        // the constructor's loops stop at i < CHAR_MAX
+    const char *from = "AaCcGgTtNnUuYyRrKkMmBbDdHhVvWwSs", *to = "TTGGCCAANNAARRYYMMKKVVHHDDBBSSWW";
+    for (int i = 0; from[i]; i++) lut[(uint8_t) from[i]] = (uint8_t) to[i];
+    lut['U'] = 'U'; lut['u'] = 'u';
+    const char *lf = "acgtnyrkmbdhvws", *lt = "tgcanrymkvhdbsw";
+    for (int i = 0; lf[i]; i++) lut[(uint8_t) lf[i]] = (uint8_t) lt[i];
+}
+
+}  // namespace cm
+
+extern "C" {
+
+const char *mbgc_copmem_last_error(void) { return cm::g_err.c_str(); }
+
+int mbgc_copmem_create(mbgc_copmem_t **out, int device) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev)
+        return cm::fail(-102, "no HIP device %d (the reverse-complement pass has no CPU fallback)", device);
+    CCHK(hipSetDevice(device));
+    mbgc_copmem *p = new mbgc_copmem();
+    p->device = device;
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { delete p; return cm::fail(-100, "hipStreamCreate failed"); }
+    *out = p;
+    return 0;
+}
+
+void mbgc_copmem_destroy(mbgc_copmem_t *p) {
+    if (!p) return;
+    (void) hipSetDevice(p->device);
+    if (p->stream) { (void) hipStreamSynchronize(p->stream); (void) hipStreamDestroy(p->stream); }
+    p->dText.release(); p->dQ.release(); p->dLut.release(); p->dTmp.release(); p->dKeys.release(); p->dVals.release(); p->dKeys2.release();
+    p->dVals2.release(); p->dCounts.release(); p->dCapped.release(); p->dStartAll.release(); p->dCumm.release(); p->dSampled.release();
+    p->dNpush.release(); p->dOff.release(); p->dDirty.release(); p->dNd.release(); p->dIdx.release(); p->dFrom.release();
+    p->dRegions.release(); p->dTail.release(); p->dOut.release(); p->dIncoming.release(); p->dLast.release();
+    delete p;
+}
+
+int mbgc_copmem_rc_matches(mbgc_copmem_t *p, const uint8_t *seq, uint64_t n, uint32_t L, uint32_t minMatchLength,
+                           const mbgc_copmem_match_t **matches, uint64_t *count, int params[4]) {
+    using namespace cm;
+    *matches = nullptr; *count = 0;
+    p->matches.clear();
+    if (n < L) return 0;                                                   // SimpleSequenceMatcher.cpp:16: no matcher is built
+    CCHK(hipSetDevice(p->device));
+    hipStream_t st = p->stream;
+    Params P;
+    memset(&P, 0, sizeof P);
+    int r;
+    if ((r = derive_params(P, n, L, minMatchLength > L ? L : minMatchLength))) return r;    // CopMEMMatcher.cpp:500-502
+    P.minLen = minMatchLength == UINT32_MAX ? L : minMatchLength;          // SimpleSequenceMatcher.cpp:80-81
+    if (P.minLen < (uint32_t) P.K) return fail(-3, "Minimal matching length cannot be smaller than K (%u < %d)", P.minLen, P.K);   // :522-525
+    if (params) { params[0] = P.K; params[1] = P.k1; params[2] = P.k2; params[3] = 32 - __builtin_clz(P.mask); }
+    const uint64_t hs = (uint64_t) P.mask + 1;
+    P.nS = (n - (uint64_t) P.K) / (uint64_t) P.k1 + 1;                     // i = 0, k1, ... < N - K + 1
+    if (P.nS >= (1ull << 32) - 1024) return fail(-103, "sequence too long for 32-bit sample numbers");
+    // query blocks: :370 (i1 + K + k2 * MULTI < N2 + 1), then :439 (i1 + K < N2 + 1)
+    const uint64_t k2M = (uint64_t) P.k2 * QB;
+    P.nMain = n + 1 > (uint64_t) P.K + k2M ? (n - (uint64_t) P.K - k2M + k2M) / k2M : 0;      // number of i1 = 0, k2M, ... with i1 + K + k2M <= N2
+    while (P.nMain * k2M + (uint64_t) P.K + k2M < n + 1) P.nMain++;
+    while (P.nMain && !((P.nMain - 1) * k2M + (uint64_t) P.K + k2M < n + 1)) P.nMain--;
+    P.tailFirst = P.nMain * QB;
+    const uint64_t tailPos = P.tailFirst * (uint64_t) P.k2;
+    P.nTail = tailPos + (uint64_t) P.K < n + 1 ? (n - (uint64_t) P.K - tailPos) / (uint64_t) P.k2 + 1 : 0;
+    if (P.nTail > (uint64_t) TAILCAP) return fail(-103, "internal: tail of %llu samples", (unsigned long long) P.nTail);
+    P.region = (uint32_t) (QB / (P.skip + 1) + 2);
+    const uint32_t nb = (uint32_t) P.nMain + 1;                            // + the tail block
+    if (P.nMain >= (1ull << 31)) return fail(-103, "sequence too long");
+
+    if ((r = p->dText.reserve(n + 64)) || (r = p->dQ.reserve(n + 64)) || (r = p->dLut.reserve(256)) || (r = p->dKeys.reserve(P.nS)) || (r = p->dVals.reserve(P.nS)) ||
+        (r = p->dKeys2.reserve(P.nS)) || (r = p->dVals2.reserve(P.nS)) || (r = p->dCounts.reserve(hs + 1)) || (r = p->dCapped.reserve(hs + 1)) ||
+        (r = p->dStartAll.reserve(hs + 1)) || (r = p->dCumm.reserve(hs + 1)) || (r = p->dNpush.reserve(nb)) || (r = p->dOff.reserve(nb + 1)) ||
+        (r = p->dDirty.reserve(nb)) || (r = p->dNd.reserve(4)) || (r = p->dIdx.reserve(nb)) || (r = p->dFrom.reserve(nb)) ||
+        (r = p->dRegions.reserve(std::max<uint64_t>(P.nMain, 1) * P.region)) || (r = p->dTail.reserve(TAILCAP + 2)) ||
+        (r = p->dIncoming.reserve(nb)) || (r = p->dLast.reserve(nb)))
+        return r;
+    uint8_t lut[256];
+    complements_lut(lut);
+    CCHK(hipMemcpyAsync(p->dLut.p, lut, 256, hipMemcpyHostToDevice, st));
+    CCHK(hipMemcpyAsync(p->dText.p, seq, n, hipMemcpyHostToDevice, st));
+    CCHK(hipMemsetAsync(p->dText.p + n, 0, 64, st));
+    CCHK(hipMemsetAsync(p->dCounts.p, 0, (hs + 1) * sizeof(uint32_t), st));
+    // ---- index
+    k_hash_samples<<<dim3((unsigned) ((P.nS + 255) / 256)), dim3(256), 0, st>>>(p->dText.p, P, p->dKeys.p, p->dVals.p, p->dCounts.p);
+    const unsigned bits = 32 - __builtin_clz(P.mask);
+    size_t tmpBytes = 0, t2 = 0, t3 = 0;
+    CCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, p->dKeys.p, p->dKeys2.p, p->dVals.p, p->dVals2.p, (size_t) P.nS, 0u, bits, st));
+    CCHK(rocprim::exclusive_scan(nullptr, t2, p->dCounts.p, p->dStartAll.p, 0u, (size_t) hs + 1, rocprim::plus<uint32_t>(), st));
+    CCHK(rocprim::exclusive_scan(nullptr, t3, p->dIdx.p, p->dFrom.p, (int32_t) -1, (size_t) nb, MaxOp(), st));
+    tmpBytes = std::max(tmpBytes, std::max(t2, t3));
+    if ((r = p->dTmp.reserve(tmpBytes + 256))) return r;
+    size_t tb = p->dTmp.cap;
+    CCHK(rocprim::radix_sort_pairs(p->dTmp.p, tb, p->dKeys.p, p->dKeys2.p, p->dVals.p, p->dVals2.p, (size_t) P.nS, 0u, bits, st));
+    tb = p->dTmp.cap;
+    CCHK(rocprim::exclusive_scan(p->dTmp.p, tb, p->dCounts.p, p->dStartAll.p, 0u, (size_t) hs + 1, rocprim::plus<uint32_t>(), st));
+    k_cap_counts<<<dim3((unsigned) ((hs + 1 + 255) / 256)), dim3(256), 0, st>>>(p->dCounts.p, p->dCapped.p, hs);
+    tb = p->dTmp.cap;
+    CCHK(rocprim::exclusive_scan(p->dTmp.p, tb, p->dCapped.p, p->dCumm.p, 0u, (size_t) hs + 1, rocprim::plus<uint32_t>(), st));
+    uint32_t hashCount = 0;
+    CCHK(hipMemcpyAsync(&hashCount, p->dCumm.p + hs, 4, hipMemcpyDeviceToHost, st));
+    CCHK(hipStreamSynchronize(st));
+    if ((r = p->dSampled.reserve((size_t) hashCount + 2))) return r;
+    k_fill<<<dim3((unsigned) ((P.nS + 255) / 256)), dim3(256), 0, st>>>(p->dKeys2.p, p->dVals2.p, p->dStartAll.p, p->dCumm.p, p->dSampled.p, P.nS);
+    // ---- query
+    k_revcomp<<<dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 65536)), dim3(256), 0, st>>>(p->dText.p, p->dQ.p, n, p->dLut.p);
+    CCHK(hipMemsetAsync(p->dQ.p + n, 0, 64, st));
+    CCHK(hipMemsetAsync(p->dIncoming.p, 0, (size_t) nb * sizeof(Back), st));
+    k_query<<<dim3(nb), dim3(QB), 0, st>>>(P, p->dText.p, p->dQ.p, p->dCumm.p, p->dSampled.p, nullptr, p->dIncoming.p, p->dRegions.p, p->dTail.p, p->dNpush.p, p->dLast.p);
+    CCHK(hipGetLastError());
+    for (int iter = 0;; iter++) {
+        if (iter > 1000000) return fail(-105, "internal: the carried state did not settle");
+        k_push_index<<<dim3((nb + 255) / 256), dim3(256), 0, st>>>(p->dNpush.p, p->dIdx.p, nb);
+        tb = p->dTmp.cap;
+        CCHK(rocprim::exclusive_scan(p->dTmp.p, tb, p->dIdx.p, p->dFrom.p, (int32_t) -1, (size_t) nb, MaxOp(), st));
+        CCHK(hipMemsetAsync(p->dNd.p, 0, 4, st));
+        k_mark<<<dim3((nb + 255) / 256), dim3(256), 0, st>>>(P, p->dFrom.p, p->dLast.p, p->dIncoming.p, p->dDirty.p, p->dNd.p, nb);
+        uint32_t nd = 0;
+        CCHK(hipMemcpyAsync(&nd, p->dNd.p, 4, hipMemcpyDeviceToHost, st));
+        CCHK(hipStreamSynchronize(st));
+        if (nd == 0) break;
+        k_query<<<dim3(nd), dim3(QB), 0, st>>>(P, p->dText.p, p->dQ.p, p->dCumm.p, p->dSampled.p, p->dDirty.p, p->dIncoming.p, p->dRegions.p, p->dTail.p, p->dNpush.p, p->dLast.p);
+        CCHK(hipGetLastError());
+    }
+    // ---- the pushes in block order
+    tb = p->dTmp.cap;
+    size_t t4 = 0;
+    CCHK(rocprim::exclusive_scan(nullptr, t4, p->dNpush.p, p->dOff.p, 0u, (size_t) nb, rocprim::plus<uint32_t>(), st));
+    if (t4 > p->dTmp.cap && (r = p->dTmp.reserve(t4 + 256))) return r;
+    tb = p->dTmp.cap;
+    CCHK(rocprim::exclusive_scan(p->dTmp.p, tb, p->dNpush.p, p->dOff.p, 0u, (size_t) nb, rocprim::plus<uint32_t>(), st));
+    uint32_t lastOff = 0, lastN = 0;
+    CCHK(hipMemcpyAsync(&lastOff, p->dOff.p + (nb - 1), 4, hipMemcpyDeviceToHost, st));
+    CCHK(hipMemcpyAsync(&lastN, p->dNpush.p + (nb - 1), 4, hipMemcpyDeviceToHost, st));
+    CCHK(hipStreamSynchronize(st));
+    const uint64_t total = (uint64_t) lastOff + lastN;
+    if ((r = p->dOut.reserve(std::max<uint64_t>(total, 1)))) return r;
+    k_gather<<<dim3(nb), dim3(64), 0, st>>>(P, p->dRegions.p, p->dTail.p, p->dNpush.p, p->dOff.p, p->dOut.p);
+    p->matches.resize(total);
+    static_assert(sizeof(Row) == sizeof(mbgc_copmem_match_t), "row layout");
+    if (total) CCHK(hipMemcpyAsync(p->matches.data(), p->dOut.p, total * sizeof(Row), hipMemcpyDeviceToHost, st));
+    CCHK(hipStreamSynchronize(st));
+    *matches = p->matches.data();
+    *count = total;
+    return 0;
+}
+
+int mbgc_copmem_rc_match_sequence(mbgc_copmem_t *p, uint8_t *seq, uint64_t n, uint32_t L, uint32_t minMatchLength, uint64_t *newLen,
+                                  const uint8_t **mapOff, uint64_t *mapOffLen, const uint8_t **mapLen, uint64_t *mapLenLen, uint64_t stats[3]) {
+    p->mapOff.clear(); p->mapLen.clear();
+    *newLen = n; *mapOff = nullptr; *mapOffLen = 0; *mapLen = nullptr; *mapLenLen = 0;
+    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    if (n < L) return 0;                                                   // SimpleSequenceMatcher.cpp:68-73: no matcher, empty maps
+    const mbgc_copmem_match_t *found = nullptr;
+    uint64_t nm = 0;
+    int r = mbgc_copmem_rc_matches(p, seq, n, L, minMatchLength, &found, &nm, nullptr);
+    if (r) return r;
+    if (minMatchLength == UINT32_MAX) minMatchLength = L;
+    std::vector<mbgc_copmem_match_t> &m = p->matches;
+    for (auto &t : m) t.posDestText = n - (t.posDestText + t.length);     // correctDestPositionDueToRevComplMatching, :59-62
+    for (auto &t : m) {                                                    // resolveMappingCollisionsInTheSameText, :150-163
+        if (t.posSrcText > t.posDestText) std::swap(t.posSrcText, t.posDestText);
+        if (t.posSrcText + t.length > t.posDestText) {
+            const uint64_t margin = (t.posSrcText + t.length - t.posDestText + 1) / 2;
+            t.length -= margin;
+            t.posDestText += margin;
+        }
+    }
+    auto put_byte_frugal = [&](uint64_t v) {                               // writeUIntByteFrugal, utils/helper.cpp:217-225
+        while (v >= 128) { p->mapLen.push_back((uint8_t) (128 + v % 128)); v /= 128; }
+        p->mapLen.push_back((uint8_t) v);
+    };
+    put_byte_frugal(minMatchLength);                                       // :91
+    auto less = [](const mbgc_copmem_match_t &a, const mbgc_copmem_match_t &b) {   // TextMatch::operator<, TextMatchers.h:30-40
+        if (a.posDestText != b.posDestText) return a.posDestText < b.posDestText;
+        if (a.posSrcText != b.posSrcText) return a.posSrcText < b.posSrcText;
+        return a.length < b.length;
+    };
+    std::sort(m.begin(), m.end(), less);                                   // :93-94
+    m.erase(std::unique(m.begin(), m.end(), [](const mbgc_copmem_match_t &a, const mbgc_copmem_match_t &b) {
+                return a.posSrcText == b.posSrcText && a.length == b.length && a.posDestText == b.posDestText; }), m.end());
+    uint64_t pos = 0, nPos = 0, overlap = 0, matched = 0;
+    const bool std32 = n <= UINT32_MAX;                                    // :102
+    const uint8_t MARK = (uint8_t) ('$' + 128);                            // MBGC_Params.h:48
+    for (auto &t : m) {                                                    // :103-131
+        if (t.posDestText < pos) {
+            const uint64_t over = pos - t.posDestText;
+            if (over >= t.length) { overlap += t.length; t.length = 0; continue; }
+            overlap += over;
+            t.length -= over;
+            t.posDestText += over;
+        }
+        if (t.length < minMatchLength) { overlap += t.length; continue; }
+        matched += t.length;
+        const uint64_t len = t.posDestText - pos;
+        memmove(seq + nPos, seq + pos, len);
+        nPos += len;
+        seq[nPos++] = MARK;
+        const size_t at = p->mapOff.size();
+        p->mapOff.resize(at + (std32 ? 4 : 8));
+        if (std32) { const uint32_t v = (uint32_t) t.posSrcText; memcpy(&p->mapOff[at], &v, 4); }
+        else memcpy(&p->mapOff[at], &t.posSrcText, 8);
+        put_byte_frugal(t.length - minMatchLength);
+        pos = t.posDestText + t.length;
+    }
+    memmove(seq + nPos, seq + pos, n - pos);
+    nPos += n - pos;
+    if (stats) { stats[0] = m.size(); stats[1] = matched; stats[2] = overlap; }
+    *newLen = nPos;
+    *mapOff = p->mapOff.data(); *mapOffLen = p->mapOff.size();
+    *mapLen = p->mapLen.data(); *mapLenLen = p->mapLen.size();
+    return 0;
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     syms = set()
-    for header, prefix in (("mbgc_swsem.h", "swsem_"), ("mbgc_fasta.h", "mbgc_fasta_")):
+    for header, prefix in (("mbgc_swsem.h", "swsem_"), ("mbgc_fasta.h", "mbgc_fasta_"), ("mbgc_copmem.h", "mbgc_copmem_")):
         src = open(os.path.join(ROOT, "include", header)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         syms |= set(re.findall(r"\b(%s[A-Za-z0-9_]+)\s*\(" % prefix, src))
@@ -27,8 +27,8 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     from mbgc_amd import binding
-    from mbgc_amd import fasta
-    assert set(binding.EXPORTS) <= set(syms) and set(fasta.EXPORTS) <= set(syms)
+    from mbgc_amd import copmem, fasta
+    assert set(binding.EXPORTS) <= set(syms) and set(fasta.EXPORTS) <= set(syms) and set(copmem.EXPORTS) <= set(syms)
 
 
 def test_no_device_means_loud_failure_not_fallback():
