@@ -60,6 +60,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     dump(pos[1], "literals", enc.literals);
+    if (params.rcRedundancyRemoval) { dump(pos[1], "rcMapOff", enc.rcMapOff); dump(pos[1], "rcMapLen", enc.rcMapLen); }
     dump(pos[1], "locksPos", enc.locksPosStream);
     dump(pos[1], "gapDelta", enc.gapDeltas);
     dump(pos[1], "flags", enc.gapMismatchesFlags);

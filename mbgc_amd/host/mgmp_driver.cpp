@@ -1,4 +1,5 @@
 #include "mgmp_driver.h"
+#include "simple_sequence_matcher.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -25,7 +26,7 @@ void MBGC_Params::setCompressionMode(int mode) {                // MBGC_Params.h
         skipMargin = 24;
         unmatchedFractionRCFactor = 128;
     }
-    if (mode == 3) sequentialMatching = true;
+    if (mode == 3) { sequentialMatching = true; rcMatchMinLength = 55; rcRedundancyRemoval = true; }   // :915-920, DEFAULT_RC_MATCH_MINIMUM_LENGTH :61
 }
 
 // PgHelpers::writeUInt64Frugal, utils/helper.cpp:237-246
@@ -599,4 +600,7 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
     params->emit.enable40bitReference = params->enable40bitReference;
     if (params->lazyDecompressionSupport) refExtLoadedPosArr.emplace_back(matcher->getLoadingPosition());   // ENC.cpp:789-791
     performMatching();
+    // prepareAndCompressStreams' first step on this path, ENC.cpp:636-638: the reverse-complement pass over the literals
+    if (params->rcRedundancyRemoval && !params->benchMode)
+        PgTools::SimpleSequenceMatcher::rcMatchSequence(literals, rcMapOff, rcMapLen, params->rcMatchMinLength, UINT32_MAX, device);
 }

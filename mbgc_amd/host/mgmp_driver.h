@@ -43,6 +43,8 @@ struct MGMP_Params {                                   // matching/MGMP_Params.h
 struct MBGC_Params : MGMP_Params {                     // mbgccoder/MBGC_Params.h (only what this path reads)
     uint8_t coderMode = 1;
     bool lazyDecompressionSupport = true;              // :38
+    uint64_t rcMatchMinLength = 0;                     // :99 (55 in -m3, :61,:917-918)
+    bool rcRedundancyRemoval = false;                  // :101
     swsem_emit_params_t emit;
     int device = 0;
     MBGC_Params() { setCompressionMode(1); }
@@ -136,6 +138,7 @@ class MBGC_Encoder : public MultipleGenomeMatchingProcessor {
 public:
     // the streams the reference enrols at ENC.cpp:779-787 (+ the two it writes beside them)
     std::string literals, mapOff, mapOff5thByte, mapLen, gapDeltas, gapMismatchesFlags, locksPosStream, refExtSizeStream;
+    std::string rcMapOff, rcMapLen;                                                     // ENC.cpp:636-638 (-m3)
     size_t extensionsMatchedCharsAll = 0, extensionsMismatchesAll = 0, removedGapBreakingMatchesAll = 0;
 
     explicit MBGC_Encoder(MBGC_Params *p) : MultipleGenomeMatchingProcessor(p), params(p) { device = p->device; }

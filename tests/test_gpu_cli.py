@@ -48,6 +48,22 @@ def test_listeria_t1_streams_equal_reference_cli(tmp_path):
         assert hashlib.md5(b).hexdigest() == e["md5"], name
 
 
+def test_listeria_m3_streams_equal_reference_cli(tmp_path):
+    """`mbgc c -m3 -t1`: the max mode — sequential matching with its own margins and, at the end, the reverse-complement pass
+    over the literal stream (rcMapOff / rcMapLen, SimpleSequenceMatcher::rcMatchSequence) — against the reference CLI's dumps"""
+    exp = json.load(open(os.path.join(LIST, "expected_m3.json")))
+    names = []
+    for f in exp["files"]:
+        (tmp_path / f).write_bytes(lzma.open(os.path.join(LIST, f + ".xz")).read())
+        names.append(str(tmp_path / f))
+    (tmp_path / "seqlist.txt").write_text("\n".join(names) + "\n")
+    run_tool(["c", "-m", "3", "-t1", "seqlist.txt", "lm"], str(tmp_path))
+    for name, e in exp["streams"].items():
+        b = (tmp_path / ("lm." + name)).read_bytes()
+        assert len(b) == e["bytes"], (name, len(b), e["bytes"])
+        assert hashlib.md5(b).hexdigest() == e["md5"], name
+
+
 def split(g, k):
     cuts = [0] + [g.size * i // k + (7 * i) % 13 for i in range(1, k)] + [g.size]
     return [g[cuts[i]:cuts[i + 1]] for i in range(k)]
