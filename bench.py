@@ -18,8 +18,8 @@ under `python -m torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
 Diagnostics (never the headline): --no-emit (matcher only), --from-host (queries cross PCIe inside the timed region),
 --check (first round against the oracle); environment: MBGC_BENCH_MAX_REF (another buffer size), MBGC_BENCH_BLOCK_STATS
 / MBGC_BENCH_BLOCK_DUMP (per-block clocks of the last resolve launch), MBGC_BENCH_ONE_DEVICE + MBGC_BENCH_BACKEND=gloo
-(several ranks on one GPU, a rehearsal of the N > 1 protocol), and the library's own switches (SWSEM_ORDER, SWSEM_RB,
-SWSEM_PROBE, SWSEM_HASH, SWSEM_RESOLVE, SWSEM_PROF_FAMS; see mbgc_amd/csrc/swsem_runtime.hip: swsem_create)."""
+(several ranks on one GPU, a rehearsal of the N > 1 protocol), and the library's own switches (SWSEM_CHAINS, SWSEM_ORDER,
+SWSEM_RB, SWSEM_RESOLVE, SWSEM_PROF_FAMS; see mbgc_amd/csrc/swsem_runtime.hip: swsem_create)."""
 import argparse
 import json
 import os
@@ -54,17 +54,14 @@ def ref_length_limit(files_count, basic_len):
 ALG_BYTES_PER_BASE = 5.5             # whole path, per input base
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s
 # SURVEY.md §8(d) splits that figure by term; per kernel family (bytes per input base of a launch):
-#   resolve k_resolve_blocks: the query scan (1 B: the scan windows hash their K-mers from the query bytes; with
-#           SWSEM_HASH=pre that byte belongs to the "probe" family, k_probe<true>, instead), the table probes the
-#           sequential loop performs (0.29 x 4 B), the reference bytes it compares (0.918 B) and the match rows it
-#           writes (24 B x 9.6 k rows / 1 M bases)
+#   resolve k_resolve_blocks4: the query scan (1 B: the scan windows hash their K-mers from the query bytes), the table
+#           probes the sequential loop performs (0.29 x 4 B), the reference bytes it compares (0.918 B) and the match rows
+#           it writes (24 B x 9.6 k rows / 1 M bases)
 #   load    extension copy, read + write (2 B);  insert  one 4-B table entry per 16 bases
 #   emit    the six streams (0.14 B)
-ALG_BYTES = {"probe": 1.0, "resolve": 4 * 0.29 + 0.918 + 0.23, "stitch": 0.23, "load": 2.0, "insert": 0.25, "emit": 0.14}
-QUERY_SCAN_BYTES = 1.0               # moves to "resolve" when no hash kernel ran
-KERNEL_OF = {"probe": "k_probe<true> (K-mer hashes of the query, SWSEM_HASH=pre only)", "resolve": "k_resolve_blocks",
-             "stitch": "k_stitch_pre + k_stitch + k_gather", "load": "k_copy_multi", "insert": "k_insert_multi",
-             "emit": "k_emit_* (13 launches)"}
+ALG_BYTES = {"resolve": 1.0 + 4 * 0.29 + 0.918 + 0.23, "stitch": 0.23, "load": 2.0, "insert": 0.25, "emit": 0.14}
+KERNEL_OF = {"resolve": "k_resolve_blocks4", "stitch": "k_stitch_pre + k_stitch + k_gather", "load": "k_copy_multi",
+             "insert": "k_insert_multi", "emit": "k_emit_* (13 launches)"}
 # HBM-side bytes per launch of each kernel, from the PMC passes over THIS command (profiles/pmc_summary.py writes the
 # file from rocprofv3's FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes); absent = null
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
@@ -400,13 +397,11 @@ def main():
     if rank == 0:
         # the dominant kernel: the families that are a single kernel per launch (emission is 13 small kernels,
         # the second half of which runs beside other work on a second stream and is timed as elapsed time)
-        dom = max(("probe", "resolve", "stitch", "insert", "load"), key=lambda k: prof[k][0])
+        dom = max(("resolve", "stitch", "insert", "load"), key=lambda k: prof[k][0])
         per_launch_ms = {k: (prof[k][0] / prof[k][1] if prof[k][1] else 0.0) for k in prof}
         dom_ms = per_launch_ms[dom]
         launch_bases = R * args.length                     # bases one launch of a family processes (this rank's round)
         alg = dict(ALG_BYTES)
-        if prof["probe"][1] == 0:                          # no hash kernel ran: the chains read the query themselves
-            alg["resolve"] += QUERY_SCAN_BYTES
         ach = alg[dom] * launch_bases / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         traffic = measured_traffic(KERNEL_OF[dom].split()[0], R)
         pre = [t for t, w in zip(step_ms, laps_at) if not w]
@@ -434,8 +429,8 @@ def main():
                          "traffic_GBs": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms else None,
                          "alg_bytes_per_base": round(alg[dom], 3), "avg_launch_ms": round(dom_ms, 4),
                          "whole_step_frac": round(ALG_BYTES_PER_BASE * value / world / HBM_PEAK_GBS, 5)},
-            "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items()},
-            "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof}, "dominant_kernel": dom,
+            "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items() if k != "probe"},
+            "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof if k != "probe"}, "dominant_kernel": dom,
             "ms_per_step_before_wrap": round(float(np.mean(pre)), 4) if pre else None, "steps_before_wrap": len(pre),
             "ms_per_step_after_wrap": round(float(np.mean(post)), 4) if post else None, "steps_after_wrap": len(post),
             "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps,

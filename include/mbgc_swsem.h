@@ -95,13 +95,6 @@ int swsem_match(swsem_t *h, const uint8_t *query, uint64_t len, uint32_t minMatc
  * and can be fetched per contig. */
 int swsem_match_batch_dev(swsem_t *h, const uint8_t *queries_dev, const uint64_t *offsets, int n,
                           uint32_t minMatchLength, const uint64_t *lockPos);
-/* Optional look-ahead: the K-mer hashes of the query scan (.cpp:200-201) depend on the query alone, so the
- * batch that will be matched NEXT can be announced while the current one is still being matched; they are
- * computed on a third stream and adopted by the swsem_match_batch_dev call with the same (queries_dev,
- * offsets, n). The buffer must hold its final bytes when announced. Purely an overlap: results are those of
- * swsem_match_batch_dev alone. By default the match kernel hashes its scan windows itself and this call does
- * nothing; it computes hash arrays ahead only when the environment sets SWSEM_HASH=pre. */
-int swsem_hash_batch_dev(swsem_t *h, const uint8_t *queries_dev, const uint64_t *offsets, int n);
 int swsem_batch_counts(swsem_t *h, uint64_t *nmatches /* [n] */);
 int swsem_batch_matches(swsem_t *h, int contig, swsem_match_t *out, uint64_t cap);
 /* order-sensitive fingerprint of all match rows of the batch, computed on the device copy */
@@ -205,7 +198,7 @@ int swsem_debug_copy_ref(swsem_t *h, uint64_t from, uint64_t n, uint8_t *out);  
 /* overwrites n reference bytes from `from` (tests: what an emission must not depend on is filled with garbage) */
 int swsem_debug_write_ref(swsem_t *h, uint64_t from, uint64_t n, const uint8_t *in);
 int swsem_debug_copy_ht(swsem_t *h, uint32_t *out /* [hash_size] 32-bit image as on the CPU */);
-enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2, SWSEM_K_EMIT2 = 3, SWSEM_K_RESOLVE = 4,
+enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2 /* unused: the chains hash their own scan windows */, SWSEM_K_EMIT2 = 3, SWSEM_K_RESOLVE = 4,
        SWSEM_K_STITCH = 5, SWSEM_K_EMIT = 6, SWSEM_K_COUNT = 7 };
 /* When enabled every kernel family's launches are bracketed by HIP events on the stream they run on; the
  * accumulated device time (ms) and bracket count per family are read back with swsem_profile_get.

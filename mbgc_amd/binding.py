@@ -20,7 +20,7 @@ EXPORTS = """swsem_last_error swsem_device_count swsem_create swsem_destroy swse
 swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circular_buffer swsem_get_ref_length
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
-swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_hash_batch_dev swsem_batch_counts swsem_batch_matches
+swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
 swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_write_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_download swsem_dev_copy""".split()
 
@@ -97,7 +97,6 @@ def lib():
         L.swsem_finalize_targets.argtypes = [vp, ci, vp, pu64, ci, ci, ci, pu64, pu64]
         L.swsem_match.argtypes = [vp, vp, u64, C.c_uint32, u64, C.POINTER(vp), pu64]
         L.swsem_match_batch_dev.argtypes = [vp, vp, pu64, ci, C.c_uint32, pu64]
-        L.swsem_hash_batch_dev.argtypes = [vp, vp, pu64, ci]
         L.swsem_batch_counts.argtypes = [vp, pu64]
         L.swsem_batch_matches.argtypes = [vp, ci, vp, u64]
         L.swsem_batch_fingerprint.argtypes = [vp, pu64, pu64, pu64]
@@ -218,11 +217,6 @@ class SlidingWindowSparseEMMatcher:
         _chk(lib().swsem_match_batch_dev(self.h, dev_ptr, offs.ctypes.data_as(C.POINTER(C.c_uint64)), n, min_len,
                                          lk.ctypes.data_as(C.POINTER(C.c_uint64)) if lk is not None else None))
         self._batch_n = n
-
-    def hash_batch_dev(self, dev_ptr, offsets):
-        """announce the batch that will be matched next: its K-mer hashes are computed beside the current work"""
-        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
-        _chk(lib().swsem_hash_batch_dev(self.h, dev_ptr, offs.ctypes.data_as(C.POINTER(C.c_uint64)), offs.size - 1))
 
     def batch_counts(self):
         out = np.zeros(self._batch_n, dtype=np.uint64)

@@ -6,10 +6,7 @@
 namespace swk {
 
 constexpr int WAVE = 64;
-constexpr int TILE = 4096;            // query positions per probe tile (dense probe / hash-ahead kernels)
 constexpr int RBU = 1024;             // unit of a resolve block's length: a block scans rb * RBU query positions
-constexpr int PROBE_THREADS = 256;
-constexpr int POS_PER_THREAD = TILE / PROBE_THREADS;
 constexpr int OVERLAP_MATCH_MAX_LENGTH = 1 << 13;   // SlidingWindowSparseEMMatcher.h:18
 
 // Hash-table entry: (epoch << 32) | (pos >> k1ord). The reference's table is "last writer wins" in
@@ -30,9 +27,6 @@ struct Contig {
     uint64_t n;        // contig length
     uint64_t lock;     // matchingLockPos or UINT64_MAX
     uint64_t matchBase;// first row of this contig in the batch match array
-    uint64_t candBase; // first slot of this contig in the candidate array (ntiles * TILE slots)
-    uint32_t tile0;    // first tile of this contig
-    uint32_t ntiles;
     uint32_t rb0;      // first resolve block of this contig
     uint32_t nrb;      // resolve blocks (= ceil(positions / (rb * RBU)))
 };

@@ -153,93 +153,6 @@ __global__ void __launch_bounds__(256) k_ht_low_words(const ht_entry *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// probe: the table lookups of the query scan, processExactMatchQueryIgnoreCollisionsTight
-// .cpp:200-222, for EVERY query position at once (the sequential loop only visits a subset; which
-// subset is decided later by the resolve chains). One workgroup = one tile of TILE consecutive
-// positions of one contig. The tile's bytes are staged once into LDS with coalesced dword loads, every
-// position's K-mer hash is built from LDS, the hash table is gathered (one 8-byte entry per position,
-// all gathers of a thread in flight together) and the entry — zeroed when empty or rejected by the
-// sliding-window test — is stored per position with coalesced dword stores.
-// ------------------------------------------------------------------------------------------------
-template <bool HASH_ONLY>
-__global__ void __launch_bounds__(PROBE_THREADS) k_probe(RefView v, const uint8_t *__restrict__ qbuf,
-                                                         const Contig *__restrict__ contigs,
-                                                         const uint32_t *__restrict__ tileContig,
-                                                         uint32_t *__restrict__ cand,
-                                                         unsigned long long *__restrict__ stats) {
-    __shared__ uint32_t qs[TILE / 4 + 24];
-    const uint32_t tile = blockIdx.x;
-    const Contig cg = contigs[tileContig[tile]];
-    const uint64_t ts = (uint64_t) (tile - cg.tile0) * TILE;        // first position of the tile
-    const int K = v.K;
-    const uint64_t npos_all = cg.n >= (uint64_t) K ? cg.n - K + 1 : 0;           // positions i with i + K <= N
-    const uint32_t npos = npos_all > ts ? (uint32_t) (npos_all - ts < TILE ? npos_all - ts : TILE) : 0;
-    const uint8_t *q = qbuf + cg.qoff;
-    // stage bytes [ts, ts + npos + K - 1) from the enclosing aligned dwords
-    const uintptr_t A = (uintptr_t) (q + ts);
-    const uint32_t sh = (uint32_t) (A & 3);
-    const uint32_t *A0 = (const uint32_t *) (A & ~(uintptr_t) 3);
-    const uint32_t nbytes = npos ? npos + K - 1 : 0;
-    const uint32_t ndw = (sh + nbytes + 3) / 4;
-    for (uint32_t w = threadIdx.x; w < ndw; w += PROBE_THREADS) qs[w] = A0[w];
-    __syncthreads();
-
-    const int nw = K / 4;
-    uint32_t hsh[POS_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < POS_PER_THREAD; k++) {
-        const uint32_t j = k * PROBE_THREADS + threadIdx.x;
-        uint32_t h = (uint32_t) K;
-        if (j < npos) {
-            const uint32_t o = sh + j;
-            const uint32_t *w = qs + (o >> 2);
-            const uint32_t s = o & 3;
-            uint32_t lo = w[0];
-            for (int x = 0; x < nw; x++) {
-                const uint32_t hi = w[x + 1];
-                h = hash_step(h, __builtin_amdgcn_alignbyte(hi, lo, s), (uint32_t) x);
-                lo = hi;
-            }
-        }
-        hsh[k] = h;                                                   // bucket = h & mask, fingerprint = its top bits
-    }
-    uint32_t *out = cand + cg.candBase + ts;
-    if (HASH_ONLY) {                                                  // lazy mode: the chains gather on demand
-#pragma unroll
-        for (int k = 0; k < POS_PER_THREAD; k++) {
-            const uint32_t j = k * PROBE_THREADS + threadIdx.x;
-            out[j] = hsh[k];
-        }
-        if (threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long) npos);
-        return;
-    }
-    // all gathers of this thread are issued before the first one is consumed
-    uint32_t ent[POS_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < POS_PER_THREAD; k++) {
-        const uint32_t j = k * PROBE_THREADS + threadIdx.x;
-        ent[k] = j < npos ? ht_value(v, v.ht[hsh[k] & v.mask], hsh[k]) : 0u;
-    }
-    uint32_t nz = 0;
-#pragma unroll
-    for (int k = 0; k < POS_PER_THREAD; k++) {
-        const uint32_t j = k * PROBE_THREADS + threadIdx.x;
-        uint32_t e = ent[k];
-        if (e != 0) {                                                 // .cpp:208
-            uint64_t lo, hi;
-            if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;   // .cpp:212-220
-        }
-        out[j] = e;                                                   // the whole tile slot is written
-        nz += e != 0;
-    }
-    const unsigned long long b = __ballot(nz != 0);
-    (void) b;
-    for (int d = WAVE / 2; d > 0; d >>= 1) nz += (uint32_t) __shfl_down((int) nz, d);
-    if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&stats[2], (unsigned long long) nz);
-    if (threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long) npos);
-}
-
-// ------------------------------------------------------------------------------------------------
 // greedy resolution: the match list semantics of .cpp:250-315, replayed on the candidate array.
 // One wave per chain; every lane runs the same (wave-uniform) automaton, 64 positions are fetched per
 // step and skipped positions are jumped over with a ballot. Reference and query bytes are only touched
@@ -272,7 +185,7 @@ __device__ __forceinline__ uint64_t rfl64(uint64_t x) { return ((uint64_t) rfl32
 #ifndef SWSEM_OVERLAP
 #define SWSEM_OVERLAP 1024
 #endif
-constexpr int OVERLAP = SWSEM_OVERLAP;          // warm-up positions of a speculative block chain (<= TILE)
+constexpr int OVERLAP = SWSEM_OVERLAP;          // warm-up positions of a speculative block chain (<= a block: RBU)
 constexpr int SNAP = 4;                // stack elements snapshotted at a block boundary / end
 
 // A row of a block chain's stack: the match plus the scan position the chain had right after emitting it.
@@ -611,8 +524,7 @@ __device__ void visit(const RefView &v, const Contig &cg, const uint8_t *q, Stac
 // the fetched window (the common case: matches of ~100 bases) costs no further load.
 struct NoStop { __device__ __forceinline__ bool operator()() { return false; } };
 
-// Lazy form of the same loop: `hashes` holds the bucket index of every query position (k_probe<true>) and
-// the hash table is consulted only for the WL positions from the scan position on — the loop visits a
+// The hash table is consulted only for the WL positions from the scan position on — the loop visits a
 // few positions after every match and jumps ~100 ahead, so most buckets never need to be fetched.
 #ifndef SWSEM_WL
 #define SWSEM_WL 32
@@ -654,8 +566,8 @@ __device__ __forceinline__ uint32_t window_hash(const RefView &v, const uint8_t 
     return h;
 }
 
-template <bool FLY, bool LAPS, class Stack, class Stop = NoStop>
-__device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ hashes,
+template <bool LAPS, class Stack, class Stop = NoStop>
+__device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t *q,
                                int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
     const int32_t lane = (int32_t) (threadIdx.x & (WAVE - 1));
     int32_t wb = -0x40000000;                                         // window [wb, wb + WL)
@@ -683,10 +595,8 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
 #endif
             const int32_t pos = s + lane;
             uint32_t e = 0;
-            uint32_t hf = 0;
-            if constexpr (FLY) hf = window_hash(v, q, s, p1 - s < WL ? p1 - s : WL, lane);
+            const uint32_t hv = window_hash(v, q, s, p1 - s < WL ? p1 - s : WL, lane);
             if (lane < WL && pos < p1) {
-                const uint32_t hv = FLY ? hf : hashes[pos];
                 e = ht_value<LAPS>(v, v.ht[hv & v.mask], hv);
                 if (e != 0) {
                     uint64_t lo, hi;
@@ -708,57 +618,18 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
 }
 
 
-template <class Stack, class Stop = NoStop>
-__device__ void run_chain(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
-                          int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    constexpr int NB = 4;
-    while (true) {
-        const int32_t s = ch.scan > p0 ? ch.scan : p0;
-        if (s >= p1) break;
-        const int32_t base = s & ~(WAVE - 1);
-        uint32_t w[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const int32_t pos = base + k * WAVE + (int32_t) lane;
-            w[k] = (pos >= s && pos < p1) ? cand[pos] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const int32_t bk = base + k * WAVE;
-            if (bk >= p1) break;
-            if (ch.scan >= bk + WAVE) continue;                       // jumped over this batch
-            unsigned long long m = __ballot(w[k] != 0);
-            const int32_t rel0 = ch.scan - bk;
-            if (rel0 > 0) m &= ~((1ull << rel0) - 1);
-            while (m) {
-                const int l = __builtin_ctzll(m);
-                visit(v, cg, q, stk, ch, bk + l, rl32(w[k], l));
-                if (stop()) return;
-                const int32_t rel = ch.scan - bk;                     // first lane still to be visited
-                m = rel >= WAVE ? 0ull : (m & ~((1ull << rel) - 1));
-            }
-            if (ch.scan < bk + WAVE) ch.scan = bk + WAVE < p1 ? bk + WAVE : p1;
-        }
-    }
-}
-
-// MODE: 0 = dense candidate array (SWSEM_PROBE=dense), 1 = on-demand table lookups from a hash array written ahead
-// (SWSEM_HASH=pre), 2 = on-demand lookups, the windows hash their own K-mers (default)
 // LAPS: the circular buffer has wrapped (ht_value then tells stale entries by their epochs)
-template <int MODE, bool LAPS, class Stack, class Stop = NoStop>
-__device__ __forceinline__ void chain_run(const RefView &v, const Contig &cg, const uint8_t *q, const uint32_t *__restrict__ cand,
-                                          int32_t p0, int32_t p1, Stack &stk, Chain &ch, Stop stop = Stop()) {
-    if constexpr (MODE != 0) run_chain_lazy<MODE == 2, LAPS>(v, cg, q, cand, p0, p1, stk, ch, stop);
-    else run_chain(v, cg, q, cand, p0, p1, stk, ch, stop);
+template <bool LAPS, class Stack, class Stop = NoStop>
+__device__ __forceinline__ void chain_run(const RefView &v, const Contig &cg, const uint8_t *q, int32_t p0, int32_t p1, Stack &stk, Chain &ch,
+                                          Stop stop = Stop()) {
+    run_chain_lazy<LAPS>(v, cg, q, p0, p1, stk, ch, stop);
 }
 
 // Sequential resolution (one wave replays a whole contig): the simple form, kept as the cross-check
 // of the block-parallel path (SWSEM_RESOLVE=seq).
-template <int MODE, bool LAPS>
+template <bool LAPS>
 __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *__restrict__ qbuf,
                                                       const Contig *__restrict__ contigs,
-                                                      const uint32_t *__restrict__ cand,
                                                       Match *__restrict__ matches, uint32_t *__restrict__ matchCount) {
     __shared__ uint2 ring[RING];
     const Contig cg = contigs[blockIdx.x];
@@ -767,7 +638,7 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
     ArrayStack<Match> stk;
     stk.st = matches + cg.matchBase; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
-    chain_run<MODE, LAPS>(v, cg, qbuf + cg.qoff, cand + cg.candBase, 0, npos, stk, ch);
+    chain_run<LAPS>(v, cg, qbuf + cg.qoff, 0, npos, stk, ch);
     if (threadIdx.x == 0) matchCount[blockIdx.x] = (uint32_t) stk.sp;
 }
 
@@ -803,12 +674,11 @@ __device__ __forceinline__ void snapshot_top(const Row *st, int sp, Match *out) 
 }
 
 // resolve block rbIdx of a contig = tiles [rbIdx*rb, (rbIdx+1)*rb) of it
-template <int MODE, bool LAPS>
+template <bool LAPS>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RESOLVE_SGPRS))) k_resolve_blocks(RefView v, const uint8_t *__restrict__ qbuf,
                                                          const Contig *__restrict__ contigs,
                                                          const uint32_t *__restrict__ rbContig,
                                                          const uint32_t *__restrict__ order,
-                                                         const uint32_t *__restrict__ cand,
                                                          Row *__restrict__ regions, uint32_t cap, uint32_t rb,
                                                          BlockRec *__restrict__ recs) {
     __shared__ uint2 ring[RING];
@@ -821,7 +691,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
     const int32_t w0 = (int32_t) (b * rb * RBU);
     const int32_t w1 = w0 + (int32_t) (rb * RBU) < npos ? w0 + (int32_t) (rb * RBU) : npos;
-    const uint32_t *cd = cand + cg.candBase;
     Chain ch;
     ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
 #ifdef SWSEM_DIAG_PHASES
@@ -834,14 +703,14 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     ArrayStack<Row> stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
-    if (b) chain_run<MODE, LAPS>(v, cg, q, cd, w0 - OVERLAP, w0, stk, ch);   // warm-up on the previous block's tail
+    if (b) chain_run<LAPS>(v, cg, q, w0 - OVERLAP, w0, stk, ch);   // warm-up on the previous block's tail
     BlockRec r;
     r.scanB = ch.scan > w0 ? ch.scan : w0;
     r.spB = stk.sp;
     __builtin_amdgcn_s_waitcnt(0);            // the wave's own stack rows are read back below
     snapshot_top(stk.st, stk.sp, r.bTop);
     ch.minTouched = 0x7fffffff; ch.minKeep = stk.sp; ch.visited = 0;
-    chain_run<MODE, LAPS>(v, cg, q, cd, w0, w1, stk, ch);
+    chain_run<LAPS>(v, cg, q, w0, w1, stk, ch);
     r.scanF = ch.scan;
     r.spF = stk.sp;
     r.minTouched = ch.visited ? ch.minTouched : 0x7fffffff;
@@ -915,9 +784,9 @@ __global__ void __launch_bounds__(256) k_stitch_pre(const Contig *__restrict__ c
 // contig's match count. The walk is a dependent chain executed by a single wave, so everything in it
 // is either scalar (readfirstlane'd record fields) or one lane-parallel LDS operation: the newest
 // SNAP true rows live in LDS as 3*SNAP u64 words and are compared / rebuilt by 3*SNAP lanes at once.
-template <int MODE, bool LAPS>
+template <bool LAPS>
 __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__restrict__ qbuf,
-                                                 const Contig *__restrict__ contigs, const uint32_t *__restrict__ cand,
+                                                 const Contig *__restrict__ contigs,
                                                  Row *__restrict__ regions, Row *__restrict__ replayArea,
                                                  uint32_t cap, uint32_t rb, const BlockRec *__restrict__ recs,
                                                  const FastRec *__restrict__ fast,
@@ -1075,7 +944,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
                     (int32_t) rfl32((uint32_t) spec[sp].scanAfter) == ch.scan) { syncAt = sp; return true; }
                 return false;
             };
-            chain_run<MODE, LAPS>(v, cg, q, cand + cg.candBase, w0, w0 + span < npos ? w0 + span : npos, vs, ch, stop);
+            chain_run<LAPS>(v, cg, q, w0, w0 + span < npos ? w0 + span : npos, vs, ch, stop);
             int n = vs.ownN;
             vs.size_ -= n; vs.ownN = 0; vs.own = nullptr;
             __builtin_amdgcn_s_waitcnt(0);

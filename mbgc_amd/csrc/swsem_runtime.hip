@@ -20,13 +20,6 @@ using namespace swk;
 
 #define SWSEM_ESPEC (-100)   /* internal: a speculative finalize cannot be queued (it would need an ungated write) */
 
-#ifdef SWSEM_HTRACE
-#include <time.h>
-static inline void htrace(const char *what) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "HT %lld.%03ld %s\n", (long long) ts.tv_sec * 1000000 + ts.tv_nsec / 1000, ts.tv_nsec % 1000, what); }
-#define HT(x) htrace(x)
-#else
-#define HT(x) ((void) 0)
-#endif
 namespace {
 
 thread_local std::string g_err;
@@ -93,9 +86,7 @@ struct swsem {
     void sep_end_set(int64_t at, int sep) { sepEndPos = at; sepEndLaps = laps; sepEndVal = sep; }
     bool pristine = true;                  // the loader has only moved forward (wraps included: told by epochs); false after swsem_set_position
     int fpBits = 0;                        // fingerprint bits of a table entry: what the bucket index leaves of the 32-bit hash, at most 8
-    uint64_t hostProbes = 0;               // query positions of the batch (what the hash kernel counts when there is one)
-    bool flyHash = true;                   // lazy chains hash their scan windows themselves (SWSEM_HASH=pre: a hash array written ahead)
-    bool lazyProbe = true;                 // chains gather the hash table on demand (SWSEM_PROBE=lazy) instead of a dense probe pass
+    uint64_t hostProbes = 0;               // query positions of the batch
     bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
     bool specMode = false;                 // a speculative finalize is being queued: nothing may be written outside its gated launches
     DevBuf<uint32_t> dGate;
@@ -111,24 +102,14 @@ struct swsem {
     // --- per-round scratch
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
-    DevBuf<uint32_t> dTileContig, dMatchCount, dRbContig, dRbOrder, dCand;
+    DevBuf<uint32_t> dMatchCount, dRbContig, dRbOrder;
     std::vector<uint32_t> rbOrderHost, rbOrderKey;   // the table on the device is kept while the batches keep their shape (rbOrderKey)
     int orderMode = 1;                     // launch order of the resolve blocks: 0 contig-major, 1 offset-major on one XCD (SWSEM_ORDER)
     bool simt = true;                      // four chains per wave (k_resolve_blocks4); SWSEM_CHAINS=1: one chain per wave (k_resolve_blocks)
     uint32_t chainsPerWave = 1;            // of the last batch
-    // K-mer hashes of a batch announced ahead (swsem_hash_batch_dev): computed on a third stream into the other
-    // hash buffer while the current batch is still being matched; swsem_match_batch_dev on the same buffers adopts them
-    DevBuf<uint32_t> dCandNext, dPrepTileContig;
-    DevBuf<Contig> dPrepContigs;
-    DevBuf<unsigned long long> dPrepStats;
-    hipStream_t stream3 = nullptr;
-    hipEvent_t evHash = nullptr, evMatched = nullptr, evMatchedPrev = nullptr;   // hashes ready / chains of the last batch (the one before) done
-    bool prepValid = false;
-    int matchedRecorded = 0;
-    const uint8_t *prepQ = nullptr;
-    std::vector<uint64_t> prepOffsets;
-    std::vector<Contig> prepContigs;
-    std::vector<uint32_t> prepTileContig, tileContigHost, rbContigHost;
+    hipStream_t stream3 = nullptr;         // device-to-host copies of emitted streams (end_slot)
+    hipEvent_t evMatched = nullptr;        // chains of the last batch done
+    std::vector<uint32_t> rbContigHost;
     DevBuf<Match> dMatches;
     DevBuf<Row> dRegions, dReplay;
     DevBuf<BlockRec> dRecs;
@@ -195,7 +176,6 @@ struct swsem {
     std::vector<uint32_t> matchCount;
     std::vector<swsem_match_t> hostMatches;
     const uint8_t *qdev = nullptr;         // query buffer of the last batch
-    uint32_t ntiles = 0;
     uint32_t minLen = 0;
     bool batchValid = false;
     uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
@@ -512,51 +492,6 @@ int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
     return stage_copy(h, dst, slot, bytes, st);
 }
 
-// K-mer hashes of a future batch, beside whatever the main stream is doing (the hashes depend on the query only)
-int prepare_hashes(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n) {
-    HT("prepare_hashes enter");
-    h->prepValid = false;
-    hipStream_t hs = h->stream3;
-    if (n <= 0 || !h->lazyProbe || h->flyHash) return SWSEM_OK;   // (nothing to prepare: the chains hash their own windows)
-    (void) hipStreamQuery(hs);             // lets the runtime retire what this stream has completed (it is never waited on by the host)
-    h->prepContigs.assign(n, Contig());
-    h->prepTileContig.clear();
-    uint32_t tiles = 0;
-    for (int c = 0; c < n; c++) {
-        Contig &cg = h->prepContigs[c];
-        cg.qoff = offsets[c];
-        cg.n = offsets[c + 1] - offsets[c];
-        if (cg.n >= (1ull << 31) - (1ull << 20)) return SWSEM_OK;          // swsem_match_batch_dev reports it
-        const uint64_t npos = cg.n >= (uint64_t) h->K ? cg.n - h->K + 1 : 0;
-        cg.tile0 = tiles;
-        cg.ntiles = (uint32_t) ((npos + TILE - 1) / TILE);
-        cg.candBase = (uint64_t) tiles * TILE;
-        h->prepTileContig.insert(h->prepTileContig.end(), cg.ntiles, (uint32_t) c);
-        tiles += cg.ntiles;
-    }
-    if (!tiles) return SWSEM_OK;
-    int r;
-    if ((r = h->dPrepContigs.reserve(n)) || (r = h->dPrepTileContig.reserve(tiles)) || (r = h->dPrepStats.reserve(8)) ||
-        (r = h->dCandNext.reserve((size_t) tiles * TILE)))
-        return r;
-    // the buffer about to be overwritten held the hashes of the batch before the current one: its chains are long done,
-    // but say so to the third stream
-    if (h->matchedRecorded >= 2) HIPCHK(hipStreamWaitEvent(hs, h->evMatchedPrev, 0));
-    if ((r = upload(h, h->dPrepContigs.p, h->prepContigs.data(), n * sizeof(Contig), hs)) ||
-        (r = upload(h, h->dPrepTileContig.p, h->prepTileContig.data(), tiles * sizeof(uint32_t), hs)) || (r = flush_copies(h)))
-        return r;
-    const RefView v = h->view();
-    h->mark(SWSEM_K_PROBE, true, hs);
-    k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, hs>>>(v, qdev, h->dPrepContigs.p, h->dPrepTileContig.p, h->dCandNext.p, h->dPrepStats.p);
-    h->mark(SWSEM_K_PROBE, false, hs);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->evHash, hs));
-    h->prepQ = qdev;
-    h->prepOffsets.assign(offsets, offsets + n + 1);
-    h->prepValid = true;
-    return SWSEM_OK;
-}
-
 // Launch order of the resolve blocks (h->contigs filled in). The genomes of a collection resemble each other, so the
 // blocks that scan the same offsets of a round's contigs look up the same buckets and compare against the same
 // reference windows. Workgroups are dealt round-robin over the eight XCDs (slot s -> XCD s mod 8, MI355X_MICROARCH.md
@@ -610,7 +545,6 @@ bool build_resolve_order(swsem *h, uint32_t rblocks, uint32_t per) {
 }
 
 int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {
-    HT("run_batch enter");
     if (n <= 0) return fail(SWSEM_EINVAL, "empty batch");
     if (minLen < (uint32_t) h->K)   // SlidingWindowSparseEMMatcher.cpp:480-483
         return fail(SWSEM_EINVAL, "Minimal matching length cannot be smaller than K (%u < %d)", minLen, h->K);
@@ -618,24 +552,24 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     h->matchCount.clear();
     h->minLen = minLen;
     h->contigs.assign(n, Contig());
-    std::vector<uint32_t> &tileContig = h->tileContigHost, &rbContig = h->rbContigHost;   // uploaded asynchronously
-    tileContig.clear(); rbContig.clear();
+    std::vector<uint32_t> &rbContig = h->rbContigHost;   // uploaded asynchronously
+    rbContig.clear();
     uint64_t matchRows = 0, bases = 0, probes = 0;
-    uint32_t tiles = 0, rblocks = 0;
+    uint32_t rblocks = 0;
     {
         // Block chains are latency-bound and a launch lasts as long as its slowest wave: the blocks are sized so
-        // that all of them are resident at once (one wave each, RESOLVE_WAVES_PER_SIMD per SIMD) and there are as many as that allows.
+        // that all of them are resident at once and there are as many as that allows.
         // Fewer, longer blocks leave wave slots empty; more of them run in two generations and lengthen the
         // sequential stitch. At least 8 units (8192 positions), so that the warm-up stays a small part of a block.
-        uint64_t allTiles = 0;                          // in units of RBU positions
+        uint64_t allUnits = 0;                          // in units of RBU positions
         for (int c = 0; c < n; c++) {
             const uint64_t len = offsets[c + 1] - offsets[c];
-            allTiles += len >= (uint64_t) h->K ? (len - h->K + 1 + RBU - 1) / RBU : 0;
+            allUnits += len >= (uint64_t) h->K ? (len - h->K + 1 + RBU - 1) / RBU : 0;
         }
-        h->chainsPerWave = (h->simt && h->lazyProbe && h->flyHash && !h->seqResolve && h->K <= K_MAX4) ? (uint32_t) GC : 1u;
+        h->chainsPerWave = (h->simt && !h->seqResolve && h->K <= K_MAX4) ? (uint32_t) GC : 1u;
         const uint64_t waves = h->chainsPerWave > 1 ? (uint64_t) h->waveSlots / RESOLVE_WAVES_PER_SIMD * RESOLVE4_WAVES_PER_SIMD : h->waveSlots;
         const uint64_t slots = std::max<uint64_t>(1, waves * h->chainsPerWave * 19 / 20);
-        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(64, std::max<uint64_t>(8, (allTiles + slots - 1) / slots));
+        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(64, std::max<uint64_t>(8, (allUnits + slots - 1) / slots));
     }
     for (int c = 0; c < n; c++) {
         Contig &cg = h->contigs[c];
@@ -646,65 +580,38 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         cg.lock = lockPos ? lockPos[c] : UINT64_MAX;
         const uint64_t npos = cg.n >= (uint64_t) h->K ? cg.n - h->K + 1 : 0;
         probes += npos;
-        cg.tile0 = tiles;
-        cg.ntiles = (uint32_t) ((npos + TILE - 1) / TILE);
-        cg.candBase = (uint64_t) tiles * TILE;
         cg.matchBase = matchRows;
         matchRows += cg.n / minLen + 2;
         cg.rb0 = rblocks;
         cg.nrb = (uint32_t) ((npos + (uint64_t) h->rb * RBU - 1) / ((uint64_t) h->rb * RBU));
-        for (uint32_t t = 0; t < cg.ntiles; t++) tileContig.push_back((uint32_t) c);
         for (uint32_t t = 0; t < cg.nrb; t++) rbContig.push_back((uint32_t) c);
-        tiles += cg.ntiles;
         rblocks += cg.nrb;
         bases += cg.n;
     }
-    h->ntiles = tiles;
     int r;
     if ((r = h->dContigs.reserve(n))) return r;
     if ((r = h->dMatchCount.reserve(n))) return r;
     if ((r = h->dStats.reserve(8))) return r;
-    if ((r = h->dTileContig.reserve(std::max<uint32_t>(tiles, 1)))) return r;
-    if (!(h->flyHash && h->lazyProbe) && (r = h->dCand.reserve((size_t) std::max<uint32_t>(tiles, 1) * TILE))) return r;
     if ((r = h->dMatches.reserve(matchRows))) return r;
     if ((r = upload(h, h->dContigs.p, h->contigs.data(), n * sizeof(Contig), h->stream))) return r;
     if ((r = h->dRbContig.reserve(std::max<uint32_t>(rblocks, 1)))) return r;
     uint32_t rslots = 0;
-    if (tiles) {
+    if (rblocks) {
         const uint32_t *had = h->dRbOrder.p;
         const bool fresh = build_resolve_order(h, rblocks, h->chainsPerWave);
         rslots = (uint32_t) (h->rbOrderHost.size() / h->chainsPerWave);
         if ((r = h->dRbOrder.reserve(h->rbOrderHost.size() + h->rbOrderHost.size() / 4 + 64))) return r;
-        if ((r = upload(h, h->dTileContig.p, tileContig.data(), tiles * sizeof(uint32_t), h->stream)) ||
-            (r = upload(h, h->dRbContig.p, rbContig.data(), rblocks * sizeof(uint32_t), h->stream)))
-            return r;
+        if ((r = upload(h, h->dRbContig.p, rbContig.data(), rblocks * sizeof(uint32_t), h->stream))) return r;
         if ((fresh || had != h->dRbOrder.p) && (r = upload(h, h->dRbOrder.p, h->rbOrderHost.data(), h->rbOrderHost.size() * sizeof(uint32_t), h->stream)))
             return r;
     }
     if ((r = zero_dev(h, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) || (r = flush_copies(h))) return r;
     const RefView v = h->view();
-    const int mode = h->lazyProbe ? (h->flyHash ? 2 : 1) : 0;       // template arguments of the chain kernels (swsem_kernels.hip: chain_run)
-    const bool wrapped = v.fpCheck == 2;
-#define SWSEM_BY_MODE(L) do { if (wrapped) { if (mode == 2) L(2, true); else if (mode == 1) L(1, true); else L(0, true); } \
-                              else { if (mode == 2) L(2, false); else if (mode == 1) L(1, false); else L(0, false); } } while (0)
-    // hashes announced ahead for exactly these buffers: adopt them
-    const bool adopted = h->prepValid && h->lazyProbe && h->prepQ == qdev && h->prepOffsets.size() == (size_t) n + 1 &&
-                         std::equal(h->prepOffsets.begin(), h->prepOffsets.end(), offsets);
-    if (adopted) h->prepValid = false;                  // (a batch in between — a retry inside a round — leaves the announcement standing)
-    if (adopted && tiles) {
-        std::swap(h->dCand, h->dCandNext);
-        HIPCHK(hipStreamWaitEvent(h->stream, h->evHash, 0));
-    } else if (tiles && !(h->flyHash && h->lazyProbe)) {
-        h->mark(SWSEM_K_PROBE, true);
-        if (h->lazyProbe) k_probe<true><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
-        else k_probe<false><<<dim3(tiles), dim3(PROBE_THREADS), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dTileContig.p, h->dCand.p, h->dStats.p);
-        h->mark(SWSEM_K_PROBE, false);
-    }
-    if (h->seqResolve || tiles == 0) {
+    const bool wrapped = v.fpCheck == 2;                // kernels instantiated with / without the lap epochs (ht_value)
+    if (h->seqResolve || rblocks == 0) {
         h->mark(SWSEM_K_RESOLVE, true);
-#define SWSEM_LAUNCH_SEQ(M, W) k_resolve_seq<M, W><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dMatches.p, h->dMatchCount.p)
-        SWSEM_BY_MODE(SWSEM_LAUNCH_SEQ);
-#undef SWSEM_LAUNCH_SEQ
+        if (wrapped) k_resolve_seq<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dMatches.p, h->dMatchCount.p);
+        else k_resolve_seq<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dMatches.p, h->dMatchCount.p);
         h->mark(SWSEM_K_RESOLVE, false);
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
@@ -718,31 +625,26 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if ((r = h->dDstOff.reserve(rblocks))) return r;
         if ((r = h->dPrev.reserve(rblocks))) return r;
         h->mark(SWSEM_K_RESOLVE, true);
-#define SWSEM_LAUNCH_RB(M, W) k_resolve_blocks<M, W><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dCand.p, \
-                                                                                      h->dRegions.p, cap, h->rb, h->dRecs.p)
         if (h->chainsPerWave == (uint32_t) GC) {
             if (wrapped) k_resolve_blocks4<true><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
             else k_resolve_blocks4<false><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
-        } else
-            SWSEM_BY_MODE(SWSEM_LAUNCH_RB);
-#undef SWSEM_LAUNCH_RB
+        } else {
+            if (wrapped) k_resolve_blocks<true><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
+            else k_resolve_blocks<false><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
+        }
         h->mark(SWSEM_K_RESOLVE, false);
         h->mark(SWSEM_K_STITCH, true);
         k_stitch_pre<<<dim3((rblocks + 255) / 256), dim3(256), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRecs.p, h->rb, rblocks, h->dFast.p);
-#define SWSEM_LAUNCH_ST(M, W) k_stitch<M, W><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dCand.p, h->dRegions.p, h->dReplay.p, cap, h->rb, \
-                                                                      h->dRecs.p, h->dFast.p, h->dSegStart.p, h->dKeepN.p, h->dPrev.p, h->dDstOff.p, \
-                                                                      h->dMatchCount.p, h->dStats.p)
-        SWSEM_BY_MODE(SWSEM_LAUNCH_ST);
-#undef SWSEM_LAUNCH_ST
+        if (wrapped) k_stitch<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p, h->dFast.p, h->dSegStart.p,
+                                                                          h->dKeepN.p, h->dPrev.p, h->dDstOff.p, h->dMatchCount.p, h->dStats.p);
+        else k_stitch<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p, h->dFast.p, h->dSegStart.p,
+                                                                    h->dKeepN.p, h->dPrev.p, h->dDstOff.p, h->dMatchCount.p, h->dStats.p);
         k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
                                                             h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
         h->mark(SWSEM_K_STITCH, false);
     }
-#undef SWSEM_BY_MODE
     HIPCHK(hipGetLastError());
-    std::swap(h->evMatched, h->evMatchedPrev);
     HIPCHK(hipEventRecord(h->evMatched, h->stream));
-    if (h->matchedRecorded < 2) h->matchedRecorded++;
     h->qdev = qdev;
     h->stats[0] = bases;
     h->hostProbes = probes;
@@ -780,7 +682,7 @@ void take_counts(swsem *h) {
     const size_t n = h->contigs.size();
     const unsigned long long *st = (const unsigned long long *) h->pin;
     h->matchCount.assign((const uint32_t *) (h->pin + 64), (const uint32_t *) (h->pin + 64) + n);
-    h->stats[1] = (h->flyHash && h->lazyProbe) ? h->hostProbes : st[1]; h->stats[2] = st[2]; h->stats[5] = st[3];
+    h->stats[1] = h->hostProbes; h->stats[2] = st[2]; h->stats[5] = st[3];
     uint64_t tot = 0;
     for (size_t c = 0; c < n; c++) tot += h->matchCount[c];
     h->stats[3] = tot;
@@ -862,13 +764,8 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
         hipEventCreateWithFlags(&h->slot[0].evDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->slot[1].evDone, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evHash, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evMatched, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evMatchedPrev, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
+        hipEventCreateWithFlags(&h->evMatched, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
-    if (const char *e = getenv("SWSEM_PROBE")) h->lazyProbe = strcmp(e, "dense") != 0;
-    if (const char *e = getenv("SWSEM_HASH")) h->flyHash = strcmp(e, "pre") != 0;
-    if (h->K > 128) h->flyHash = false;                               // (a window's bytes must fit one dword per lane)
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_ORDER")) h->orderMode = strcmp(e, "contig") == 0 ? 0 : 1;
@@ -906,7 +803,7 @@ void swsem_destroy(swsem_t *h) {
     if (h->ref) (void) hipFree(h->ref);
     if (h->ht) (void) hipFree(h->ht);
     if (h->lut) (void) hipFree(h->lut);
-    h->stage.release(); h->dContigs.release(); h->dTileContig.release(); h->dCand.release(); h->dCandNext.release(); h->dPrepTileContig.release(); h->dPrepContigs.release(); h->dPrepStats.release();
+    h->stage.release(); h->dContigs.release(); 
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dFast.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
     h->dPrev.release(); h->dRbContig.release(); h->dRbOrder.release();
@@ -920,9 +817,7 @@ void swsem_destroy(swsem_t *h) {
     for (auto &e : h->idle) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     h->idle.clear();
     if (h->stream3) { (void) hipStreamSynchronize(h->stream3); (void) hipStreamDestroy(h->stream3); }
-    if (h->evHash) (void) hipEventDestroy(h->evHash);
     if (h->evMatched) (void) hipEventDestroy(h->evMatched);
-    if (h->evMatchedPrev) (void) hipEventDestroy(h->evMatchedPrev);
     if (h->evP1) (void) hipEventDestroy(h->evP1);
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
@@ -1046,21 +941,14 @@ static int finalize_impl(swsem_t *h, int n, const uint8_t *const *ext_dev, const
         if (!r && lockPos) r = swsem_release_lock(h, lockPos[i]);
     }
     h->deferInserts = false;
-    HT("finalize: pieces done");
     if (r == SWSEM_ESPEC) { h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear(); return r; }
     const int r2 = flush_inserts(h, gate);
-    HT("finalize: flushed");
     return r ? r : r2;
 }
 
 int swsem_finalize_targets(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
                            int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter) {
     return finalize_impl(h, n, ext_dev, ext_len, addSep, sep, lazySeparator, lockPos, loadedAfter, nullptr);
-}
-
-int swsem_hash_batch_dev(swsem_t *h, const uint8_t *q, const uint64_t *offsets, int n) {
-    HIPCHK(hipSetDevice(h->device));
-    return prepare_hashes(h, q, offsets, n);
 }
 
 int swsem_match_batch_dev(swsem_t *h, const uint8_t *q, const uint64_t *offsets, int n, uint32_t minLen, const uint64_t *lockPos) {
@@ -1207,13 +1095,6 @@ int swsem_debug_phases(swsem_t *h, uint64_t *out) {
 }
 #endif
 
-// diagnostics: one raw 64-bit table entry
-int swsem_debug_ht_entry(swsem_t *h, uint64_t bucket, uint64_t *out) {
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, h->ht + bucket, 8, hipMemcpyDeviceToHost));
-    return SWSEM_OK;
-}
-
 int swsem_profile_enable(swsem_t *h, int on) {
     h->drain_events();
     h->prof = on != 0;
@@ -1271,11 +1152,9 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
                            const int *factor, const int64_t *processed, const int64_t *targetIdx,
                            const uint64_t *refExtLoadedPos, uint64_t nLoaded, const swsem_spec_finalize_t *spec, int *applied) {
     HIPCHK(hipSetDevice(h->device));
-    HT("emit_begin enter");
     if (applied) *applied = 0;
     const int si = h->latest ^ 1;                                     // the slot not used by the previous emission
     { int e = end_slot(h, si); if (e) return e; }                    // its scratch is about to be reused
-    HT("slot ended");
     swsem::EmitSlot &E = h->slot[si];
     if (!h->batchValid) return fail(SWSEM_EINVAL, "swsem_emit: no match results on the handle");
     if (n <= 0) return fail(SWSEM_EINVAL, "swsem_emit: empty request");
@@ -1311,7 +1190,6 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         for (int st = 0; st < SWSEM_NSTREAMS; st++) { e.streamBase[st] = arena; arena += (szs[st] + 15) & ~15ull; }
     }
     const uint32_t chunks = (uint32_t) E.chunkOwner.size();
-    HT("tables built");
     h->capN = std::max<uint64_t>(h->capN, (uint64_t) n); h->capRows = std::max(h->capRows, rows); h->capArena = std::max(h->capArena, arena);
     if (nLoaded + 1 > h->capLoaded) h->capLoaded = std::max<uint64_t>(4096, 2 * (nLoaded + 1));   // (regrowing a buffer waits for the whole device: rarely)
     h->capChunks = std::max<uint64_t>(h->capChunks, chunks);
@@ -1325,9 +1203,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
             (r = E.dEPack.reserve((size_t) N * SWSEM_NSTREAMS)))
             return r;
     }
-    HT("reserved");
     if ((r = upload(h, E.dEOwner.p, E.chunkOwner.data(), chunks * sizeof(uint32_t), h->stream))) return r;
-    HT("owner uploaded");
     if ((r = upload(h, E.dECg.p, E.ecg.data(), n * sizeof(EmitContig), h->stream)) || (r = upload(h, E.dEWhich.p, which.data(), n * sizeof(int), h->stream))) return r;
     E.eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
     if ((r = upload(h, E.dELoaded.p, E.eloaded.data(), nLoaded * sizeof(uint64_t), h->stream))) return r;
@@ -1349,7 +1225,6 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     v.chunkOwner = E.dEOwner.p;
     v.ncontigs = (uint32_t) n;
     const dim3 grid2(chunks);
-    HT("p1 launch");
     h->mark(SWSEM_K_EMIT, true);
     k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
     k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
@@ -1371,7 +1246,6 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (hipHostMalloc((void **) &E.pinE, want, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
         E.pinECap = want;
     }
-    HT("phase2 launch");
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
     h->mark(SWSEM_K_EMIT2, true, h->stream2);
     k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p);
@@ -1403,7 +1277,6 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     // bookkeeping accordingly; when the prediction fails nothing on the device has changed.
     struct { int64_t pos1, sepEndPos; int laps, sepEndLaps, sepEndVal; uint64_t samplingPos, swEnd; uint32_t epoch, eCur, ePrev; bool pristine; std::deque<uint64_t> locks; } snap;
     bool queued = false;
-    HT("spec begin");
     if (spec && spec->ntargets > 0) {
         snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch; snap.eCur = h->eCur; snap.ePrev = h->ePrev; snap.sepEndPos = h->sepEndPos; snap.sepEndLaps = h->sepEndLaps; snap.sepEndVal = h->sepEndVal;
         snap.pristine = h->pristine; snap.locks = h->locks;
@@ -1418,9 +1291,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
                        h->pristine = snap.pristine; h->locks = snap.locks; }
     }
-    HT("spec queued, waiting");
     HIPCHK(hipEventSynchronize(h->evP1));                           // pass 1 and its copies to the host (not what was queued after them)
-    HT("evP1 done");
     if (needCounts) take_counts(h);
     E.eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
     if (queued) {

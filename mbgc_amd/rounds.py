@@ -163,8 +163,8 @@ class RoundRunner:
         [offsets[c], offsets[c+1]). targets[c] = index (0..T-1) of the local target contig c belongs to
         (default: one contig per target). Every rank passes the same number of targets T; globally the
         round's targets are ordered rank-major. Returns this rank's match counts per contig.
-        next_batch = (qbuf, offsets) of the round that follows, if its bytes are already in HBM: its K-mer
-        hashes are then computed beside this round's match-finding (they depend on the query only)."""
+        next_batch = (qbuf, offsets) of the round that follows, if its bytes are already in HBM: with several ranks its
+        size rides on this round's length exchange, so that the next round's extension all-gather starts without one."""
         m = self.m
         ncont = len(offsets) - 1
         targets = list(range(ncont)) if targets is None else list(targets)
@@ -191,9 +191,6 @@ class RoundRunner:
             if pending:
                 self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
                             [lock_of[c] for c in pending], min_len)
-                if next_batch is not None and hasattr(m, "hash_batch_dev"):
-                    m.hash_batch_dev(next_batch[0].data_ptr(), next_batch[1])
-                    next_batch = None
                 spec_applied = False
                 if self.p is not None:
                     tgt = [first + self.rank * T + targets[c] for c in pending]

@@ -196,13 +196,12 @@ def test_batch_round_on_device(binding):
     assert fp == _orc.fingerprint(allm) and tot == len(allm) and ln == int(allm[:, 1].sum())
 
 
-@pytest.mark.parametrize("env", [{"SWSEM_RESOLVE": "seq"}, {"SWSEM_RB": "1"}, {"SWSEM_RB": "2"}, {"SWSEM_RB": "16"},
-                                 {"SWSEM_PROBE": "dense"}, {"SWSEM_PROBE": "dense", "SWSEM_RESOLVE": "seq"},
-                                 {"SWSEM_PROBE": "dense", "SWSEM_RB": "1"}, {"SWSEM_HASH": "pre"}, {"SWSEM_HASH": "pre", "SWSEM_RB": "1"},
-                                 {"SWSEM_HASH": "pre", "SWSEM_RESOLVE": "seq"}])
+@pytest.mark.parametrize("env", [{"SWSEM_RESOLVE": "seq"}, {"SWSEM_RB": "1"}, {"SWSEM_RB": "2"}, {"SWSEM_RB": "16"}, {"SWSEM_RB": "64"},
+                                 {"SWSEM_CHAINS": "1"}, {"SWSEM_CHAINS": "1", "SWSEM_RB": "1"}, {"SWSEM_CHAINS": "1", "SWSEM_RB": "5"},
+                                 {"SWSEM_ORDER": "contig"}, {"SWSEM_ORDER": "contig", "SWSEM_RB": "3"}])
 def test_resolve_variants_agree_with_oracle(binding, env, monkeypatch):
-    """sequential replay, block-parallel speculation at several block sizes, and the dense probe pass instead
-    of the chains' on-demand table lookups: same rows"""
+    """one wave replaying a whole contig, block-parallel speculation at several block lengths (units of 1024 positions),
+    four chains per wave (default) and one chain per wave, both launch orders: same rows"""
     for k, val in env.items():
         monkeypatch.setenv(k, val)
     for div, seed in ((0.01, 41), (0.0005, 42), (0.1, 43)):
