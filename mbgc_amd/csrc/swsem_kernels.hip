@@ -132,7 +132,9 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
     const int nw = K / 4;
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
     const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
+#ifndef SWSEM_INSERT_NOREAD
     if (ht[h & mask] >= key) return;                   // (entries only grow: a stale read shows a smaller one at worst, then the atomic decides)
+#endif
     atomicMax(&ht[h & mask], key);
 }
 

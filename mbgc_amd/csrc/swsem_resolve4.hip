@@ -124,7 +124,6 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
     uint64_t lock = UINT64_MAX;
     int32_t w0 = 0, w1 = 0, p0 = 0, p1 = 0, scan = 0;
     Row *st = regions;
-    BlockRec *rec = recs;
     if (g != 0xFFFFFFFFu) {
         const Contig *cg = contigs + rbContig[g];
         q = qbuf + cg->qoff;
@@ -135,7 +134,6 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
         w0 = (int32_t) (b * rb * RBU);
         w1 = w0 + (int32_t) (rb * RBU) < npos ? w0 + (int32_t) (rb * RBU) : npos;
         st = regions + (uint64_t) g * cap;
-        rec = recs + g;
         phase = 0;
         p0 = b ? w0 - OVERLAP : 0;                 // block 0 starts from the true (empty) state: its warm-up is empty
         p1 = w0;
@@ -143,9 +141,8 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
     }
     if (__ballot(phase != 2) == 0) return;
     const uint64_t tstart = __builtin_amdgcn_s_memtime();
-    int32_t sp = 0, ringLow = 0, spB = 0;
-    int32_t minTouched = 0x7fffffff, minKeep = 0x7fffffff, visited = 0;
-    uint32_t cands = 0;
+    int32_t sp = 0, ringLow = 0;
+    int32_t minTouched = 0x7fffffff, minKeep = 0x7fffffff;   // (minTouched stays at its start value exactly while no hit has been processed)
     int32_t wb = -0x40000000;                      // scan window [wb, wb + GL)
     uint32_t went = 0, m16 = 0;                    // this lane's table value in the window / the group's candidate lanes
     int32_t qb0 = 0, qlo = 0, qhi = 0;             // query cache: first byte position of the buffer, valid positions [qlo, qhi)
@@ -166,6 +163,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                 if (s < p1) scan = s;
                 else {
                     __builtin_amdgcn_s_waitcnt(0);                 // the chain's own rows are read back below
+                    BlockRec *rec = recs + g;
                     Match *top = phase == 0 ? rec->bTop : rec->fTop;
                     if (gl < 3u * SNAP) {                          // newest rows, newest first, one u64 per lane
                         const int32_t j = (int32_t) (gl / 3u), f = (int32_t) (gl % 3u);
@@ -173,17 +171,17 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                     }
                     if (phase == 0) {
                         if (gl == 0) { rec->scanB = scan > w0 ? scan : w0; rec->spB = sp; }
-                        spB = sp;
-                        minTouched = 0x7fffffff; minKeep = sp; visited = 0;
+                        minTouched = 0x7fffffff; minKeep = sp;
                         phase = 1; p0 = w0; p1 = w1;
                         wb = -0x40000000;                          // positions from w0 on were not looked up
                     } else {
                         if (gl == 0) {
+                            const int32_t spB = rec->spB;                    // (written at the boundary by this lane)
                             rec->scanF = scan; rec->spF = sp;
-                            rec->minTouched = visited ? minTouched : 0x7fffffff;
+                            rec->minTouched = minTouched;
                             rec->minKeep = minKeep < spB ? minKeep : spB;
                             rec->cycles = __builtin_amdgcn_s_memtime() - tstart;
-                            rec->visits = cands; rec->emits = (uint32_t) sp;
+                            rec->visits = 0; rec->emits = (uint32_t) sp;
                         }
                         phase = 2;
                     }
@@ -280,7 +278,6 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
             const uint32_t l = (uint32_t) __builtin_ctz(mk);
             i = wb + (int32_t) l;
             const uint32_t val = gread(went, gbase + l);
-            cands++;
             c = (uint64_t) val << v.k1ord;                         // htDecodePos, .h:133
             uint64_t lo = 0, hi = 0;
             window_ok(v, lock, c, lo, hi);
@@ -373,7 +370,6 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                 }
                 if (!brokeOut) keep = -1;
                 if (keep < minTouched) minTouched = keep;
-                visited++;
                 if (keep < 0) {                                               // .cpp:277-280
                     int32_t t = loDist < i + 1 ? loDist : i + 1;
                     need_ell(t - 1);
