@@ -186,6 +186,27 @@ void swsem_emit_set_host_copy(swsem_t *h, int on);
 int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched /* [n of the last swsem_emit_batch] */);
 int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total);
 
+/* ---- the decoder's per-contig automaton on the device: the exact inverse of processMatches,
+ * MBGC_Decoder::decodeSequenceAndReturnUnmatchedChars + extendMatchLeft/Right (mbgccoder/MBGC_Decoder.cpp:319-523), one
+ * wave per contig against the handle's reference buffer (the contigs of a call are independent: each stands against the
+ * reference as its lock position froze it). All pointers are device pointers. destLen[k] = bytes written, unmatched[k] =
+ * the function's return value or -1 for a malformed stream set (a stream ran out, bytes were left over, dest too small). */
+typedef struct {
+    const uint8_t *stream_dev[SWSEM_NSTREAMS];
+    uint64_t size[SWSEM_NSTREAMS];
+    uint64_t refLockPos;                  /* the target's matching-lock position, SWSEM_NO_LOCK if none */
+    uint8_t *dest_dev;
+    uint64_t destCap;
+} swsem_decode_job_t;
+int swsem_decode_contigs_dev(swsem_t *h, const swsem_emit_params_t *p, int n, const swsem_decode_job_t *jobs,
+                             uint64_t *destLen, int64_t *unmatched);
+/* Device-side check of the selected emission (see swsem_emit_select): every emitted contig's six streams, still packed in
+ * HBM, are decoded by that automaton — no encoder logic involved — and compared with the query bytes they were emitted
+ * for and with processMatches' return value. *nbad = contigs that fail; *firstBad / *firstDiff (may be NULL) = the first
+ * of them and the first differing byte. Valid while the reference text the emission could match is still in the buffer,
+ * i.e. before the rounds after it start overwriting it (a circular buffer that has wrapped). Waits for the emission. */
+int swsem_emit_verify(swsem_t *h, int *nbad, int *firstBad, uint64_t *firstDiff);
+
 /* ---- device-memory plumbing for host code that stays free of HIP headers (the C++ facade) */
 int swsem_dev_malloc(swsem_t *h, uint64_t bytes, void **out_dev);
 int swsem_dev_free(swsem_t *h, void *p_dev);

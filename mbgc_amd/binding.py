@@ -22,7 +22,7 @@ swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length 
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
 swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_debug_copy_ref swsem_debug_write_ref swsem_debug_copy_ht
-swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_download swsem_dev_copy""".split()
+swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_download swsem_dev_copy swsem_decode_contigs_dev swsem_emit_verify""".split()
 
 
 class SpecFinalize(C.Structure):
@@ -45,6 +45,11 @@ class EmitParams(C.Structure):
                 ("allowedTargetsOutrunForDissimilarContigs", C.c_int),
                 ("minimalLengthForDissimilarContigs", C.c_uint64),
                 ("unmatchedFractionFactorTweakForDissimilarContigs", C.c_int)]
+
+
+class DecodeJob(C.Structure):
+    _fields_ = [("stream_dev", C.c_void_p * 6), ("size", C.c_uint64 * 6), ("refLockPos", C.c_uint64), ("dest_dev", C.c_void_p),
+                ("destCap", C.c_uint64)]
 
 
 class Streams(C.Structure):
@@ -114,6 +119,8 @@ def lib():
         L.swsem_emit_set_host_copy.restype = None
         L.swsem_emit_pack_dev.argtypes = [vp, vp, u64, pu64, pu64]
         L.swsem_emit_unmatched.argtypes = [vp, pu64]
+        L.swsem_emit_verify.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), pu64]
+        L.swsem_decode_contigs_dev.argtypes = [vp, C.POINTER(EmitParams), ci, vp, pu64, C.POINTER(C.c_int64)]
         L.swsem_debug_copy_ref.argtypes = [vp, u64, u64, vp]
         L.swsem_debug_write_ref.argtypes = [vp, u64, u64, vp]
         L.swsem_debug_copy_ht.argtypes = [vp, vp]
@@ -294,6 +301,29 @@ class SlidingWindowSparseEMMatcher:
     def emit_select(self, previous): _chk(lib().swsem_emit_select(self.h, int(previous)))
 
     def emit_set_host_copy(self, on): lib().swsem_emit_set_host_copy(self.h, int(on))
+
+    def emit_verify(self):
+        """device-side check of the selected emission: its streams decoded by the decoder's automaton against the query.
+        -> (contigs that fail, first of them or -1, first differing byte)"""
+        nbad, first, diff = C.c_int(), C.c_int(), C.c_uint64()
+        _chk(lib().swsem_emit_verify(self.h, C.byref(nbad), C.byref(first), C.byref(diff)))
+        return nbad.value, first.value, diff.value
+
+    def decode_contigs_dev(self, params, jobs):
+        """jobs: list of (six (device pointer, size) pairs, lock position, dest device pointer, dest capacity).
+        -> (bytes written per contig, unmatchedChars per contig or -1)"""
+        n = len(jobs)
+        arr = (DecodeJob * n)()
+        for k, (streams, lock, dest, cap) in enumerate(jobs):
+            for st, (ptr, size) in enumerate(streams):
+                arr[k].stream_dev[st] = ptr
+                arr[k].size[st] = size
+            arr[k].refLockPos, arr[k].dest_dev, arr[k].destCap = lock, dest, cap
+        dl = np.zeros(n, dtype=np.uint64)
+        un = np.zeros(n, dtype=np.int64)
+        _chk(lib().swsem_decode_contigs_dev(self.h, C.byref(params), n, C.cast(arr, C.c_void_p), dl.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            un.ctypes.data_as(C.POINTER(C.c_int64))))
+        return dl, un
 
     def emit_pack_sizes(self, n):
         sizes = np.zeros(n * 6, dtype=np.uint64)

@@ -6,6 +6,7 @@
 #include "swsem_kernels.hip"
 #include "swsem_resolve4.hip"
 #include "swsem_emit.hip"
+#include "swsem_decode.hip"
 
 #include <algorithm>
 #include <cstdarg>
@@ -117,6 +118,9 @@ struct swsem {
     DevBuf<uint32_t> dSegStart, dKeepN, dDstOff;
     DevBuf<int32_t> dPrev;
     DevBuf<unsigned long long> dStats;
+    DevBuf<uint8_t> dDecode;                 // contigs given back by the device decoder (swsem_emit_verify)
+    DevBuf<DecodeJob> dJobs;
+    DevBuf<DecodeOut> dDecOut;
     // --- emission: two slots, so that the second phase of one batch can still be running while the next is begun
     struct EmitSlot {
         DevBuf<EmitContig> dECg;
@@ -136,6 +140,8 @@ struct swsem {
         std::vector<EmitOut> eout;
         hipEvent_t evDone = nullptr;
         bool outstanding = false, refGuarded = false;
+        const uint8_t *qdev = nullptr;       // query buffer the emission reads
+        swsem_emit_params_t params;          // its parameters
         uint64_t emitPos1 = 0;               // loading position the emission started at
         uint64_t lockMin = UINT64_MAX;       // lowest matching-lock position of its contigs (UINT64_MAX: some contig had none)
         int emitLaps = 0;                    // laps of the buffer when it started
@@ -806,7 +812,7 @@ void swsem_destroy(swsem_t *h) {
     h->stage.release(); h->dContigs.release(); 
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dFast.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
-    h->dPrev.release(); h->dRbContig.release(); h->dRbOrder.release();
+    h->dPrev.release(); h->dRbContig.release(); h->dRbOrder.release(); h->dDecode.release(); h->dJobs.release(); h->dDecOut.release();
     for (auto &E : h->slot) E.release();
     h->dTables.release(); h->dGate.release(); h->dPred.release();
     if (h->pin) { (void) hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
@@ -1261,7 +1267,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     if ((r = download(h, E.pinE, E.dEOut.p, n * sizeof(EmitOut), h->stream2)) || (r = flush_copies(h))) return r;
     HIPCHK(hipEventRecord(E.evDone, h->stream2));
     h->latest = si; h->selected = -1;
-    E.outstanding = true; E.refGuarded = false; E.emitN = n; E.emitPos1 = (uint64_t) h->pos1;
+    E.outstanding = true; E.refGuarded = false; E.emitN = n; E.emitPos1 = (uint64_t) h->pos1; E.qdev = h->qdev; E.params = *p;
     E.emitLaps = h->laps;
     E.lockMin = UINT64_MAX;
     {
@@ -1390,6 +1396,71 @@ int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
     out->totalMatched = o.totalMatched;
     out->removedGapBreakingMatches = o.removed;
     out->nmatches = o.nmatches;
+    return SWSEM_OK;
+}
+
+// ---- the decoder's automaton on the device (swsem_decode.hip)
+static int decode_jobs(swsem_t *h, const swsem_emit_params_t *p, int n, const std::vector<DecodeJob> &jobs, std::vector<DecodeOut> &outs) {
+    int r;
+    if ((r = h->dJobs.reserve(n)) || (r = h->dDecOut.reserve(n))) return r;
+    HIPCHK(hipMemcpyAsync(h->dJobs.p, jobs.data(), (size_t) n * sizeof(DecodeJob), hipMemcpyHostToDevice, h->stream));
+    k_decode_contigs<<<dim3(n), dim3(WAVE), 0, h->stream>>>(h->ref, *p, h->dJobs.p, h->dDecOut.p);
+    HIPCHK(hipGetLastError());
+    outs.resize(n);
+    HIPCHK(hipMemcpyAsync(outs.data(), h->dDecOut.p, (size_t) n * sizeof(DecodeOut), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SWSEM_OK;
+}
+
+int swsem_decode_contigs_dev(swsem_t *h, const swsem_emit_params_t *p, int n, const swsem_decode_job_t *jobs, uint64_t *destLen, int64_t *unmatched) {
+    HIPCHK(hipSetDevice(h->device));
+    if (n <= 0) return SWSEM_OK;
+    std::vector<DecodeJob> jb(n);
+    for (int k = 0; k < n; k++) {
+        for (int st = 0; st < SWSEM_NSTREAMS; st++) { jb[k].stream[st] = jobs[k].stream_dev[st]; jb[k].size[st] = jobs[k].size[st]; }
+        jb[k].refLockPos = jobs[k].refLockPos; jb[k].dest = jobs[k].dest_dev; jb[k].destCap = jobs[k].destCap; jb[k].expect = nullptr;
+    }
+    std::vector<DecodeOut> outs;
+    int r = decode_jobs(h, p, n, jb, outs);
+    if (r) return r;
+    for (int k = 0; k < n; k++) { destLen[k] = outs[k].destLen; unmatched[k] = outs[k].unmatched; }
+    return SWSEM_OK;
+}
+
+int swsem_emit_verify(swsem_t *h, int *nbad, int *firstBad, uint64_t *firstDiff) {
+    HIPCHK(hipSetDevice(h->device));
+    swsem::EmitSlot &E = h->sel();
+    { int e = end_slot(h, (int) (&E - h->slot)); if (e) return e; }
+    const int n = (int) E.eout.size();
+    *nbad = 0; if (firstBad) *firstBad = -1; if (firstDiff) *firstDiff = UINT64_MAX;
+    if (n == 0) return SWSEM_OK;
+    uint64_t total = 0;
+    for (int k = 0; k < n; k++) total += E.ecg[k].n + 16;
+    int r;
+    if ((r = h->dDecode.reserve(total))) return r;
+    std::vector<DecodeJob> jb;
+    std::vector<int> which;
+    uint64_t at = 0;
+    for (int k = 0; k < n; k++) {
+        if (E.eout[k].unmatchedChars == UINT64_MAX) { at += E.ecg[k].n + 16; continue; }   // given up as dissimilar: nothing was emitted
+        DecodeJob j;
+        for (int st = 0; st < SWSEM_NSTREAMS; st++) { j.stream[st] = E.dEArena.p + E.hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st]; j.size[st] = E.eout[k].size[st]; }
+        j.refLockPos = E.ecg[k].lock; j.dest = h->dDecode.p + at; j.destCap = E.ecg[k].n; j.expect = E.qdev + E.ecg[k].qoff;
+        at += E.ecg[k].n + 16;
+        jb.push_back(j); which.push_back(k);
+    }
+    if (jb.empty()) return SWSEM_OK;
+    std::vector<DecodeOut> outs;
+    if ((r = decode_jobs(h, &E.params, (int) jb.size(), jb, outs))) return r;
+    for (size_t i = 0; i < jb.size(); i++) {
+        const int k = which[i];
+        const bool ok = outs[i].unmatched >= 0 && outs[i].destLen == E.ecg[k].n && outs[i].firstDiff == UINT64_MAX &&
+                        (uint32_t) outs[i].unmatched == (uint32_t) E.eout[k].unmatchedChars;
+        if (!ok) {
+            if (*nbad == 0) { if (firstBad) *firstBad = k; if (firstDiff) *firstDiff = outs[i].unmatched < 0 ? outs[i].destLen : outs[i].firstDiff; }
+            (*nbad)++;
+        }
+    }
     return SWSEM_OK;
 }
 
