@@ -374,7 +374,7 @@ def main():
         _b.lib().swsem_debug_block_times.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
         _b.lib().swsem_debug_block_times(m.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), 200000, C.byref(nb))
         t = buf[: 3 * nb.value].reshape(-1, 3).astype(np.float64)
-        print("resolve blocks %d: ticks mean %.0f max %.0f (100 MHz), visits %d (mean %.0f/block), rows %d" %
+        print("resolve blocks %d: ticks mean %.0f max %.0f (shader clock), visits %d (mean %.0f/block), rows %d" %
               (nb.value, t[:, 0].mean(), t[:, 0].max(), t[:, 1].sum(), t[:, 1].mean(), t[:, 2].sum()), file=sys.stderr)
         if hasattr(_b.lib(), "swsem_debug_phases"):       # diagnostics build (-DSWSEM_DIAG_PHASES) only
             ph = np.zeros(8, dtype=np.uint64)

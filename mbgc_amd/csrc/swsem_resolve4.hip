@@ -22,6 +22,10 @@ namespace swk {
 
 constexpr int GL = 16;                 // lanes of a chain
 constexpr int GC = WAVE / GL;          // chains per wave
+#ifndef SWSEM_WIN4
+#define SWSEM_WIN4 16
+#endif
+constexpr int WN4 = SWSEM_WIN4;          // positions looked up per window (<= GL)
 constexpr int RING4 = 16;              // newest rows of a chain's stack mirrored in LDS
 constexpr int LEFT4 = 64;              // bytes left of the candidate covered by a visit's first load
 constexpr int LL4 = LEFT4 / 16;        // lanes holding them
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
         // One iteration: the chains that have left their window look the next 16 positions up (doR), then every chain
         // with a candidate at or after its scan position visits it (doV) — the chains that just looked up included.
         if (SWSEM_SYNC_SPAN && __ballot(phase != 2 && scan - start0 < syncRel) == 0) syncRel += SWSEM_SYNC_SPAN;
-        const bool doR = phase != 2 && (scan < wb || scan >= wb + GL) && (!SWSEM_SYNC_SPAN || scan - start0 < syncRel);
+        const bool doR = phase != 2 && (scan < wb || scan >= wb + WN4) && (!SWSEM_SYNC_SPAN || scan - start0 < syncRel);
 
         // ---- doR, issue: K-mer hashes of the window (run_chain_lazy's refill), then the table gather
         int32_t cnt = 0;
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
         ht_entry hte = 0;
         if (doR) {
             wb = scan;
-            cnt = p1 - wb < GL ? p1 - wb : GL;
+            cnt = p1 - wb < WN4 ? p1 - wb : WN4;
             const int nw = K / 4;
             uint32_t h = (uint32_t) K;
             // the window's bytes: from the chain's query cache in LDS (the 256 bytes around the last visit, or the last
@@ -261,9 +265,9 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
 
         // ---- first candidate at or after the scan position; a window without one is left behind
         uint32_t mk = 0;
-        if (phase != 2 && scan >= wb && scan < wb + GL) {              // (a chain waiting for the others stands outside its window)
+        if (phase != 2 && scan >= wb && scan < wb + WN4) {              // (a chain waiting for the others stands outside its window)
             mk = m16 & (0xFFFFu << (uint32_t) (scan - wb)) & 0xFFFFu;
-            if (!mk) scan = wb + GL < p1 ? wb + GL : p1;
+            if (!mk) scan = wb + WN4 < p1 ? wb + WN4 : p1;
         }
         const bool doV = mk != 0;
 
