@@ -439,6 +439,7 @@ def main():
         if world > 1:
             out["rccl_ranks_seen"] = dist.get_world_size()
             out["extension_allgathers_started_ahead"] = {"started": runner.pregathers[0], "used": runner.pregathers[1]}
+            out["round_finalizes_queued_on_device_verdicts"] = {"tried": runner.spec_rounds[0], "applied": runner.spec_rounds[1]}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit, max_ref)
         print(json.dumps(out), flush=True)

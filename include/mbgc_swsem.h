@@ -167,6 +167,19 @@ typedef struct {
     uint64_t *loadedAfter;
     const uint8_t *predExt, *predRC;                            /* [n emitted contigs] predicted decisions */
     int factor, rcFactor;                                       /* unmatchedFractionFactor, unmatchedFractionRCFactor */
+    /* Several replicas (one handle per GPU, the round's targets sharded over them): the finalize covers the targets of
+     * ALL replicas, so it may only run when EVERY replica's pass 1 confirms its part of the prediction. gate_dev: the
+     * device word (1 = confirmed) the check writes and the gated launches read — caller's memory, valid until they have
+     * run (NULL = the handle's own). exchange(ctx, 0, gate_dev, stream) is called once, after the check has been queued
+     * on `stream` (a hipStream_t) and before any gated launch: it queues, on that stream, the reduction of the word to
+     * its minimum over the replicas in place (ncclAllReduce / its torch.distributed form) and whatever else the gated
+     * launches must wait for (the all-gather that delivers ext_dev); non-zero return = error. exchange(ctx, 1, …) is
+     * called later, if the finalize could be queued, and returns the reduced word (it may block until it is known).
+     * veto: this replica cannot take part (its share of ext_dev is not what was predicted): its word is 0. */
+    uint32_t *gate_dev;
+    int (*exchange)(void *ctx, int phase, void *gate_dev, void *stream);
+    void *exchange_ctx;
+    int veto;
 } swsem_spec_finalize_t;
 int swsem_emit_batch_begin_spec(swsem_t *h, const swsem_emit_params_t *p, int n, const int *contigIdx, const uint64_t *lockPos,
                                 const int *unmatchedFractionFactor, const int64_t *processedTargetsCount, const int64_t *targetIdx,

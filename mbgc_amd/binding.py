@@ -28,7 +28,11 @@ swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_
 class SpecFinalize(C.Structure):
     _fields_ = [("ntargets", C.c_int), ("ext_dev", C.c_void_p), ("ext_len", C.POINTER(C.c_uint64)), ("addSep", C.c_int), ("sep", C.c_int),
                 ("lazySeparator", C.c_int), ("lockPos", C.POINTER(C.c_uint64)), ("loadedAfter", C.POINTER(C.c_uint64)),
-                ("predExt", C.c_void_p), ("predRC", C.c_void_p), ("factor", C.c_int), ("rcFactor", C.c_int)]
+                ("predExt", C.c_void_p), ("predRC", C.c_void_p), ("factor", C.c_int), ("rcFactor", C.c_int),
+                ("gate_dev", C.c_void_p), ("exchange", C.c_void_p), ("exchange_ctx", C.c_void_p), ("veto", C.c_int)]
+
+
+SPEC_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
 
 
 class SwsemError(RuntimeError):
@@ -278,9 +282,13 @@ class SlidingWindowSparseEMMatcher:
     def emit_batch_end(self): _chk(lib().swsem_emit_batch_end(self.h))
 
     def emit_batch_begin_spec(self, params, locks, factors, processed, target_idx, loaded, n, ext_ptrs, ext_lens, target_locks,
-                              pred_ext, pred_rc, factor, rc_factor, lazy=True, add_sep=True, sep=0):
+                              pred_ext, pred_rc, factor, rc_factor, lazy=True, add_sep=True, sep=0, gate=0, reduce=None,
+                              verdict=None, veto=False):
         """emit_batch_begin plus a speculative finalize of the round's targets (see include/mbgc_swsem.h). Returns
-        (applied, loaded_after): applied False means nothing was done and finalize_targets is still to be called."""
+        (applied, loaded_after): applied False means nothing was done and finalize_targets is still to be called.
+        Several replicas: gate = device address of the int32 word the check writes, reduce(stream) queues its reduction
+        (minimum over the replicas) on the handle's stream, verdict() returns the reduced word, veto = this replica's
+        word is 0 whatever its pass 1 finds."""
         u64, P = np.uint64, C.POINTER(C.c_uint64)
         lk, fa = np.ascontiguousarray(locks, dtype=u64), np.ascontiguousarray(factors, dtype=np.int32)
         pr, ti = np.ascontiguousarray(processed, dtype=np.int64), np.ascontiguousarray(target_idx, dtype=np.int64)
@@ -293,10 +301,26 @@ class SlidingWindowSparseEMMatcher:
         pe, prc = np.ascontiguousarray(pred_ext, dtype=np.uint8), np.ascontiguousarray(pred_rc, dtype=np.uint8)
         sp = SpecFinalize(nt, C.cast(ptrs, C.c_void_p), lens.ctypes.data_as(P), int(add_sep), sep, int(lazy), tl.ctypes.data_as(P),
                           after.ctypes.data_as(P), pe.ctypes.data_as(C.c_void_p), prc.ctypes.data_as(C.c_void_p), int(factor), int(rc_factor))
+        failure = []
+        if reduce is not None:
+            def _cb(ctx, phase, gate_dev, stream):
+                try:
+                    if phase == 0:
+                        reduce(stream)
+                        return 0
+                    return int(verdict())
+                except BaseException as e:           # (an exception cannot cross the C frames)
+                    failure.append(e)
+                    return -1
+            cb = SPEC_EXCHANGE(_cb)
+            sp.gate_dev, sp.exchange, sp.veto = int(gate), C.cast(cb, C.c_void_p), int(veto)
         applied = C.c_int()
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        _chk(lib().swsem_emit_batch_begin_spec(self.h, C.byref(params), n, None, vp(lk), vp(fa), vp(pr), vp(ti), vp(ld), ld.size,
-                                               C.byref(sp), C.byref(applied)))
+        rc = lib().swsem_emit_batch_begin_spec(self.h, C.byref(params), n, None, vp(lk), vp(fa), vp(pr), vp(ti), vp(ld), ld.size,
+                                               C.byref(sp), C.byref(applied))
+        if failure:
+            raise failure[0]
+        _chk(rc)
         return bool(applied.value), after
     def emit_select(self, previous): _chk(lib().swsem_emit_select(self.h, int(previous)))
 

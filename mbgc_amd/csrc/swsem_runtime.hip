@@ -1286,10 +1286,14 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     if (spec && spec->ntargets > 0) {
         snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch; snap.eCur = h->eCur; snap.ePrev = h->ePrev; snap.sepEndPos = h->sepEndPos; snap.sepEndLaps = h->sepEndLaps; snap.sepEndVal = h->sepEndVal;
         snap.pristine = h->pristine; snap.locks = h->locks;
-        k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, h->dGate.p);
+        uint32_t *gate = spec->gate_dev ? spec->gate_dev : h->dGate.p;
+        k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, gate);
+        if (spec->veto) HIPCHK(hipMemsetAsync(gate, 0, sizeof(uint32_t), h->stream));
+        // several replicas: the word becomes the minimum over all of them before anything gated by it is queued
+        if (spec->exchange && spec->exchange(spec->exchange_ctx, 0, gate, (void *) h->stream)) return fail(SWSEM_EHIP, "speculative finalize: the exchange between the replicas failed");
         h->specMode = true;
         r = finalize_impl(h, spec->ntargets, spec->ext_dev, spec->ext_len, spec->addSep, spec->sep, spec->lazySeparator, spec->lockPos,
-                          spec->loadedAfter, h->dGate.p);
+                          spec->loadedAfter, gate);
         h->specMode = false;
         if (r == SWSEM_ESPEC) r = SWSEM_OK;                         // not possible this time: nothing was queued
         else if (r) return r;
@@ -1301,12 +1305,13 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     if (needCounts) take_counts(h);
     E.eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
     if (queued) {
-        bool ok = true;                                             // the same test k_spec_verify makes
+        bool ok = !spec->veto;                                      // the same test k_spec_verify makes
         for (int k = 0; k < n && ok; k++) {
             const uint64_t un = E.eout[k].unmatchedChars, len = E.ecg[k].n;
             ok = un != UINT64_MAX && (un * (uint64_t) spec->factor > len) == (spec->predExt[k] != 0) &&
                  (un * (uint64_t) spec->rcFactor > len) == (spec->predRC[k] != 0);
         }
+        if (spec->exchange) ok = spec->exchange(spec->exchange_ctx, 1, nullptr, (void *) h->stream) == 1 && ok;   // ... and every other replica's
         if (ok) { if (applied) *applied = 1; }
         else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
                h->pristine = snap.pristine; h->locks = snap.locks; }

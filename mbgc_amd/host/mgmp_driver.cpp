@@ -397,7 +397,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
         std::vector<const uint8_t *> extDev(T, nullptr);
         std::vector<uint64_t> extLen(T, 0), loadedAfter(T, 0);
         std::vector<uint8_t> predExt(ncont, predicted == 1), predRC(ncont, 0);
-        swsem_spec_finalize_t spec;
+        swsem_spec_finalize_t spec = {};
         const bool useSpec = predicted >= 0;
         if (useSpec) {
             if (predicted == 1)

@@ -10,6 +10,7 @@ the all-gather of the extension bytes and the gather of the emitted stream bytes
 feeds the (unchanged, host-side) PPMd/LZMA backend: RCCL over xGMI on GPUs, gloo in the CPU tests.
 
 PyTorch is plumbing only: device buffers, the process group and the collectives."""
+import contextlib
 import os
 
 import numpy as np
@@ -75,9 +76,11 @@ class RoundRunner:
         self._pre = None                             # extension all-gather started ahead under that prediction (see _pregather)
         self.pregathers = [0, 0]                     # started / used (diagnostics)
         self._gathers = []                           # stream gathers still running (work, output, input)
-        self._next_announce = -1                     # bytes of the next round's query buffer (run_round's next_batch), -1: unknown
-        self._next_key = None
-        self._next_sizes = None                      # every rank's announcement, once exchanged (rides on a round's length exchange)
+        self._next_key = None                        # the buffer this rank announced for the next round (see _post_announce)
+        self._ann = None                             # the announcement exchange in flight
+        self._ctl = None                             # its stream
+        self._gate = self._gate_host = self._gate_ev = None     # the speculative finalize's word, several ranks (see _world_speculation)
+        self.spec_rounds = [0, 0]                    # several ranks: speculative finalizes tried / applied (diagnostics)
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -115,17 +118,65 @@ class RoundRunner:
         parts = self._allgather_bytes(t.view(torch.uint8))
         return [p.view(torch.int64).tolist() for p in parts]
 
-    def _pregather(self, qbuf, offsets, targets, T):
+    def _side(self):
+        """the stream of the small exchanges that must not wait for what the main stream has queued"""
+        if self.device.type != "cuda":
+            return contextlib.nullcontext()
+        if self._ctl is None:
+            self._ctl = torch.cuda.Stream(self.device)
+        return torch.cuda.stream(self._ctl)
+
+    def _post_announce(self, next_batch, T):
+        """Several ranks: what this rank's NEXT round looks like — bytes of its query buffer, bytes of every target —
+        travels now, on a stream of its own, so that nothing at the top of the next round has to wait for an exchange:
+        its extension all-gather and its speculative finalize are set up from these numbers. Every rank takes part in
+        every round (-1 = nothing to say); next_batch = (buffer, offsets[, target of every contig])."""
+        self._next_key = None
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        vals = [-1] * (2 + T)
+        if next_batch is not None:
+            nb, no = next_batch[0], next_batch[1]
+            nt = list(next_batch[2]) if len(next_batch) > 2 and next_batch[2] is not None else list(range(len(no) - 1))
+            if int(no[0]) == 0 and int(no[-1]) == nb.numel() and all(nt[c] <= nt[c + 1] for c in range(len(nt) - 1)):
+                vals[0], self._next_key = int(nb.numel()), (nb.data_ptr(), nb.numel())
+                tn = max(nt) + 1 if nt else 0
+                if tn <= T:
+                    lens = [0] * tn
+                    for c, t in enumerate(nt):
+                        lens[t] += int(no[c + 1]) - int(no[c])
+                    vals[1], vals[2: 2 + tn] = tn, lens
+        with self._side():
+            t = torch.tensor(vals, dtype=torch.int64, device=self.device)
+            out = torch.empty(self.world * len(vals), dtype=torch.int64, device=self.device)
+            work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+        self._ann = (work, out, t, len(vals))
+
+    def _take_announce(self):
+        """-> per rank (bytes of its buffer or -1, bytes per target or None) as announced for the round that starts now"""
+        a, self._ann = self._ann, None
+        if a is None:
+            return None
+        work, out, _, k = a
+        with self._side():
+            work.wait()
+            flat = out.tolist()
+        return [(flat[r * k], flat[r * k + 2: r * k + 2 + flat[r * k + 1]] if flat[r * k + 1] >= 0 else None)
+                for r in range(self.world)]
+
+    def _pregather(self, qbuf, offsets, targets, T, ann):
         """Several ranks: in a collection nearly every target ends up loaded into the reference whole, so the bytes the
         round's all-gather will carry are known before the round starts — they are the queries. When the last round went
         that way on every rank (a fact all ranks hold, so all of them decide alike), the all-gather is started here,
         asynchronously, and runs beside match-finding instead of after it; _finalize_range uses its result if this
         round's decisions come out the same on every rank, and falls back to the ordinary exchange otherwise."""
         self._pre = None
-        announced, self._next_sizes = self._next_sizes, None           # (valid for this round only)
+        announced = [a[0] for a in ann] if ann is not None and min(a[0] for a in ann) >= 0 else None
         if self.world == 1 or not self._gpred or self.p is None or os.environ.get("MBGC_ROUNDS_PREGATHER", "1") == "0":
             return
         ncont = len(offsets) - 1
+        lens = None
         usable = not (int(offsets[0]) != 0 or int(offsets[-1]) != qbuf.numel() or
                       any(targets[c] > targets[c + 1] for c in range(ncont - 1)))
         import torch.distributed as dist
@@ -136,6 +187,14 @@ class RoundRunner:
             # collective — the others will — and says so in the length exchange, which sends everybody down the ordinary path.
             sizes = announced
             poisoned = not usable or self._next_key != (qbuf.data_ptr(), qbuf.numel()) or qbuf.numel() != sizes[self.rank]
+            # every rank's bytes per target, if all of them named T targets that add up to their buffers: what the
+            # speculative finalize of the round needs (_world_speculation)
+            if all(a[1] is not None and len(a[1]) == T and sum(a[1]) == a[0] for a in ann):
+                lens = [a[1] for a in ann]
+                mine = [0] * T
+                for c, t in enumerate(targets):
+                    mine[t] += int(offsets[c + 1]) - int(offsets[c])
+                poisoned = poisoned or mine != lens[self.rank]
         else:
             # (whether this rank's buffer has the expected layout is local knowledge: it travels with the sizes, so that
             # every rank enters the big collective or none does)
@@ -146,6 +205,8 @@ class RoundRunner:
             if min(sizes) < 0:
                 return
         mx = max(max(sizes), 1)
+        if announced is None:
+            lens = None
         if qbuf.numel() == mx and not poisoned:
             pad = qbuf
         else:
@@ -154,7 +215,7 @@ class RoundRunner:
                 pad[: qbuf.numel()] = qbuf
         out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
         work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
-        self._pre = dict(work=work, out=out, pad=pad, mx=mx, sizes=sizes, poisoned=poisoned)
+        self._pre = dict(work=work, out=out, pad=pad, mx=mx, sizes=sizes, poisoned=poisoned, lens=lens)
         self.pregathers[0] += 1
 
     # ---- one round ----------------------------------------------------------------------------
@@ -172,12 +233,8 @@ class RoundRunner:
         ntot = T * self.world
         first = self.targets_done                   # global index of the round's first target
         locks = [m.acquire_lock() for _ in range(ntot)]                     # MGMP.cpp:353-358
-        self._pregather(qbuf, offsets, targets, T)
-        self._next_announce, self._next_key = -1, None
-        if next_batch is not None and self.world > 1:
-            nb, no = next_batch
-            if int(no[0]) == 0 and int(no[-1]) == nb.numel():
-                self._next_announce, self._next_key = int(nb.numel()), (nb.data_ptr(), nb.numel())
+        self._pregather(qbuf, offsets, targets, T, self._take_announce())
+        self._post_announce(next_batch, T)
         lock_of = [locks[self.rank * T + targets[c]] for c in range(ncont)]
         pending = list(range(ncont))                # contigs still to be matched + emitted
         counts = np.zeros(ncont, dtype=np.uint64)
@@ -187,6 +244,7 @@ class RoundRunner:
         emitted_here = False                        # an emission of THIS round has been begun (the deferred one is then "previous")
         ext_done = {}
         first_pass = True                           # rank-invariant: every rank is in its first pass over the whole round
+        spec_applied = False
         while True:
             if pending:
                 self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
@@ -195,7 +253,24 @@ class RoundRunner:
                 if self.p is not None:
                     tgt = [first + self.rank * T + targets[c] for c in pending]
                     spec = self._speculation(qbuf, offsets, targets, T, pending, finalized, ncont)
-                    if spec is not None:
+                    wspec = self._world_speculation(T) if first_pass else None
+                    if wspec is not None:
+                        # several ranks: the finalize of ALL the round's targets, read from the extension all-gather that
+                        # was started ahead, is queued behind pass 1 on every rank and runs iff every rank's pass 1 finds
+                        # what was predicted — the ranks' verdicts are reduced on the stream, no host in between
+                        before = m.loaded_ref_length()
+                        self.spec_rounds[0] += 1
+                        spec_applied, after = m.emit_batch_begin_spec(
+                            self.p, [lock_of[c] for c in pending], [self.policy.factor] * ncont, [self.targets_done] * ncont, tgt,
+                            self.loaded, ncont, wspec[0], wspec[1], locks, [True] * ncont, [False] * ncont,
+                            self.policy.factor, self.policy.rc_factor, self.lazy, gate=self._gate.data_ptr(),
+                            reduce=self._reduce_gate, verdict=self._gate_verdict, veto=self._pre["poisoned"])
+                        if spec_applied:
+                            self.spec_rounds[1] += 1
+                            self.pregathers[1] += 1
+                            self._keep.append(self._pre["out"])
+                            self._pre = None
+                    elif spec is not None:
                         # the round's finalize is queued behind pass 1 under the prediction "every contig decides as the
                         # last round's did"; the library applies it only if that is what pass 1 finds
                         before = m.loaded_ref_length()
@@ -226,7 +301,9 @@ class RoundRunner:
             # "discard, wait until the earlier targets are loaded, retry")
             first_skip_local = min([self.rank * T + targets[c] for c in skipped_local], default=ntot)
             merged = None
-            if self.world > 1 and first_pass:
+            if self.world > 1 and first_pass and spec_applied:
+                first_skip = ntot                   # every rank's pass 1 came out as predicted: there is nothing to tell
+            elif self.world > 1 and first_pass:
                 # first pass over the whole round: the skip index travels together with what this rank would load if
                 # nobody skips (one exchange instead of two on the path between pass 1 and the round's finalize)
                 if skipped_local:
@@ -234,10 +311,10 @@ class RoundRunner:
                 else:
                     pieces, whole = self._build_pieces(qbuf, offsets, targets, T, unmatched, 0, ntot)
                 got = self._allgather_ints([first_skip_local] + ([x[1] for x in pieces] if pieces is not None else [0] * T) +
-                                           [self._next_announce, 1 if whole else 0], fixed=True)
+                                           [1 if whole else 0], fixed=True)
                 first_skip = min(v[0] for v in got)
                 if first_skip == ntot:
-                    merged = (pieces, [v[1: 1 + T] for v in got], [v[-2] for v in got], [v[-1] for v in got])
+                    merged = (pieces, [v[1: 1 + T] for v in got], [v[-1] for v in got])
             elif self.world > 1:
                 first_skip = min(x[0] for x in self._allgather_ints([first_skip_local], fixed=True))
             else:
@@ -385,7 +462,7 @@ class RoundRunner:
         if hi <= lo:
             return
         if merged is not None:
-            pieces, all_lens, nxt, flags = merged
+            pieces, all_lens, flags = merged
         else:
             pieces, whole = self._build_pieces(qbuf, offsets, targets, T, unmatched, lo, hi)
         # finalize_targets returns with its copies queued: their sources must outlive this function
@@ -395,13 +472,11 @@ class RoundRunner:
             return
         whole_round = lo == 0 and hi == T * self.world                                     # then: T targets on every rank
         if merged is None:
-            got = self._allgather_ints([x[1] for x in pieces] + [self._next_announce if whole_round else -1, 1 if whole else 0, -1],
+            got = self._allgather_ints([x[1] for x in pieces] + [1 if whole else 0, -1],
                                        fixed=whole_round)                                  # (-1 keeps the tensor non-empty)
             flags = [l[-2] for l in got]
-            nxt = [l[-3] for l in got]
-            all_lens = [l[:-3] for l in got]
+            all_lens = [l[:-2] for l in got]
         pre, self._pre = self._pre, None
-        self._next_sizes = nxt if whole_round and min(nxt) >= 0 else None
         self._gpred = all(flags) and whole_round
         if pre is not None:
             pre["work"].wait()                       # (always: the collective was entered by every rank)
@@ -447,6 +522,49 @@ class RoundRunner:
             for t, (s, e) in span.items():
                 ptrs[t], lens[t] = (base + s, e - s) if e > s else (0, 0)
         return ptrs, lens
+
+    def _world_speculation(self, T):
+        """Several ranks: (ext pointers, ext lengths) of all the round's targets, rank-major, inside the output of the
+        extension all-gather started ahead (_pregather) — under the prediction that made it start: every target of
+        every rank is loaded whole, without reverse complement. None when the round cannot carry a speculative finalize;
+        the conditions are facts every rank holds, so that all of them enter the verdict's reduction or none does (a
+        rank whose own buffer is not what it announced takes part with a veto)."""
+        pre = self._pre
+        if self.world == 1 or pre is None or pre["lens"] is None or not hasattr(self.m, "emit_batch_begin_spec"):
+            return None
+        if self._gate is None:
+            self._gate = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._gate_host = torch.zeros(1, dtype=torch.int32)
+            if self.device.type == "cuda":
+                self._gate_host = self._gate_host.pin_memory()
+        ptrs, lens, base = [], [], pre["out"].data_ptr()
+        for r in range(self.world):
+            cur = base + r * pre["mx"]
+            for ln in pre["lens"][r]:
+                ptrs.append(cur if ln else 0)
+                lens.append(ln)
+                cur += ln
+        return ptrs, lens
+
+    def _reduce_gate(self, stream):
+        """called by the library between the device-side check of this rank's prediction and the launches it gates:
+        they must see every rank's verdict, and the bytes they copy — both are made to precede them on the stream"""
+        import torch.distributed as dist
+        cuda = self.device.type == "cuda"
+        on = (torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device))
+              if cuda and stream and stream != torch.cuda.current_stream(self.device).cuda_stream else contextlib.nullcontext())
+        with on:
+            self._pre["work"].wait()
+            dist.all_reduce(self._gate, op=dist.ReduceOp.MIN, group=self.group)
+            self._gate_host.copy_(self._gate, non_blocking=True)
+            if cuda:
+                self._gate_ev = torch.cuda.Event()
+                self._gate_ev.record()
+
+    def _gate_verdict(self):
+        if self._gate_ev is not None:
+            self._gate_ev.synchronize()
+        return int(self._gate_host[0])
 
     def _learn(self, offsets, unmatched, skipped):
         """prediction for the next round: what every contig of this one decided, if they all decided alike"""

@@ -73,6 +73,24 @@ class OracleDeviceMatcher:
     def emit_batch_begin(self, *a, **k):
         return self.emit_batch(*a, **k)
 
+    def emit_batch_begin_spec(self, params, locks, factors, processed, target_idx, loaded, n, ext_ptrs, ext_lens, target_locks,
+                              pred_ext, pred_rc, factor, rc_factor, lazy=True, add_sep=True, sep=0, gate=0, reduce=None,
+                              verdict=None, veto=False):
+        """the speculative finalize's contract (include/mbgc_swsem.h): emission, this replica's verdict on the prediction,
+        the reduction over the replicas, then the finalize of all targets or nothing"""
+        self.emit_batch(params, None, locks, factors, processed, target_idx, loaded, n)
+        ok = not veto
+        for k in range(n):
+            un, ln = int(self._em[k][0]), len(self._contigs[k])
+            ok = ok and un != _orc.SKIPPED and (un * factor > ln) == bool(pred_ext[k]) and (un * rc_factor > ln) == bool(pred_rc[k])
+        if reduce is not None:
+            np.ctypeslib.as_array(C.cast(int(gate), C.POINTER(C.c_int32)), shape=(1,))[0] = int(ok)
+            reduce(None)
+            ok = verdict() == 1 and ok
+        if not ok:
+            return False, np.zeros(len(ext_lens), dtype=np.uint64)
+        return True, self.finalize_targets(ext_ptrs, ext_lens, target_locks, lazy, add_sep, sep)
+
     def emit_batch_end(self):
         pass
 

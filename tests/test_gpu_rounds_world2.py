@@ -22,7 +22,7 @@ def collection(n, length, div, seed):
     return [synth.genome(base, i, div) for i in range(n)]
 
 
-def _worker(rank, world, port, outdir, div, n):
+def _worker(rank, world, port, outdir, div, n, announce):
     import torch
     import torch.distributed as dist
     from mbgc_amd import binding
@@ -35,16 +35,23 @@ def _worker(rank, world, port, outdir, div, n):
     h.load_ref(gs[0], load_rc=True)
     runner = RoundRunner(h, rank, world, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1))
     runner.start()
+    rounds = []
     for rnd in round_schedule(len(gs) - 1, 2, world):
         mine = [gs[1 + t] for t in rnd[rank]]
         buf = torch.from_numpy(np.concatenate(mine)).to("cuda:0")
         offs = np.zeros(len(mine) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum([c.size for c in mine])
-        torch.cuda.synchronize()
-        runner.run_round(buf, offs)
+        rounds.append((buf, offs))
+    torch.cuda.synchronize()
+    for i, (buf, offs) in enumerate(rounds):
+        # with `announce` every round names the next one's buffer: the ranks then know each other's sizes ahead, the
+        # extension all-gather starts at the top of the round and the round's finalize is queued behind pass 1, gated
+        # by the reduction of the ranks' device-side verdicts (RoundRunner._world_speculation)
+        runner.run_round(buf, offs, next_batch=rounds[i + 1] if announce and i + 1 < len(rounds) else None)
     runner.flush()
     np.save(os.path.join(outdir, "ht%d.npy" % rank), h.ht())
     open(os.path.join(outdir, "pregathers%d" % rank), "w").write("%d %d" % tuple(runner.pregathers))
+    open(os.path.join(outdir, "spec%d" % rank), "w").write("%d %d" % tuple(runner.spec_rounds))
     if rank == 0:
         for k, v in runner.streams.items():
             open(os.path.join(outdir, k), "wb").write(bytes(v))
@@ -55,13 +62,13 @@ def _worker(rank, world, port, outdir, div, n):
     h.close()
 
 
-@pytest.mark.parametrize("div,n", [(0.002, 13), (0.012, 9)])
-def test_two_replicas_on_one_gpu_equal_the_reference_loop(tmp_path, div, n):
+@pytest.mark.parametrize("div,n,announce", [(0.002, 13, 0), (0.012, 9, 0), (0.002, 13, 1), (0.012, 13, 1)])
+def test_two_replicas_on_one_gpu_equal_the_reference_loop(tmp_path, div, n, announce):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path), div, n), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), div, n, announce), nprocs=2, join=True)
     gs = collection(n, 80_000, div, seed=23)
     o = _orc.OracleMatcher(LIM)
     res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], 4)
@@ -75,4 +82,8 @@ def test_two_replicas_on_one_gpu_equal_the_reference_loop(tmp_path, div, n):
     assert pg[0] == pg[1]
     if div < 0.005:
         assert int(pg[0].split()[1]) >= 1, pg          # the extension all-gather started ahead of a round was used
+    sp = [(tmp_path / ("spec%d" % r)).read_text() for r in range(2)]
+    assert sp[0] == sp[1]
+    if announce and div < 0.005:
+        assert int(sp[0].split()[1]) >= 1, sp          # ... and a whole round's finalize ran on the two ranks' device-side verdicts
     o.close()

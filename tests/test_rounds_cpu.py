@@ -62,7 +62,7 @@ def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None, announce
         offs[1:] = np.cumsum([c.size for c in contigs])
         rounds.append((buf, offs, tg))
     for i, (buf, offs, tg) in enumerate(rounds):
-        nxt = (rounds[i + 1][0], rounds[i + 1][1]) if announce and i + 1 < len(rounds) else None
+        nxt = rounds[i + 1] if announce and i + 1 < len(rounds) else None
         if announce == 2 and rank == 1 and i > 0:
             buf = buf.clone()                           # not the buffer named in the round before
         runner.run_round(buf, offs, tg, next_batch=nxt)
@@ -89,6 +89,7 @@ def _worker(rank, world, port, outdir, div, cpt, announce=0, n=9):
     runner, m = run_rank(rank, world, gs, 2, cpt, announce=announce)
     np.save(os.path.join(outdir, "ht%d.npy" % rank), m.ht())
     open(os.path.join(outdir, "pregathers%d" % rank), "w").write("%d %d" % tuple(runner.pregathers))
+    open(os.path.join(outdir, "spec%d" % rank), "w").write("%d %d" % tuple(runner.spec_rounds))
     if rank == 0:
         for k, v in runner.streams.items():
             open(os.path.join(outdir, k), "wb").write(bytes(v))
@@ -124,9 +125,10 @@ def test_world_size_2_gloo(tmp_path, div, cpt):
 
 @pytest.mark.parametrize("announce", [1, 2])
 def test_world_size_2_gloo_with_announced_buffers(tmp_path, announce):
-    """the next round's buffer is named ahead (next_batch): its size rides on the round's length exchange and the
-    extension all-gather starts without an exchange of its own; a rank that then passes another buffer makes all ranks
-    fall back — same bytes either way"""
+    """the next round's buffer is named ahead (next_batch): its size and its targets' sizes travel during the round
+    before, the extension all-gather starts without an exchange of its own and the round's finalize is queued behind
+    pass 1 on every rank, gated by the reduction of the ranks' verdicts; a rank that then passes another buffer makes all
+    ranks fall back — same bytes either way"""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -143,8 +145,13 @@ def test_world_size_2_gloo_with_announced_buffers(tmp_path, announce):
     pg = [(tmp_path / ("pregathers%d" % r)).read_text() for r in range(2)]
     assert pg[0] == pg[1]
     started, used = (int(x) for x in pg[0].split())
+    sp = [(tmp_path / ("spec%d" % r)).read_text() for r in range(2)]
+    assert sp[0] == sp[1]
     if announce == 1:
         assert (started, used) == (3, 3)               # rounds 2..4 of 4
+        # ... each of them with the whole round's finalize queued behind pass 1 and applied on both ranks' say-so
+        assert sp[0] == "3 3", sp
     else:
+        assert sp[0] == "2 0", sp                      # tried with rank 1's veto: applied on neither rank
         # round 2: started, found poisoned, everybody falls back — and nobody predicts for round 3; round 4: the same again
         assert (started, used) == (2, 0)
