@@ -198,6 +198,10 @@ int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out);
 void swsem_emit_set_host_copy(swsem_t *h, int on);
 int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched /* [n of the last swsem_emit_batch] */);
 int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total);
+/* the counters processMatches adds up (MBGC_Encoder.cpp:293-306), per contig of the selected emission, without its bytes:
+ * unmatchedChars, extensionsMatchedChars, extensionsMismatches, totalMatched, removedGapBreakingMatches, matches. Waits
+ * for the emission like swsem_emit_result. */
+int swsem_emit_counters(swsem_t *h, uint64_t *out /* [n * 6] */);
 
 /* ---- the decoder's per-contig automaton on the device: the exact inverse of processMatches,
  * MBGC_Decoder::decodeSequenceAndReturnUnmatchedChars + extendMatchLeft/Right (mbgccoder/MBGC_Decoder.cpp:319-523), one

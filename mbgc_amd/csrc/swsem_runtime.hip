@@ -1380,6 +1380,17 @@ int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *si
     return SWSEM_OK;
 }
 
+int swsem_emit_counters(swsem_t *h, uint64_t *out) {
+    swsem::EmitSlot &E = h->sel();
+    { int e = end_slot(h, (int) (&E - h->slot)); if (e) return e; }
+    for (size_t k = 0; k < E.eout.size(); k++) {
+        const EmitOut &o = E.eout[k];
+        const uint64_t v[6] = {o.unmatchedChars, o.extMatched, o.extMismatches, o.totalMatched, o.removed, o.nmatches};
+        memcpy(out + k * 6, v, sizeof v);
+    }
+    return SWSEM_OK;
+}
+
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
     swsem::EmitSlot &E = h->sel();
     { int e = end_slot(h, (int) (&E - h->slot)); if (e) return e; }

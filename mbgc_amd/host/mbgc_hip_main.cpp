@@ -4,6 +4,11 @@
 // stream order of MBGC_Decoder.cpp:1085-1112): literals(13) locksPos(14) gapDelta(15) flags(16)
 // mapOff(17) mapLen(18) refExtSize(19). Entropy coding (PPMd/LZMA) is the unchanged host backend of the
 // reference and is not part of this tool.
+//
+// --gpus N: one process per GPU, forked here BEFORE anything touches a GPU; a round then holds -R targets per GPU, the
+// replicas exchange the round's reference extensions and their verdicts over RCCL (include/mbgc_exchange.h) and rank 0
+// takes the streams and writes them. Results equal -R (N x R) on one GPU. --exchange hostmem puts every rank on device
+// -d and moves the bytes through host shared memory: a rehearsal of the protocol on a one-GPU box, not a speed.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -12,7 +17,31 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <thread>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "mgmp_driver.h"
+
+// what the ranks share before their exchange exists: the RCCL ids rank 0 makes, then (host-memory transport) its mapping
+struct Bootstrap {
+    std::atomic<uint32_t> idsReady, failed;
+    uint32_t pad[14];
+    uint8_t ids[2 * MBGC_XCHG_ID_BYTES];
+};
+// A rank that gives up (the reference's way: message + exit(EXIT_FAILURE)) must not leave the others waiting inside a
+// collective: it raises the flag on its way out, the others watch it.
+static Bootstrap *g_boot = nullptr;
+static std::atomic<bool> g_done{false};
+static void raiseFailure() { if (g_boot && !g_done.load()) g_boot->failed.store(1); }
+static void watchOtherRanks() {
+    std::thread([] {
+        while (!g_boot->failed.load()) usleep(50000);
+        if (!g_done.load()) { fprintf(stderr, "mbgc-hip: another rank failed\n"); _exit(EXIT_FAILURE); }
+    }).detach();
+}
 
 static void dump(const std::string &prefix, const char *name, const std::string &data) {
     std::ofstream f(prefix + "." + name, std::ios::binary | std::ios::trunc);
@@ -22,6 +51,9 @@ static void dump(const std::string &prefix, const char *name, const std::string 
 int main(int argc, char **argv) {
     MBGC_Params params;
     std::vector<std::string> pos;
+    int gpus = 1;
+    std::string transport = "rccl";
+    size_t shmMb = 64;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "c") continue;
@@ -33,10 +65,18 @@ int main(int argc, char **argv) {
         else if (a == "-U") params.uppercaseDNA = true;                          // MBGC_Params.h: converts bases to uppercase
         else if (a == "--bench") params.benchMode = true;                        // rounds timed with every contig resident in HBM (no streams written)
         else if (a == "--warmup" && i + 1 < argc) params.benchWarmup = atoi(argv[++i]);
+        else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (a == "--exchange" && i + 1 < argc) transport = argv[++i];
+        else if (a == "--shm-mb" && i + 1 < argc) shmMb = (size_t) atol(argv[++i]);
         else pos.push_back(a);
     }
     if (pos.size() != 2) {
-        fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--bench [--warmup rounds]] <sequencesListFile> <outputPrefix>\n");
+        fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--bench [--warmup rounds]] "
+                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] <sequencesListFile> <outputPrefix>\n");
+        return EXIT_FAILURE;
+    }
+    if (gpus < 1 || (transport != "rccl" && transport != "hostmem") || (gpus > 1 && params.sequentialMatching)) {
+        fprintf(stderr, "--gpus needs a positive count, --exchange rccl or hostmem, and the round mode (not -t1 / -m 3: those match sequentially)\n");
         return EXIT_FAILURE;
     }
     std::vector<std::string> files;
@@ -49,15 +89,65 @@ int main(int argc, char **argv) {
             if (!line.empty()) files.push_back(line);
         }
     }
+    // ---- the ranks: forked before the first GPU call; the parent is rank 0 and reports for all
+    int rank = 0;
+    std::vector<pid_t> children;
+    Bootstrap *boot = nullptr;
+    size_t sharedBytes = 0;
+    const bool explicitExchange = gpus > 1 || transport == "hostmem";
+    if (explicitExchange || getenv("MBGC_HIP_EXCHANGE")) {
+        sharedBytes = sizeof(Bootstrap) + (transport == "hostmem" ? std::max<size_t>(shmMb << 20, mbgc_xchg_hostmem_min_bytes(gpus)) : 0);
+        void *m = mmap(nullptr, sharedBytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);      // (zero-filled)
+        if (m == MAP_FAILED) { perror("mmap"); return EXIT_FAILURE; }
+        boot = g_boot = (Bootstrap *) m;
+        atexit(raiseFailure);
+        fflush(stdout); fflush(stderr);
+        for (int r = 1; r < gpus; r++) {
+            const pid_t pid = fork();
+            if (pid < 0) { perror("fork"); return EXIT_FAILURE; }
+            if (pid == 0) { rank = r; children.clear(); break; }
+            children.push_back(pid);
+        }
+        watchOtherRanks();
+        if (transport == "rccl") {
+            params.device = rank;                                                // one rank per GPU
+            if (rank == 0) {
+                if (mbgc_xchg_unique_ids(boot->ids)) { fprintf(stderr, "exchange: %s\n", mbgc_xchg_last_error()); return EXIT_FAILURE; }
+                boot->idsReady.store(1);
+            } else {
+                while (!boot->idsReady.load() && !boot->failed.load()) usleep(1000);
+            }
+            if (mbgc_xchg_create_rccl(&params.exchange, boot->ids, rank, gpus, params.device)) {
+                fprintf(stderr, "exchange (rank %d): %s\n", rank, mbgc_xchg_last_error());
+                return EXIT_FAILURE;
+            }
+        } else if (mbgc_xchg_create_hostmem(&params.exchange, (uint8_t *) m + sizeof(Bootstrap), sharedBytes - sizeof(Bootstrap), rank, gpus, params.device)) {
+            fprintf(stderr, "exchange (rank %d): %s\n", rank, mbgc_xchg_last_error());
+            return EXIT_FAILURE;
+        }
+    }
+    auto finish = [&](int rc) {
+        g_done.store(rc == 0);
+        if (params.exchange) { mbgc_xchg_destroy(params.exchange); params.exchange = nullptr; }
+        if (rank != 0) { fflush(stdout); fflush(stderr); _exit(rc); }
+        for (pid_t pid : children) {
+            int st = 0;
+            if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : EXIT_FAILURE;
+        }
+        return rc;
+    };
     MBGC_Encoder enc(&params);
     enc.encode(files);
+    if (rank != 0) return finish(0);
     if (params.benchMode) {
         // the C++ host's own measurement of the hot path (BASELINE.json metric): inputs resident in HBM, rounds of -R targets
         printf("{\"metric\": \"input Gbases/s (compress hot path, C++ host)\", \"value\": %.4f, \"unit\": \"Gbases/s\", \"rounds\": %d, "
-               "\"warmup_rounds\": %d, \"targets_per_round\": %d, \"bases\": %llu, \"seconds\": %.6f, \"ms_per_round\": %.4f}\n",
-               params.benchBases / params.benchSeconds / 1e9, params.benchRounds, params.benchWarmup, params.roundSize,
-               (unsigned long long) params.benchBases, params.benchSeconds, params.benchSeconds * 1e3 / std::max(1, params.benchRounds));
-        return 0;
+               "\"warmup_rounds\": %d, \"targets_per_round\": %d, \"bases\": %llu, \"seconds\": %.6f, \"ms_per_round\": %.4f, "
+               "\"n_gpus\": %d, \"exchange\": \"%s\", \"rounds_finalized_on_device_verdicts\": %d}\n",
+               params.benchBases / params.benchSeconds / 1e9, params.benchRounds, params.benchWarmup, params.roundSize * gpus,
+               (unsigned long long) params.benchBases, params.benchSeconds, params.benchSeconds * 1e3 / std::max(1, params.benchRounds),
+               gpus, params.exchange ? transport.c_str() : "none", params.specRounds);
+        return finish(0);
     }
     dump(pos[1], "literals", enc.literals);
     if (params.rcRedundancyRemoval) { dump(pos[1], "rcMapOff", enc.rcMapOff); dump(pos[1], "rcMapLen", enc.rcMapLen); }
@@ -73,5 +163,6 @@ int main(int argc, char **argv) {
     printf("swsMEM unmatched chars: %zu\n", enc.unmatchedChars());
     printf("extensions matched chars: %zu\n", enc.extensionsMatchedCharsAll);
     printf("final unmatched chars: %zu\n", enc.unmatchedChars() - enc.extensionsMatchedCharsAll);
-    return 0;
+    if (params.exchange) printf("rounds finalized on the ranks' device-side verdicts: %d\n", params.specRounds);
+    return finish(0);
 }

@@ -106,6 +106,10 @@ void MultipleGenomeMatchingProcessor::readG0(const std::string &path, std::vecto
 void MultipleGenomeMatchingProcessor::loadRound(uint32_t f0, uint32_t f1, RoundBatch &B) {
     openInputStage();
     const int nf = (int) (f1 - f0);
+    if (nf <= 0) {                                           // (a rank without targets in a short last round)
+        B.offsets.assign(1, 0); B.targetOf.clear(); B.bytes = 0;
+        return;
+    }
     rawFiles.clear();
     std::vector<uint64_t> fileOff(1, 0);
     for (uint32_t f = f0; f < f1; f++) {
@@ -486,6 +490,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
 
 void MultipleGenomeMatchingProcessor::performMatching() {
     if (params->sequentialMatching) processTargetsWithParallelIO();
+    else if (targetsCount && params->exchange) processTargetsRoundsSharded();
     else if (targetsCount) processTargetsRounds();
     else {
         fprintf(stderr, "Error selecting processing mode (no targets for parallel matching?)!\n");
@@ -601,6 +606,6 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
     if (params->lazyDecompressionSupport) refExtLoadedPosArr.emplace_back(matcher->getLoadingPosition());   // ENC.cpp:789-791
     performMatching();
     // prepareAndCompressStreams' first step on this path, ENC.cpp:636-638: the reverse-complement pass over the literals
-    if (params->rcRedundancyRemoval && !params->benchMode)
+    if (params->rcRedundancyRemoval && !params->benchMode && (!params->exchange || mbgc_xchg_rank(params->exchange) == 0))
         PgTools::SimpleSequenceMatcher::rcMatchSequence(literals, rcMapOff, rcMapLen, params->rcMatchMinLength, UINT32_MAX, device);
 }

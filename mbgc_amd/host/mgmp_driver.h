@@ -13,6 +13,7 @@
 
 #include "sw_matcher.h"
 #include "../../include/mbgc_fasta.h"
+#include "../../include/mbgc_exchange.h"
 
 struct MGMP_Params {                                   // matching/MGMP_Params.h (only what this path reads)
     int k = 32, k1 = 16, k2 = 1;                       // :199-202
@@ -34,6 +35,9 @@ struct MGMP_Params {                                   // matching/MGMP_Params.h
     bool benchMode = false;
     int benchWarmup = 0;
     double benchSeconds = 0; uint64_t benchBases = 0; int benchRounds = 0;   // filled by processTargetsRounds
+    // several GPUs: this process is one rank of `exchange`; a round then holds roundSize targets PER RANK
+    mbgc_xchg_t *exchange = nullptr;
+    int specRounds = 0;                                // rounds whose finalize ran on the ranks' device-side verdicts (diagnostics)
     static const uint64_t MIN_BASIC_BLOCK_SIZE = 1 << 21;                 // :48
     static const uint64_t REFERENCE_LENGTH_LIMIT = (uint64_t) UINT32_MAX << 8;   // :55
     bool isContigProperForRefExtension(uint64_t len, uint64_t unmatched, int f) const { return unmatched * f > len; }      // :179-186
@@ -83,6 +87,7 @@ protected:
     void processTargetsWithParallelIO();                                                // :232-313  (-t1)
     void processTargetsRounds();                                                        // :340-468 as deterministic rounds
     void processRoundWithRetries(RoundBatch &B);                                        // a round holding a dissimilar contig (:382-388), blocking calls
+    void processTargetsRoundsSharded();                                                 // the rounds with their targets sharded over the ranks of params->exchange (mgmp_sharded.cpp)
     // input stage (MGMP.cpp:7-35,349-372 on the device parser)
     mbgc_fasta_t *fasta = nullptr;
     std::string rawFiles;

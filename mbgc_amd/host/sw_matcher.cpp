@@ -144,6 +144,18 @@ void SlidingWindowSparseEMMatcher::emitTake(int k, EmittedStreams &out) {
     take(st, out);
 }
 
+uint64_t SlidingWindowSparseEMMatcher::emitPack(uint8_t *dstDev, uint64_t cap, std::vector<uint64_t> *sizes, int n) {
+    uint64_t total = 0;
+    if (sizes) sizes->assign((size_t) n * SWSEM_NSTREAMS, 0);
+    check(swsem_emit_pack_dev(h, dstDev, cap, sizes ? sizes->data() : nullptr, &total), "processMatches");
+    return total;
+}
+
+void SlidingWindowSparseEMMatcher::emitCounters(std::vector<uint64_t> &out, int n) {
+    out.assign((size_t) n * 6, 0);
+    check(swsem_emit_counters(h, out.data()), "processMatches");
+}
+
 void SlidingWindowSparseEMMatcher::emitEnd() { check(swsem_emit_batch_end(h), "processMatches"); }
 
 void SlidingWindowSparseEMMatcher::finalizeTargets(const std::vector<const uint8_t *> &extDev, const std::vector<uint64_t> &extLen,

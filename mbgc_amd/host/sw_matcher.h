@@ -85,6 +85,10 @@ public:
     void setEmitHostCopy(bool on);                                          // off: the streams stay in HBM until emitTake asks for them
     void emitSelect(bool previous);
     void emitTake(int k, EmittedStreams &out);                              // streams of contig k of the selected emission (waits for it)
+    // the selected emission as one packed device blob ((contig, stream) major; sizes[n*6]) and its counters without the bytes
+    // (n*6: unmatchedChars, extensionsMatchedChars, extensionsMismatches, totalMatched, removedGapBreakingMatches, matches)
+    uint64_t emitPack(uint8_t *dstDev, uint64_t cap, std::vector<uint64_t> *sizes, int n);
+    void emitCounters(std::vector<uint64_t> &out, int n);
     void emitEnd();
     void finalizeTargets(const std::vector<const uint8_t *> &extDev, const std::vector<uint64_t> &extLen, bool addSep, char sep,
                          bool lazySeparator, const std::vector<uint64_t> &lockPos, std::vector<uint64_t> &loadedAfter);

@@ -31,6 +31,22 @@ def test_library_exports_every_declared_symbol():
     assert set(binding.EXPORTS) <= set(syms) and set(fasta.EXPORTS) <= set(syms) and set(copmem.EXPORTS) <= set(syms)
 
 
+def test_exchange_library_exports_every_declared_symbol():
+    """include/mbgc_exchange.h (the C++ host's exchange between the GPUs of a node) against libmbgc_xchg.so"""
+    import __graft_entry__ as g
+    g.build()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mbgc_exchange.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mbgc_xchg_[A-Za-z0-9_]+)\s*\(", src)))
+    assert len(syms) >= 14, syms
+    lib = ctypes.CDLL(os.path.join(ROOT, "mbgc_amd", "libmbgc_xchg.so"))
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    lib.mbgc_xchg_hostmem_min_bytes.restype = ctypes.c_uint64
+    assert lib.mbgc_xchg_hostmem_min_bytes(2) >= 64
+    x = ctypes.c_void_p()
+    assert lib.mbgc_xchg_create_hostmem(ctypes.byref(x), None, 0, 0, 2, 0) != 0          # no mapping: refused before any device call
+
+
 def test_no_device_means_loud_failure_not_fallback():
     from mbgc_amd import binding
     L = binding.lib()

@@ -1,0 +1,86 @@
+"""`mbgc-hip c --gpus N`: the C++ host with a round's targets sharded over N ranks (mbgc_amd/host/mgmp_sharded.cpp) and the
+exchange of include/mbgc_exchange.h between them. The test box has one GPU, so the ranks share it and the bytes move
+through host shared memory (`--exchange hostmem`: same calls, same order, same bytes as RCCL, which refuses two ranks on
+one device); RCCL itself runs here with one rank. N ranks x R targets must equal one GPU with rounds of N x R — which
+test_gpu_cli.py pins on the oracle-driven reference loop — byte for byte, in every stream."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from mbgc_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "mbgc_amd", "mbgc-hip")
+STREAMS = ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags", "locksPos", "refExtSize")
+
+
+def run_tool(args, cwd, env=None):
+    r = subprocess.run(["timeout", "-k", "10", "280", TOOL] + args, cwd=cwd, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    return r.stdout
+
+
+def split(g, k):
+    cuts = [0] + [g.size * i // k + (7 * i) % 13 for i in range(1, k)] + [g.size]
+    return [g[cuts[i]:cuts[i + 1]] for i in range(k)]
+
+
+def write_collection(tmp_path, n, length, div, contigs=2, seed=61):
+    base = synth.base_codes(length, seed)
+    paths = []
+    for i in range(n):
+        p = tmp_path / ("g%02d.fa" % i)
+        with open(p, "wb") as f:
+            for j, c in enumerate(split(synth.genome(base, i, div), (1, 2, 3)[i % 3] if contigs == "ragged" else contigs)):
+                f.write(synth.fasta_bytes(c, i * 10 + j))
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+
+
+def dumps(tmp_path, prefix):
+    return {k: (tmp_path / (prefix + "." + k)).read_bytes() for k in STREAMS}
+
+
+# 0.3 %: every contig extends the reference, none with its reverse complement (from the third round on the round's finalize runs on the ranks' device-side
+# verdicts); 1.5 %: with reverse complements; 0.1 %: none does; 6 %: contigs are given up as dissimilar and the round is redone from there on every rank;
+# 11 / 12 files: the last round is short (a rank without targets) / full
+@pytest.mark.parametrize("gpus,r,n,div,contigs", [(2, 2, 17, 0.003, 2), (2, 2, 11, 0.015, "ragged"), (2, 2, 12, 0.06, 2), (2, 3, 11, 0.001, 1),
+                                                  (3, 1, 12, 0.015, "ragged"), (3, 2, 15, 0.06, "ragged")])
+def test_ranks_on_one_gpu_equal_the_single_gpu_rounds(tmp_path, gpus, r, n, div, contigs):
+    write_collection(tmp_path, n, 70_000, div, contigs)
+    one = run_tool(["c", "-R", str(gpus * r), "list.txt", "one"], str(tmp_path))
+    many = run_tool(["c", "--gpus", str(gpus), "--exchange", "hostmem", "--shm-mb", "1", "-R", str(r), "list.txt", "many"], str(tmp_path))
+    a, b = dumps(tmp_path, "one"), dumps(tmp_path, "many")
+    for k in STREAMS:
+        assert a[k] == b[k], k
+    for line in ("exact matches total", "removed matches breaking gaps total", "swsMEM unmatched chars", "final unmatched chars"):
+        assert [x for x in one.splitlines() if x.startswith(line)] == [x for x in many.splitlines() if x.startswith(line)], line
+    spec = int([x for x in many.splitlines() if x.startswith("rounds finalized on the ranks' device-side verdicts")][0].split(":")[1])
+    if div == 0.003:
+        assert spec >= 2, many                              # 4 rounds of 2 x 2: the third and the fourth
+    if div == 0.06:
+        assert spec == 0
+
+
+def test_rccl_with_one_rank_equals_the_plain_loop(tmp_path):
+    """the RCCL transport on the hardware at hand: one rank — communicators, the two collectives' streams, the on-stream
+    reduction inside the speculative finalize, the gather — against the loop without an exchange"""
+    write_collection(tmp_path, 13, 70_000, 0.003, 2)
+    run_tool(["c", "-R", "3", "list.txt", "one"], str(tmp_path))
+    out = run_tool(["c", "--gpus", "1", "-R", "3", "list.txt", "x"], str(tmp_path), env={"MBGC_HIP_EXCHANGE": "1"})
+    a, b = dumps(tmp_path, "one"), dumps(tmp_path, "x")
+    for k in STREAMS:
+        assert a[k] == b[k], k
+    assert "rounds finalized on the ranks' device-side verdicts: 3" in out or "verdicts: 2" in out, out
+
+
+def test_bench_mode_with_ranks(tmp_path):
+    write_collection(tmp_path, 17, 300_000, 0.003, 1)
+    out = run_tool(["c", "--bench", "--warmup", "1", "--gpus", "2", "--exchange", "hostmem", "-R", "2", "list.txt", "x"], str(tmp_path))
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["rounds"] == 3 and d["bases"] == 12 * 300_000 and d["value"] > 0
+    assert d["rounds_finalized_on_device_verdicts"] >= 1
