@@ -30,11 +30,17 @@ for lo in range(0, n + 1, 100):
 with open(os.path.join(d, "list.txt"), "w") as f:
     f.write("\n".join(paths) + "\n")
 print("wrote %d files in %.1f s" % (len(paths), time.time() - t0), file=sys.stderr)
-t0 = time.time()
-r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c", "--bench", "--warmup", str(warm), "-R", str(rnd),
-                    os.path.join(d, "list.txt"), os.path.join(d, "out")], capture_output=True, text=True)
-print("tool: %.1f s wall, rc %d" % (time.time() - t0, r.returncode), file=sys.stderr)
-sys.stderr.write(r.stderr[-2000:])
-print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "")
+rc = 0
+# the plain loop, then the same through the sharded loop's exchange with ONE rank over RCCL (communicators, the all-gather of
+# the round's extensions on the bulk stream, the on-stream reduction inside the speculative finalize): what the exchange
+# costs a rank before a second GPU is there
+for env in ({}, {"MBGC_HIP_EXCHANGE": "1"}):
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c", "--bench", "--warmup", str(warm), "-R", str(rnd),
+                        os.path.join(d, "list.txt"), os.path.join(d, "out")], capture_output=True, text=True, env=dict(os.environ, **env))
+    print("tool %s: %.1f s wall, rc %d" % (env, time.time() - t0, r.returncode), file=sys.stderr)
+    sys.stderr.write(r.stderr[-2000:])
+    print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "")
+    rc = rc or r.returncode
 subprocess.run(["rm", "-rf", d])
-sys.exit(r.returncode)
+sys.exit(rc)
