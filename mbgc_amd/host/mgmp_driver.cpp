@@ -7,6 +7,7 @@
 #include <cstring>
 #include <fstream>
 #include <time.h>
+#include <zlib.h>
 
 using PgTools::TextMatch;
 
@@ -44,6 +45,11 @@ static void writeUInt64Frugal(std::string &dest, uint64_t value) {
 // mgmpInOpen / whole-file read (MGMP.cpp:7-14; gz inflate is the host's libdeflate in the reference and is not part
 // of this repo) + kseq_read_lossless_fasta on the device (include/mbgc_fasta.h), status handling of
 // validate_kseq_status (MGMP.cpp:16-35).
+// mgmpInOpen (matching/input_with_libdeflate_wrapper.cpp:51-124): the whole file, and when it starts with the gzip magic,
+// its members inflated one after the other (the reference: libdeflate_gzip_decompress_ex in a loop until the input is
+// used up, output buffer sized by the ISIZE trailer and doubled when short; here: zlib on the host — DEFLATE's bit-serial
+// Huffman decoding has no place on the device, and a round's files inflate on the host while the GPU matches the round
+// before)
 static bool readWholeFile(const std::string &path, std::string &dest) {
     std::ifstream f(path, std::ios::binary | std::ios::ate);
     if (!f) return false;
@@ -52,7 +58,42 @@ static bool readWholeFile(const std::string &path, std::string &dest) {
     const size_t at = dest.size();
     dest.resize(at + (size_t) n);
     if (n) f.read(&dest[at], n);
-    return (bool) f;
+    if (!f) return false;
+    if (n < 18 || (uint8_t) dest[at] != 0x1f || (uint8_t) dest[at + 1] != 0x8b) return true;   // GZIP_ID1, GZIP_ID2
+    std::string gz(dest, at);
+    dest.resize(at);
+    uint32_t isize;
+    memcpy(&isize, gz.data() + gz.size() - 4, 4);
+    size_t cap = isize ? isize : gz.size() * 4, out = 0;
+    dest.resize(at + cap);
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 16 + MAX_WBITS) != Z_OK) { fprintf(stderr, "Cannot allocate decompressor.\n"); exit(EXIT_FAILURE); }
+    z.next_in = (Bytef *) gz.data();
+    size_t inLeft = gz.size();
+    while (true) {
+        z.avail_in = (uInt) std::min<size_t>(inLeft, 1u << 30);
+        const size_t inGiven = z.avail_in;
+        z.next_out = (Bytef *) &dest[at + out];
+        z.avail_out = (uInt) std::min<size_t>(cap - out, 1u << 30);
+        const size_t outGiven = z.avail_out;
+        const int res = inflate(&z, Z_NO_FLUSH);
+        inLeft -= inGiven - z.avail_in;
+        out += outGiven - z.avail_out;
+        if (res == Z_STREAM_END) {
+            if (inLeft == 0) break;
+            if (inflateReset(&z) != Z_OK) { fprintf(stderr, "Error decompressing gz file: %d.\n", res); exit(EXIT_FAILURE); }   // the next member
+        } else if (res == Z_OK || res == Z_BUF_ERROR) {
+            if (out == cap) { cap *= 2; dest.resize(at + cap); }
+            else if (inLeft == 0) { fprintf(stderr, "Error decompressing gz file: %d.\n", res); exit(EXIT_FAILURE); }            // truncated
+        } else {
+            fprintf(stderr, "Error decompressing gz file: %d.\n", res);
+            exit(EXIT_FAILURE);
+        }
+    }
+    inflateEnd(&z);
+    dest.resize(at + out);
+    return true;
 }
 
 static void validate_kseq_status(const std::string &fileName, int status) {

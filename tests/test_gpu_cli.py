@@ -69,6 +69,16 @@ def split(g, k):
     return [g[cuts[i]:cuts[i + 1]] for i in range(k)]
 
 
+def gzip_member(data):
+    import gzip
+    return gzip.compress(data, 6)
+
+
+def gzip_open_bytes(path):
+    import gzip
+    return gzip.open(path).read()
+
+
 def crlf(c):
     """the contig as kseq_read_lossless_fasta returns it from a CRLF file: the carriage returns stay (utils/kseq.h:233-274,
     ks_getuntil2 with loosy = false) — 80 bases, CR, 80 bases, CR ..."""
@@ -84,27 +94,33 @@ def crlf(c):
 
 
 # divergence 1.5 %: every contig extends the reference (the speculative finalize applies from the second round on);
-# 0.1 %: none does; 6 %: dissimilar contigs are given up and retried (the blocking path); "crlf": CRLF line ends
+# 0.1 %: none does; 6 %: dissimilar contigs are given up and retried (the blocking path); "crlf": CRLF line ends; "gz": gzip files
 @pytest.mark.parametrize("args,rs,div", [(["-t1"], 0, 0.015), (["-R", "3"], 3, 0.015), (["-R", "8"], 8, 0.015), (["-R", "2"], 2, 0.001),
-                                         (["-R", "3"], 3, 0.06), (["-R", "3"], 3, "crlf"), (["-t1"], 0, "crlf")])
+                                         (["-R", "3"], 3, 0.06), (["-R", "3"], 3, "crlf"), (["-t1"], 0, "crlf"), (["-R", "3"], 3, "gz"),
+                                         (["-t1"], 0, "gz")])
 def test_synthetic_files_equal_oracle_driver(tmp_path, args, rs, div):
     base = synth.base_codes(70_000, 55)
-    cr = div == "crlf"
-    gs = [synth.genome(base, i, 0.015 if cr else div) for i in range(8)]
+    cr, gz = div == "crlf", div == "gz"
+    gs = [synth.genome(base, i, 0.015 if cr or gz else div) for i in range(8)]
     files = [split(g, 2) for g in gs]
     paths = []
     for i, contigs in enumerate(files):
-        p = tmp_path / ("g%02d.fa" % i)
+        p = tmp_path / ("g%02d.fa%s" % (i, ".gz" if gz else ""))
         with open(p, "wb") as f:
             for j, c in enumerate(contigs):
                 data = synth.fasta_bytes(c, i * 10 + j)
-                f.write(data.replace(b"\n", b"\r\n") if cr else data)
+                data = data.replace(b"\n", b"\r\n") if cr else data
+                # gz: mgmpInOpen inflates what starts with the gzip magic, member after member (every record its own member
+                # in the odd files, one member per file in the even ones)
+                f.write(gzip_member(data) if gz and i % 2 else data)
+        if gz and i % 2 == 0:
+            p.write_bytes(gzip_member(p.read_bytes()))
         paths.append(str(p))
     if cr:
         files = [[crlf(c) for c in contigs] for contigs in files]
     (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
     run_tool(["c"] + args + ["list.txt", "out"], str(tmp_path))
-    fsize = os.path.getsize(paths[0])
+    fsize = len(gzip_open_bytes(paths[0])) if gz else os.path.getsize(paths[0])      # (the reference sizes by the inflated bytes, MGMP.cpp:109)
     if rs == 0:
         lim, _ = _driver.ref_length_limit(len(files), fsize)
         o = _orc.OracleMatcher(lim)
