@@ -1,0 +1,231 @@
+// The backend's job table and container framing (include/mbgc_backend.h). Host code: which
+// stream goes to which coder is policy, the coders are the reference's own behind a callback.
+#include "../../include/mbgc_backend.h"
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const char *fmt, ...) {
+    char buf[400];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+enum { LEVEL_FAST = 1, LEVEL_NORMAL = 2, LEVEL_MAX = 3 };                  // CodersLib.h:28-30
+enum { PERIOD_8 = 0, PERIOD_16 = 1, PERIOD_32 = 2 };                       // LZMA_DATAPERIODCODE_*, CodersLib.h:22-26
+
+// a coder as the job table names it: a leaf, the compound of two leaves, or either in parallel blocks
+struct Coder {
+    mbgc_leaf_coder_t leaf{};
+    bool compound = false;
+    mbgc_leaf_coder_t primary{};                       // compound: `leaf` is the secondary coder, run over primary's output
+    int blocks = 0;                                    // > 0: ParallelBlocksCoderProps(blocks, this coder)
+};
+
+mbgc_leaf_coder_t lzma(int level, int period, int threads) {               // getDefaulLzmaCoderProps, PropsLibrary.cpp:8-22
+    mbgc_leaf_coder_t c{};
+    c.coder = MBGC_LZMA_CODER;
+    c.lc = 3; c.lp = period; c.pb = period; c.algo = -1; c.numThreads = threads > 1 ? 2 : 1;
+    if (level == LEVEL_FAST) { c.level = 5; c.dictSize = 1u << 24; c.fb = 6; }
+    else { c.level = 9; c.dictSize = 3u << 29; c.fb = level == LEVEL_NORMAL ? 128 : 273; }
+    return c;
+}
+
+mbgc_leaf_coder_t ppmd(int level, int order) {                             // getDefaultPpmdCoderProps, PropsLibrary.cpp:24-36
+    mbgc_leaf_coder_t c{};
+    c.coder = MBGC_PPMD7_CODER;
+    if (level == LEVEL_FAST) { c.memSize = 16u << 20; c.order = 2; }
+    else { c.memSize = 192u << 20; c.order = level == LEVEL_NORMAL && order > 2 ? order / 2 + 1 : order; }
+    return c;
+}
+
+// MBGC_Encoder::prepareAndCompressStreams, MBGC_Encoder.cpp:641-710
+bool jobFor(const mbgc_backend_params_t &p, int st, Coder &c) {
+    const bool fast = p.coderMode == 0, repo = p.coderMode == 2, best = p.coderMode >= 3;
+    const int th = p.numberOfThreads;
+    const int level = best ? LEVEL_MAX : (fast ? LEVEL_FAST : LEVEL_NORMAL);                    // defaultCoderLevel, :689
+    c = Coder();
+    switch (st) {
+    case MBGC_ST_NAMES: c.leaf = ppmd(LEVEL_MAX, 6); return true;                              // :647-648
+    case MBGC_ST_SEQ_COUNTS: c.leaf = ppmd(LEVEL_MAX, 4); return true;                         // :649-650
+    case MBGC_ST_HEADER_TEMPLATES: c.leaf = lzma(LEVEL_NORMAL, PERIOD_8, th); return true;     // :651-652
+    case MBGC_ST_HEADERS:                                                                      // :653-660
+        if (p.ultraStreamsCompression) { c.compound = true; c.primary = lzma(LEVEL_NORMAL, PERIOD_8, th); c.leaf = ppmd(LEVEL_NORMAL, 3); }
+        else c.leaf = ppmd(LEVEL_MAX, fast ? 8 : 16);
+        c.blocks = best ? 1 : 2;
+        return true;
+    case MBGC_ST_DNA_LINE_LENGTHS: c.leaf = ppmd(LEVEL_MAX, 8); return true;                   // :661-662
+    case MBGC_ST_UNMATCHED_FRACTION_FACTORS: c.leaf = ppmd(LEVEL_MAX, 4); return true;         // :663-665
+    case MBGC_ST_LITERALS:                                                                     // :666-676
+        if (p.ultraStreamsCompression) c.leaf = lzma(LEVEL_MAX, PERIOD_8, th);
+        else if (fast || p.k == 16) c.leaf = lzma(LEVEL_FAST, PERIOD_8, th);
+        else c.leaf = ppmd(LEVEL_MAX, p.enableExtensionsWithMismatches ? (p.mismatchesWithExclusion ? 5 : 7) : (p.sequentialMatching ? 6 : 7));
+        c.blocks = best ? 1 : (fast ? 4 : (repo ? 3 : 2));
+        return true;
+    case MBGC_ST_RC_MAP_OFF: c.leaf = lzma(LEVEL_MAX, PERIOD_32, th); return p.rcRedundancyRemoval != 0;    // :677-682
+    case MBGC_ST_RC_MAP_LEN: c.leaf = lzma(LEVEL_MAX, PERIOD_8, th); return p.rcRedundancyRemoval != 0;
+    case MBGC_ST_LOCKS_POS: c.leaf = ppmd(LEVEL_MAX, 8); return true;                          // :683-684
+    case MBGC_ST_GAP_DELTAS:                                                                   // :685-689
+        c.leaf = ppmd(LEVEL_MAX, best ? 12 : (fast ? 2 : 8));
+        c.blocks = repo ? 4 : (best ? 1 : 2);
+        return true;
+    case MBGC_ST_GAP_MISMATCHES_FLAGS:                                                         // :690-696
+        c.leaf = ppmd(LEVEL_MAX, fast ? 8 : 14);
+        c.blocks = fast ? 3 : 2;
+        return p.enableExtensionsWithMismatches != 0;
+    case MBGC_ST_MAP_OFF:                                                                      // :697-700
+        c.leaf = lzma(level, PERIOD_32, th);
+        c.blocks = best ? 1 : (fast ? 4 : 3);
+        return true;
+    case MBGC_ST_MAP_OFF_5TH_BYTE: c.leaf = ppmd(LEVEL_MAX, 4); return p.refFinalTotalLength > UINT32_MAX;   // :701-703
+    case MBGC_ST_MAP_LEN:                                                                      // :704-708
+        c.leaf = lzma(level, p.frugal64bitLenEncoding ? PERIOD_16 : PERIOD_32, th);
+        c.blocks = best ? 2 : (fast ? 10 : (repo ? 3 : 5));
+        return true;
+    case MBGC_ST_REF_EXT_SIZE: c.leaf = ppmd(LEVEL_MAX, 6); return p.lazyDecompressionSupport != 0;          // :709-712
+    default: return false;
+    }
+}
+
+struct Sink {
+    std::string s;
+    template<typename T> void put(T v) { s.append((const char *) &v, sizeof v); }
+    void put(const uint8_t *p, size_t n) { s.append((const char *) p, n); }
+};
+
+struct Job { const uint8_t *src; size_t n; Coder coder; std::string packed; uint64_t compLen = 0; bool failed = false; };
+
+struct Ctx { mbgc_leaf_compress_fn leaf; void *ctx; };
+
+bool leafCompress(const Ctx &x, const mbgc_leaf_coder_t &c, const uint8_t *src, size_t n, std::string &out) {
+    out.resize(n + n / 3 + 256);
+    uint64_t len = 0;
+    if (x.leaf(x.ctx, &c, src, n, (uint8_t *) &out[0], out.size(), &len) != 0 || len > out.size()) return false;
+    out.resize(len);
+    return true;
+}
+
+bool compress(const Ctx &x, Job &j, bool inBlocks);
+
+// CompressionJob::writeCompressedCollectiveParallel, CodersLib.cpp:372-415: every job compressed (in parallel), then
+// header + payload per job in order; a job that does not shrink is stored raw
+bool collective(const Ctx &x, std::vector<Job> &jobs, Sink &out, int threads) {
+    std::atomic<size_t> next{0};
+    auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < jobs.size();) if (jobs[i].n) jobs[i].failed = !compress(x, jobs[i], false); };
+    const size_t nt = threads > 0 ? std::min<size_t>(threads, jobs.size()) : jobs.size();
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    for (Job &j : jobs) {
+        if (j.failed) return false;
+        if (j.n == 0) { out.put<uint64_t>(0); continue; }
+        const size_t destLen = j.packed.size();
+        // writeHeader, CodersLib.cpp:202-218
+        out.put<uint64_t>(j.n);
+        if (j.coder.compound && !j.coder.blocks) {
+            out.put<uint64_t>(destLen + 17);                                // + primaryCoder->getHeaderLen()
+            out.put<uint8_t>(MBGC_COMPOUND_CODER);
+            out.put<uint64_t>(j.compLen);
+            out.put<uint8_t>(j.compLen == j.n ? MBGC_NO_CODER : (uint8_t) j.coder.primary.coder);
+            out.put<uint64_t>(j.compLen);                                   // the secondary coder's own header over the primary's output
+            if (destLen >= j.compLen) { out.put<uint64_t>(j.compLen); out.put<uint8_t>(MBGC_NO_CODER); }
+            else { out.put<uint64_t>(destLen); out.put<uint8_t>((uint8_t) j.coder.leaf.coder); }
+        } else if (destLen >= j.n) {
+            out.put<uint64_t>(j.n); out.put<uint8_t>(MBGC_NO_CODER);
+        } else {
+            out.put<uint64_t>(destLen);
+            out.put<uint8_t>(j.coder.blocks ? (uint8_t) MBGC_PARALLEL_BLOCKS_CODER : (uint8_t) j.coder.leaf.coder);
+        }
+        if (destLen < j.n) out.put((const uint8_t *) j.packed.data(), destLen);
+        else out.put(j.src, j.n);
+        j.packed.clear(); j.packed.shrink_to_fit();
+    }
+    return true;
+}
+
+// Compress, CodersLib.cpp:53-132
+bool compress(const Ctx &x, Job &j, bool inBlocks) {
+    if (j.coder.blocks && !inBlocks) {
+        // parallelBlocksCompress, CodersLib.cpp:292-314 (+ ParallelBlocksCoderProps::prepare, CodersLib.h:163-171)
+        int nb = j.coder.blocks;
+        const int maxBlocks = (int) (j.n / (1u << 20));
+        if (nb > maxBlocks) nb = maxBlocks;
+        if (nb == 0) nb = 1;
+        const size_t blockSize = ((j.n / nb) / 16) * 16;
+        Coder inner = j.coder;
+        inner.blocks = 0;
+        std::vector<Job> blocks;
+        size_t off = 0;
+        for (int i = 0; i < nb - 1; i++) { blocks.push_back(Job{j.src + off, blockSize, inner}); off += blockSize; }
+        blocks.push_back(Job{j.src + off, j.n - off, inner});
+        Sink s;
+        s.put<int32_t>(nb);
+        if (!collective(x, blocks, s, 0)) return false;
+        j.packed = std::move(s.s);
+        return true;
+    }
+    if (j.coder.compound) {
+        std::string first;
+        if (!leafCompress(x, j.coder.primary, j.src, j.n, first)) return false;
+        if (first.size() >= j.n) first.assign((const char *) j.src, j.n);
+        j.compLen = first.size();
+        if (!leafCompress(x, j.coder.leaf, (const uint8_t *) first.data(), first.size(), j.packed)) return false;
+        if (j.packed.size() >= j.compLen) j.packed = std::move(first);
+        return true;
+    }
+    return leafCompress(x, j.coder.leaf, j.src, j.n, j.packed);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mbgc_backend_last_error(void) { return g_err.c_str(); }
+
+int mbgc_backend_job(const mbgc_backend_params_t *p, int st, int *blocks, mbgc_leaf_coder_t *coder, mbgc_leaf_coder_t *primary) {
+    Coder c;
+    if (!p || !jobFor(*p, st, c)) return -1;
+    if (blocks) *blocks = c.blocks;
+    if (coder) *coder = c.leaf;
+    if (primary) { *primary = c.primary; if (!c.compound) primary->coder = 0; }
+    return 0;
+}
+
+int mbgc_backend_compress_streams(const mbgc_backend_params_t *p, const uint8_t *const data[MBGC_ST_COUNT], const uint64_t size[MBGC_ST_COUNT],
+                                  mbgc_leaf_compress_fn leaf, void *ctx, int threads, uint8_t **out, uint64_t *outLen) {
+    if (!p || !data || !size || !leaf || !out || !outLen) return fail("mbgc_backend_compress_streams: null argument");
+    std::vector<Job> jobs;
+    for (int st = 0; st < MBGC_ST_COUNT; st++) {
+        Coder c;
+        if (!jobFor(*p, st, c)) continue;
+        if (size[st] && !data[st]) return fail("mbgc_backend_compress_streams: stream %d has a size and no bytes", st);
+        jobs.push_back(Job{data[st], (size_t) size[st], c});
+    }
+    Sink s;
+    const Ctx x{leaf, ctx};
+    if (!collective(x, jobs, s, threads)) return fail("Error during compression.");       // (the reference exits, CodersLib.cpp:103-108)
+    *out = (uint8_t *) malloc(s.s.size() ? s.s.size() : 1);
+    if (!*out) return fail("out of memory");
+    memcpy(*out, s.s.data(), s.s.size());
+    *outLen = s.s.size();
+    return 0;
+}
+
+void mbgc_backend_free(uint8_t *p) { free(p); }
+
+}  // extern "C"

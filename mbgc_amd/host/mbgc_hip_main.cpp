@@ -19,6 +19,8 @@
 
 #include <atomic>
 #include <thread>
+#include <dlfcn.h>
+#include <time.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -54,6 +56,8 @@ int main(int argc, char **argv) {
     int gpus = 1;
     std::string transport = "rccl";
     size_t shmMb = 64;
+    std::string backend;                                                        // a library with the reference's leaf coders (mbgc_leaf_compress)
+    int backendThreads = 8;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "c") continue;
@@ -68,11 +72,13 @@ int main(int argc, char **argv) {
         else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (a == "--exchange" && i + 1 < argc) transport = argv[++i];
         else if (a == "--shm-mb" && i + 1 < argc) shmMb = (size_t) atol(argv[++i]);
+        else if (a == "--backend" && i + 1 < argc) backend = argv[++i];
+        else if (a == "--backend-threads" && i + 1 < argc) backendThreads = atoi(argv[++i]);
         else pos.push_back(a);
     }
     if (pos.size() != 2) {
         fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--bench [--warmup rounds]] "
-                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] <sequencesListFile> <outputPrefix>\n");
+                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T]] <sequencesListFile> <outputPrefix>\n");
         return EXIT_FAILURE;
     }
     if (gpus < 1 || (transport != "rccl" && transport != "hostmem") || (gpus > 1 && params.sequentialMatching)) {
@@ -158,6 +164,22 @@ int main(int argc, char **argv) {
     dump(pos[1], "mapOff5th", enc.mapOff5thByte);
     dump(pos[1], "mapLen", enc.mapLen);
     dump(pos[1], "refExtSize", enc.refExtSizeStream);
+    if (!backend.empty()) {
+        // the streams through the backend's job table and container framing (include/mbgc_backend.h), entropy-coded by the
+        // library given: the reference's unchanged PPMd7 / LZMA (its symbol mbgc_leaf_compress has the callback's signature)
+        void *lib = dlopen(backend.c_str(), RTLD_NOW | RTLD_LOCAL);
+        mbgc_leaf_compress_fn leaf = lib ? (mbgc_leaf_compress_fn) dlsym(lib, "mbgc_leaf_compress") : nullptr;
+        if (!leaf) { fprintf(stderr, "cannot load the leaf coders from %s: %s\n", backend.c_str(), dlerror()); return finish(EXIT_FAILURE); }
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        const std::string section = enc.compressStreams(leaf, nullptr, backendThreads);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        dump(pos[1], "collective", section);
+        const size_t raw = enc.literals.size() + enc.rcMapOff.size() + enc.rcMapLen.size() + enc.locksPosStream.size() + enc.gapDeltas.size() +
+                           enc.gapMismatchesFlags.size() + enc.mapOff.size() + enc.mapOff5thByte.size() + enc.mapLen.size() + enc.refExtSizeStream.size();
+        printf("backend: %zu stream bytes to %zu in %.0f ms (%d threads)\n", raw, section.size(),
+               (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, backendThreads);
+    }
     printf("exact matches total: %zu\n", enc.exactMatches());
     printf("removed matches breaking gaps total: %zu\n", enc.removedGapBreakingMatchesAll);
     printf("swsMEM unmatched chars: %zu\n", enc.unmatchedChars());

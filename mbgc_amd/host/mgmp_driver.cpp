@@ -650,3 +650,32 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
     if (params->rcRedundancyRemoval && !params->benchMode && (!params->exchange || mbgc_xchg_rank(params->exchange) == 0))
         PgTools::SimpleSequenceMatcher::rcMatchSequence(literals, rcMapOff, rcMapLen, params->rcMatchMinLength, UINT32_MAX, device);
 }
+
+std::string MBGC_Encoder::compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads) {
+    mbgc_backend_params_t bp = {};
+    bp.coderMode = params->coderMode; bp.k = params->k;
+    bp.enableExtensionsWithMismatches = params->emit.enableExtensionsWithMismatches;
+    bp.mismatchesWithExclusion = params->emit.mismatchesWithExclusion;
+    bp.sequentialMatching = params->sequentialMatching; bp.rcRedundancyRemoval = params->rcRedundancyRemoval;
+    bp.frugal64bitLenEncoding = params->emit.frugal64bitLenEncoding; bp.lazyDecompressionSupport = params->lazyDecompressionSupport;
+    bp.refFinalTotalLength = refFinalTotalLength; bp.numberOfThreads = threads;
+    const std::string factors((const char *) unmatchedFractionFactors.data(), unmatchedFractionFactors.size());
+    const std::string *src[MBGC_ST_COUNT] = {};
+    src[MBGC_ST_UNMATCHED_FRACTION_FACTORS] = &factors; src[MBGC_ST_LITERALS] = &literals; src[MBGC_ST_RC_MAP_OFF] = &rcMapOff;
+    src[MBGC_ST_RC_MAP_LEN] = &rcMapLen; src[MBGC_ST_LOCKS_POS] = &locksPosStream; src[MBGC_ST_GAP_DELTAS] = &gapDeltas;
+    src[MBGC_ST_GAP_MISMATCHES_FLAGS] = &gapMismatchesFlags; src[MBGC_ST_MAP_OFF] = &mapOff; src[MBGC_ST_MAP_OFF_5TH_BYTE] = &mapOff5thByte;
+    src[MBGC_ST_MAP_LEN] = &mapLen; src[MBGC_ST_REF_EXT_SIZE] = &refExtSizeStream;
+    const uint8_t *data[MBGC_ST_COUNT] = {};
+    uint64_t size[MBGC_ST_COUNT] = {};
+    for (int st = 0; st < MBGC_ST_COUNT; st++)
+        if (src[st]) { data[st] = (const uint8_t *) src[st]->data(); size[st] = src[st]->size(); }
+    uint8_t *out = nullptr;
+    uint64_t n = 0;
+    if (mbgc_backend_compress_streams(&bp, data, size, leaf, ctx, threads, &out, &n) != 0) {
+        fprintf(stderr, "%s\n", mbgc_backend_last_error());
+        exit(EXIT_FAILURE);
+    }
+    std::string res((const char *) out, n);
+    mbgc_backend_free(out);
+    return res;
+}

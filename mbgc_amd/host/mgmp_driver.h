@@ -2,8 +2,9 @@
 //   MultipleGenomeMatchingProcessor  matching/MultipleGenomeMatchingProcessor.{h,cpp}  (file list, G0
 //       reference, matcher sizing, the two target loops, in-order reference extension)
 //   MBGC_Encoder                     mbgccoder/MBGC_Encoder.{h,cpp}:128-564,759-807      (the hooks
-//       that collect the match/literal byte streams; the PPMd/LZMA backend is NOT part of this repo:
-//       the collected streams are what the reference hands to prepareAndCompressStreams, :615-732)
+//       that collect the match/literal byte streams, and prepareAndCompressStreams' job table + container framing
+//       (:641-710, include/mbgc_backend.h) around the PPMd/LZMA coders, which are NOT part of this repo: they are the
+//       reference's unchanged backend, handed in as a callback)
 // Policy (which contigs extend the reference, dissimilar-contig retry, lock bookkeeping) stays on the
 // host exactly as in the reference; everything that touches sequence bytes runs through the C ABI.
 #pragma once
@@ -14,6 +15,7 @@
 #include "sw_matcher.h"
 #include "../../include/mbgc_fasta.h"
 #include "../../include/mbgc_exchange.h"
+#include "../../include/mbgc_backend.h"
 
 struct MGMP_Params {                                   // matching/MGMP_Params.h (only what this path reads)
     int k = 32, k1 = 16, k2 = 1;                       // :199-202
@@ -148,6 +150,10 @@ public:
 
     explicit MBGC_Encoder(MBGC_Params *p) : MultipleGenomeMatchingProcessor(p), params(p) { device = p->device; }
     void encode(const std::vector<std::string> &files);                                 // :759-807 up to performMatching()
+    // prepareAndCompressStreams' collective section (:641-710) for the streams this path produces — the file-name / header /
+    // line-length streams belong to the part of the tool that is not rebuilt here and go in empty (eight zero bytes each) —
+    // with the caller's leaf coders; what CompressionJob::writeCompressedCollectiveParallel would write for them
+    std::string compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads);
     size_t exactMatches() const { return resCount; }
     size_t unmatchedChars() const { return unmatchedCharsAll; }
 };

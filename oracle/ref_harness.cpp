@@ -39,6 +39,9 @@
 #include "mbgccoder/MBGC_Encoder.h"
 #include "matching/SimpleSequenceMatcher.h"
 #include "matching/copmem/CopMEMMatcher.h"
+#include "coders/LzmaCoder.h"
+#include "coders/PpmdCoder.h"
+#include "coders/PropsLibrary.h"
 #undef private
 #undef protected
 
@@ -190,6 +193,91 @@ uint64_t refrc_find_matches(const char *seq, uint64_t n, uint32_t targetMatchLen
     m.matchTexts(res, q, true, true, minMatchLength == UINT32_MAX ? targetMatchLength : minMatchLength);
     for (size_t i = 0; i < res.size() && i < cap; i++) { out[3 * i] = res[i].posSrcText; out[3 * i + 1] = res[i].length; out[3 * i + 2] = res[i].posDestText; }
     return res.size();
+}
+
+// ---------------------------------------------------------------- backend: leaf coders and the collective section
+// One leaf coder call as Compress() makes it (coders/CodersLib.cpp:53-66): LzmaCompress / Ppmd7Compress with the given
+// properties. Returns 0 and the coder's bytes, or non-zero.
+int refbk_leaf(int coder, int level, uint32_t dictSize, int lc, int lp, int pb, int fb, int algo, int numThreads, uint32_t memSize,
+               int order, const unsigned char *src, uint64_t n, unsigned char *dest, uint64_t cap, uint64_t *destLen) {
+    quiet();
+    std::unique_ptr<CoderProps> props;
+    if (coder == LZMA_CODER) props.reset(new LzmaCoderProps(level, dictSize, lc, lp, pb, fb, algo, numThreads));
+    else if (coder == PPMD7_CODER) props.reset(new PpmdCoderProps(memSize, order));
+    else return -1;
+    size_t len = 0;
+    unsigned char *out = Compress(len, src, n, props.get(), 1, &null_stream);
+    if (len > cap) { delete[] out; return -2; }
+    memcpy(dest, out, len);
+    delete[] out;
+    *destLen = len;
+    return 0;
+}
+
+// MBGC_Encoder::prepareAndCompressStreams (mbgccoder/MBGC_Encoder.cpp:615-732) on streams given from outside: writes the
+// archive (MBGC_Params::write, writeStats, then the collective section) to `path`. *prefix = bytes in front of the
+// collective section. headers / headerTemplates go in as the one file's (prepareHeadersStreams appends the file separator
+// to the templates). flags: bit0 ultraStreamsCompression, bit1 lazyDecompressionSupport, bit2 sequentialMatching.
+int refbk_archive(const char *path, int mode, int flags, int threads, uint64_t refFinalTotalLength, const unsigned char *const *data,
+                  const uint64_t *size, uint64_t *prefix) {
+    quiet();
+    MBGC_Params params;
+    params.setCompressionMode(mode);
+    if (flags & 1) params.setUltraStreamsCompression();
+    params.lazyDecompressionSupport = (flags & 2) != 0;
+    params.sequentialMatching = (flags & 4) != 0;
+    params.backendThreads = threads;
+    params.outArchiveFileName = path;
+    params.forceOverwrite = true;
+    MBGC_Encoder e(&params);
+    auto str = [&](int i) { return std::string((const char *) data[i], size[i]); };
+    e.filesCount = 1;
+    e.namesStr = str(0);
+    e.seqsCountsDest << str(1);
+    e.fileHeadersTemplates.assign(1, str(2));
+    e.fileHeaders.assign(1, str(3));
+    e.dnaLineLengthsDest << str(4);
+    e.unmatchedFractionFactors.assign(data[5], data[5] + size[5]);
+    e.targetLiterals.assign(1, str(6));
+    e.locksPosStream = str(9);
+    e.targetGapDeltas.assign(1, str(10));
+    e.targetGapMismatchesFlags.assign(1, str(11));
+    e.mapOffStream = str(12);
+    e.targetMapOff5thByte.assign(1, str(13));
+    e.mapLenStream = str(14);
+    e.refExtSizeDest << str(15);
+    e.refFinalTotalLength = refFinalTotalLength;
+    std::ostringstream head;
+    params.write(head);
+    e.writeStats(head);
+    *prefix = head.str().size();
+    e.prepareAndCompressStreams();
+    return 0;
+}
+
+// the leaf callback of include/mbgc_backend.h served by the reference's coders: what a maintainer's build passes to
+// mbgc_backend_compress_streams, and what `mbgc-hip c --backend oracle/_ref/libswsem_ref.so` loads in the tests
+struct RefLeafCoder { int coder, level, lc, lp, pb, fb, algo, numThreads; uint32_t dictSize, memSize; int order; };
+int mbgc_leaf_compress(void *ctx, const RefLeafCoder *c, const unsigned char *src, uint64_t n, unsigned char *dest, uint64_t cap, uint64_t *destLen) {
+    return refbk_leaf(c->coder, c->level, c->dictSize, c->lc, c->lp, c->pb, c->fb, c->algo, c->numThreads, c->memSize, c->order, src, n, dest, cap, destLen);
+}
+
+// readCompressedCollectiveParallel (coders/CodersLib.cpp:417-478) over a collective section in memory: the reference's
+// own reader. sizes[i] = length of stream i; out receives the streams back to back (capacity cap). Returns total bytes.
+uint64_t refbk_read_collective(const unsigned char *section, uint64_t n, int nStreams, uint64_t *sizes, unsigned char *out, uint64_t cap) {
+    quiet();
+    std::istringstream in(std::string((const char *) section, n));
+    std::vector<std::string> strs(nStreams);
+    std::vector<std::string *> ptrs;
+    for (auto &x : strs) ptrs.push_back(&x);
+    readCompressedCollectiveParallel(in, ptrs);
+    uint64_t at = 0;
+    for (int i = 0; i < nStreams; i++) {
+        sizes[i] = strs[i].size();
+        if (at + strs[i].size() <= cap) memcpy(out + at, strs[i].data(), strs[i].size());
+        at += strs[i].size();
+    }
+    return at;
 }
 
 }  // extern "C"

@@ -169,3 +169,44 @@ def test_bench_mode_reports_throughput(tmp_path):
     out = run_tool(["c", "--bench", "--warmup", "1", "-R", "4", "list.txt", "x"], str(tmp_path))
     d = json.loads(out.strip().splitlines()[-1])
     assert d["rounds"] == 2 and d["bases"] == 8 * 400_000 and d["value"] > 0
+
+
+def test_backend_section_is_read_back_by_the_reference(tmp_path):
+    """`--backend`: the tool's streams through the job table + container framing of include/mbgc_backend.h with the
+    reference's own PPMd7 / LZMA (oracle/_ref) as the leaf coders; the reference's reader
+    (readCompressedCollectiveParallel, coders/CodersLib.cpp:417-478) must give back the dumps, and the section must weigh
+    what the reference's archive of the same three genomes weighs (1 016 021 bytes) minus its name /
+    header streams and parameters"""
+    import ctypes as C
+    import _refh
+    if not _refh.available():
+        pytest.skip("oracle/_ref not built")
+    exp = json.load(open(os.path.join(LIST, "expected_t1.json")))
+    names = []
+    for f in exp["files"]:
+        (tmp_path / f).write_bytes(lzma.open(os.path.join(LIST, f + ".xz")).read())
+        names.append(str(tmp_path / f))
+    (tmp_path / "seqlist.txt").write_text("\n".join(names) + "\n")
+    out = run_tool(["c", "-t1", "--backend", os.path.join(ROOT, "oracle", "_ref", "libswsem_ref.so"), "--backend-threads", "1",
+                    "seqlist.txt", "lm"], str(tmp_path))
+    assert "backend:" in out
+    section = (tmp_path / "lm.collective").read_bytes()
+    assert 900_000 < len(section) < 1_016_021
+    R = _refh.lib()
+    order = [None, None, None, None, None, "factors", "literals", "locksPos", "gapDelta", "flags", "mapOff", "mapLen", "refExtSize"]
+    sizes = (C.c_uint64 * len(order))()
+    cap = 16 << 20
+    buf = C.create_string_buffer(cap)
+    R.refbk_read_collective.restype = C.c_uint64
+    total = R.refbk_read_collective(section, C.c_uint64(len(section)), len(order), sizes, buf, C.c_uint64(cap))
+    assert total <= cap
+    at = 0
+    for name, n in zip(order, sizes):
+        got = buf.raw[at: at + n]
+        at += n
+        if name is None:
+            assert n == 0
+        elif name == "factors":
+            assert got == bytes([128, 8] * 3)                           # one pair per file in the -t1 schedule (MGMP.cpp:252-255)
+        else:
+            assert got == (tmp_path / ("lm." + name)).read_bytes(), name
