@@ -109,7 +109,14 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
 // The same for several loadRef pieces in one launch. Epochs make the result independent of the order in
 // which the samples arrive, so all pieces of a round are inserted concurrently once their bytes (and the
 // separators) are in place. first[p] = index of piece p's first thread (prefix sums, first[np] = total).
-struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, pad; };
+//
+// The bytes a piece's samples hash are, for all but a few of them, bytes of the text the piece's loadRef step copies into
+// the buffer: reference positions [lo, hi) hold src[0 .. hi - lo). FROM_SRC launches hash those samples from the text
+// itself, so the insertion need not wait for the copy (which runs beside it on a stream of its own); the samples whose
+// window reaches outside [lo, hi) — into the previous text, a separator — are left to a small launch over the buffer
+// once the copy has landed (the host lists them as runs of their own).
+struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, pad; const uint8_t *src; uint64_t lo, hi; };
+template<bool FROM_SRC>
 __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                       const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first,
                                                       int np, int k1, int k1ord, int K, uint32_t mask, int fpBits,
@@ -128,6 +135,10 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
     const bool tail = t >= pc.nMain;
     const uint64_t p = tail ? pc.T + (t - pc.nMain) * (uint64_t) k1 : pc.S + t * (uint64_t) k1;
     const uint8_t *s = ref + p;
+    if (FROM_SRC) {
+        if (!pc.src || p < pc.lo || p + (uint64_t) K > pc.hi) return;
+        s = pc.src + (p - pc.lo);
+    }
     uint32_t h = (uint32_t) K;
     const int nw = K / 4;
     for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);

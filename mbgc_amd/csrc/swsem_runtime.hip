@@ -93,6 +93,10 @@ struct swsem {
     DevBuf<uint32_t> dGate;
     DevBuf<uint8_t> dPred;
     std::vector<InsertPiece> pendingPieces;
+    std::vector<InsertPiece> edgePieces;   // flush_inserts: the samples left to the launch behind the copies
+    bool insertBeside = true;              // insertion hashes from the copies' sources, the copies run beside it (SWSEM_INSERT_BESIDE=0: one after the other)
+    hipStream_t streamLoad = nullptr;      // ... on this stream
+    hipEvent_t evLoadFork = nullptr, evLoadDone = nullptr;
     std::vector<CopyPiece> pendingCopies;    // ... and its byte writes: device-to-device copies,
     std::vector<BytePiece> pendingBytes;     // then single bytes (separators), each list in program order
     DevBuf<uint64_t> dTables;                // one upload: insert pieces, their prefix, copy pieces, their prefix, bytes
@@ -271,7 +275,7 @@ void build_lut(uint8_t *lut) {
 }
 
 // processIgnoreCollisionsRef (.cpp:146-171): derive the two sample sets and launch one insertion.
-int insert_samples(swsem *h) {
+int insert_samples(swsem *h, const uint8_t *src = nullptr, uint64_t lo = 0, uint64_t hi = 0) {
     const int64_t STEP = (int64_t) h->k1 * 128;
     const int64_t E = h->pos1 - h->K;
     const int64_t S = (int64_t) h->samplingPos;
@@ -287,6 +291,7 @@ int insert_samples(swsem *h) {
     if (total && h->deferInserts) {
         InsertPiece pc;
         pc.S = (uint64_t) S; pc.nMain = nMain; pc.T = (uint64_t) T; pc.nTail = nTail; pc.epoch = h->epoch; pc.pad = 0;
+        pc.src = src; pc.lo = lo; pc.hi = hi;                       // reference positions [lo, hi) will hold src[0 .. hi - lo)
         h->pendingPieces.push_back(pc);
     } else if (total) {
         h->mark(SWSEM_K_INSERT, true);
@@ -367,8 +372,10 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
             else k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->swEnd - 1, (uint8_t) sep);
             h->sep_end_set((int64_t) h->swEnd, sep);
         }
+        const bool viaTable = tmpLength && !rc && h->deferInserts;
+        const uint64_t copiedTo = (uint64_t) h->pos1;
         h->pos1 += (int64_t) tmpLength;
-        int r = insert_samples(h);
+        int r = viaTable ? insert_samples(h, text, copiedTo, copiedTo + tmpLength) : insert_samples(h);
         if (r) return r;
         text += rc ? 0 : tmpLength;
         len = (uint64_t) h->pos1 == tmpEnd ? 0 : len - tmpLength;
@@ -397,10 +404,51 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
         }
     }
     constexpr uint64_t CHUNK = 256 * 16;                 // bytes per copy block
-    const size_t wPieces = np * (sizeof(InsertPiece) / 8), wCopies = nc * (sizeof(CopyPiece) / 8), wBytes = nb * (sizeof(BytePiece) / 8);
+    // Insertion beside the copies: a sample whose K bytes all come out of its own piece's copy is hashed from the copy's
+    // source (k_insert_multi<true>), while the copies run on a stream of their own; what is left — windows that reach into
+    // the previous text or a separator, pieces without a copy — is listed as runs of its own and inserted from the buffer
+    // once the copies have landed. A byte a separator of this flush overwrites is not "the copy's" any more.
+    std::vector<InsertPiece> &edge = h->edgePieces;
+    edge.clear();
+    bool beside = h->insertBeside && np && nc;
+    if (beside) {
+        for (size_t i = 0; i < nc && beside; i++)        // (two copies of one flush over the same bytes: only in order)
+            for (size_t j = i + 1; j < nc && beside; j++)
+                beside = h->pendingCopies[i].dst + h->pendingCopies[i].len <= h->pendingCopies[j].dst || h->pendingCopies[j].dst + h->pendingCopies[j].len <= h->pendingCopies[i].dst;
+    }
+    if (beside) {
+        const int64_t k1 = h->k1, K = h->K;
+        for (auto &pc : h->pendingPieces) {
+            if (pc.src)
+                for (auto &b : h->pendingBytes)
+                    if (b.off >= pc.lo && b.off < pc.hi) { if (b.off - pc.lo < pc.hi - b.off) { pc.src += b.off + 1 - pc.lo; pc.lo = b.off + 1; } else pc.hi = b.off; }
+            // samples p = base + t*k1, t < n, that k_insert_multi<true> does not take: p < lo or p + K > hi
+            auto runs = [&](uint64_t base, uint64_t n, uint32_t epoch) {
+                if (!n) return;
+                int64_t a = 0, b = -1;                              // taken from the source: t in [a, b]
+                if (pc.src && (int64_t) pc.hi - K >= (int64_t) base) {
+                    a = (int64_t) pc.lo > (int64_t) base ? ((int64_t) pc.lo - (int64_t) base + k1 - 1) / k1 : 0;
+                    b = std::min<int64_t>((int64_t) n - 1, ((int64_t) pc.hi - K - (int64_t) base) / k1);
+                }
+                auto push = [&](int64_t t0, int64_t t1) {           // [t0, t1)
+                    if (t1 <= t0) return;
+                    InsertPiece e = {};
+                    e.S = base + (uint64_t) t0 * (uint64_t) k1; e.nMain = (uint64_t) (t1 - t0); e.epoch = epoch;
+                    edge.push_back(e);
+                };
+                if (b < a) push(0, (int64_t) n);
+                else { push(0, a); push(b + 1, (int64_t) n); }
+            };
+            runs(pc.S, pc.nMain, pc.epoch);
+            runs(pc.T, pc.nTail, pc.epoch + 1);
+        }
+    } else
+        for (auto &pc : h->pendingPieces) pc.src = nullptr;
+    const size_t ne = edge.size();
+    const size_t wPieces = np * (sizeof(InsertPiece) / 8), wCopies = nc * (sizeof(CopyPiece) / 8), wBytes = nb * (sizeof(BytePiece) / 8), wEdge = ne * (sizeof(InsertPiece) / 8);
     // host table: a member (two alternating ones), so the upload needs no wait before returning
     swsem::HostTab &ht = h->hostTables[h->hostTableSel ^= 1];
-    const size_t words = wPieces + (np + 1) + wCopies + (nc + 1) + wBytes;
+    const size_t words = wPieces + (np + 1) + wCopies + (nc + 1) + wBytes + wEdge + (ne + 1);
     if (ht.pending) { HIPCHK(hipEventSynchronize(ht.ev)); ht.pending = false; }
     if (ht.cap < words) {
         if (ht.p) HIPCHK(hipHostFree(ht.p));
@@ -412,7 +460,8 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     }
     if (!ht.ev) HIPCHK(hipEventCreateWithFlags(&ht.ev, hipEventDisableTiming));
     struct { uint64_t *p; uint64_t *data() { return p; } size_t n; size_t size() const { return n; } } tab = {ht.p, words};
-    uint64_t *tPieces = tab.data(), *tFirst = tPieces + wPieces, *tCopies = tFirst + np + 1, *tCFirst = tCopies + wCopies, *tBytes = tCFirst + nc + 1;
+    uint64_t *tPieces = tab.data(), *tFirst = tPieces + wPieces, *tCopies = tFirst + np + 1, *tCFirst = tCopies + wCopies, *tBytes = tCFirst + nc + 1,
+             *tEdge = tBytes + wBytes, *tEFirst = tEdge + wEdge;
     if (np) memcpy(tPieces, h->pendingPieces.data(), np * sizeof(InsertPiece));
     tFirst[0] = 0;
     for (size_t i = 0; i < np; i++) tFirst[i + 1] = tFirst[i] + h->pendingPieces[i].nMain + h->pendingPieces[i].nTail;
@@ -420,6 +469,9 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     tCFirst[0] = 0;
     for (size_t i = 0; i < nc; i++) tCFirst[i + 1] = tCFirst[i] + (h->pendingCopies[i].len + CHUNK - 1) / CHUNK;
     if (nb) memcpy(tBytes, h->pendingBytes.data(), nb * sizeof(BytePiece));
+    if (ne) memcpy(tEdge, edge.data(), ne * sizeof(InsertPiece));
+    tEFirst[0] = 0;
+    for (size_t i = 0; i < ne; i++) tEFirst[i + 1] = tEFirst[i] + edge[i].nMain;
     int r;
     if ((r = h->dTables.reserve(std::max<size_t>(2 * tab.size(), 1 << 16)))) return r;   // regrowing = hipFree = a device-wide wait
     // (a kernel reading the pinned table: a runtime copy here costs an engine switch in the middle of the main stream)
@@ -427,18 +479,37 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     HIPCHK(hipEventRecord(ht.ev, h->stream));
     ht.pending = true;
     const uint64_t *d = h->dTables.p;
-    if (nc) {
-        h->mark(SWSEM_K_LOAD, true);
-        k_copy_multi<<<dim3((unsigned) tCFirst[nc]), dim3(256), 0, h->stream>>>(h->ref, (const CopyPiece *) (d + (tCopies - tab.data())),
-                                                                              d + (tCFirst - tab.data()), (int) nc, gate);
-        h->mark(SWSEM_K_LOAD, false);
+    hipStream_t cs = h->stream;                                    // the copies' stream
+    if (beside) {
+        if (!h->streamLoad && (hipStreamCreateWithFlags(&h->streamLoad, hipStreamNonBlocking) != hipSuccess ||
+                               hipEventCreateWithFlags(&h->evLoadFork, hipEventDisableTiming) != hipSuccess ||
+                               hipEventCreateWithFlags(&h->evLoadDone, hipEventDisableTiming) != hipSuccess))
+            return fail(SWSEM_EHIP, "hipStreamCreate failed");
+        cs = h->streamLoad;
+        HIPCHK(hipEventRecord(h->evLoadFork, h->stream));            // (behind the tables, the gate and every wait the writes were given)
+        HIPCHK(hipStreamWaitEvent(cs, h->evLoadFork, 0));
     }
-    if (nb) k_set_bytes<<<1, 1, 0, h->stream>>>(h->ref, (const BytePiece *) (d + (tBytes - tab.data())), (int) nb, gate);
+    if (nc) {
+        h->mark(SWSEM_K_LOAD, true, cs);
+        k_copy_multi<<<dim3((unsigned) tCFirst[nc]), dim3(256), 0, cs>>>(h->ref, (const CopyPiece *) (d + (tCopies - tab.data())),
+                                                                       d + (tCFirst - tab.data()), (int) nc, gate);
+        h->mark(SWSEM_K_LOAD, false, cs);
+    }
+    if (nb) k_set_bytes<<<1, 1, 0, cs>>>(h->ref, (const BytePiece *) (d + (tBytes - tab.data())), (int) nb, gate);
+    if (beside) HIPCHK(hipEventRecord(h->evLoadDone, cs));
     if (np) {
         h->mark(SWSEM_K_INSERT, true);
-        k_insert_multi<<<dim3((unsigned) ((tFirst[np] + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (const InsertPiece *) (d + (tPieces - tab.data())), d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
+        const dim3 grid((unsigned) ((tFirst[np] + 255) / 256));
+        const InsertPiece *dp = (const InsertPiece *) (d + (tPieces - tab.data()));
+        if (beside) k_insert_multi<true><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, dp, d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
+        else k_insert_multi<false><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, dp, d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
         h->mark(SWSEM_K_INSERT, false);
+    }
+    if (beside) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->evLoadDone, 0));
+        if (ne && tEFirst[ne])
+            k_insert_multi<false><<<dim3((unsigned) ((tEFirst[ne] + 255) / 256)), dim3(256), 0, h->stream>>>(
+                h->ref, h->ht, (const InsertPiece *) (d + (tEdge - tab.data())), d + (tEFirst - tab.data()), (int) ne, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
     }
     HIPCHK(hipGetLastError());
     h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear();
@@ -775,6 +846,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_ORDER")) h->orderMode = strcmp(e, "contig") == 0 ? 0 : 1;
+    if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
@@ -819,6 +891,9 @@ void swsem_destroy(swsem_t *h) {
     if (h->ring) { (void) hipHostFree(h->ring); h->ring = nullptr; h->ringCap = 0; }
     for (auto &t : h->hostTables) { if (t.p) (void) hipHostFree(t.p); if (t.ev) (void) hipEventDestroy(t.ev); t = swsem::HostTab(); }
     if (h->stream2) { (void) hipStreamSynchronize(h->stream2); (void) hipStreamDestroy(h->stream2); }
+    if (h->streamLoad) { (void) hipStreamSynchronize(h->streamLoad); (void) hipStreamDestroy(h->streamLoad); }
+    if (h->evLoadFork) (void) hipEventDestroy(h->evLoadFork);
+    if (h->evLoadDone) (void) hipEventDestroy(h->evLoadDone);
     h->drain_events();
     for (auto &e : h->idle) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     h->idle.clear();
