@@ -56,6 +56,13 @@ int mbgc_fasta_parse_host(mbgc_fasta_t *p, const uint8_t *file_host, uint64_t n,
                           uint64_t *seqBytes, mbgc_fasta_record_t *records, uint64_t recCap, uint64_t *nrec,
                           uint64_t *dnaLineLen, int *status);
 
+/* The way into HBM ("fed by pinned-memory reads"): page-locked host memory for the reader threads to
+ * read files into, and its copy to the device on the input stage's own stream — it returns when the bytes have arrived
+ * and waits for nothing the matcher has queued. */
+int mbgc_fasta_host_alloc(mbgc_fasta_t *p, uint64_t bytes, void **out);
+int mbgc_fasta_host_free(mbgc_fasta_t *p, void *ptr);
+int mbgc_fasta_upload(mbgc_fasta_t *p, uint8_t *dst_dev, const void *src_host, uint64_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -466,4 +466,27 @@ int mbgc_fasta_parse_host(mbgc_fasta_t *p, const uint8_t *file_host, uint64_t n,
     return 0;
 }
 
+int mbgc_fasta_host_alloc(mbgc_fasta_t *p, uint64_t bytes, void **out) {
+    using namespace fa;
+    FCHK(hipSetDevice(p->device));
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return fail(-101, "cannot pin %llu B of host memory", (unsigned long long) bytes);
+    return 0;
+}
+
+int mbgc_fasta_host_free(mbgc_fasta_t *p, void *ptr) {
+    using namespace fa;
+    FCHK(hipSetDevice(p->device));
+    if (ptr) FCHK(hipHostFree(ptr));
+    return 0;
+}
+
+int mbgc_fasta_upload(mbgc_fasta_t *p, uint8_t *dst_dev, const void *src_host, uint64_t bytes) {
+    using namespace fa;
+    FCHK(hipSetDevice(p->device));
+    if (bytes) FCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, p->stream));
+    FCHK(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
 }  // extern "C"

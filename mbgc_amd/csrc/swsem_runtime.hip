@@ -151,7 +151,21 @@ struct swsem {
         int emitLaps = 0;                    // laps of the buffer when it started
         int emitN = 0;
         uint8_t *pinE = nullptr; size_t pinECap = 0;
-        std::vector<uint8_t> hostStreams;
+        // the streams on the host: page-locked (the copy runs at the link's rate and nothing is zero-filled), grow-only
+        struct PinBytes {
+            uint8_t *p = nullptr; size_t cap = 0;
+            uint8_t *data() { return p; }
+            int reserve(size_t n) {
+                if (n <= cap) return 0;
+                if (p) (void) hipHostFree(p);
+                p = nullptr; cap = 0;
+                const size_t want = n + n / 2 + 4096;
+                if (hipHostMalloc((void **) &p, want, hipHostMallocDefault) != hipSuccess) return -1;
+                cap = want;
+                return 0;
+            }
+            void release() { if (p) (void) hipHostFree(p); p = nullptr; cap = 0; }
+        } hostStreams;
         std::vector<uint64_t> hostStreamOff; // [k * NSTREAMS + s] offset into hostStreams
         bool hostStreamsValid = false;
         uint64_t packedBytes = 0;
@@ -160,6 +174,7 @@ struct swsem {
             dEPack.release(); dERm.release(); dEArena.release(); dEKeep.release(); dEMeta.release(); dECorr.release();
             dESz.release(); dEOfs.release(); dEChunk.release(); dEStates.release(); dEStat.release();
             if (pinE) { (void) hipHostFree(pinE); pinE = nullptr; pinECap = 0; }
+            hostStreams.release();
             if (evDone) { (void) hipEventDestroy(evDone); evDone = nullptr; }
         }
     } slot[2];
@@ -794,7 +809,7 @@ int end_slot(swsem *h, int si) {
     E.packedBytes = tot;
     E.hostStreamsValid = false;
     if (h->emitHostCopy) {
-        E.hostStreams.resize(tot + 1);
+        if (E.hostStreams.reserve(tot + 1)) return fail(SWSEM_ENOMEM, "cannot pin %llu B of host memory", (unsigned long long) tot);
         if (tot) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, tot, hipMemcpyDeviceToHost, h->stream3));
         HIPCHK(hipStreamSynchronize(h->stream3));
         E.hostStreamsValid = true;
@@ -1471,7 +1486,7 @@ int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
     { int e = end_slot(h, (int) (&E - h->slot)); if (e) return e; }
     if (k < 0 || k >= (int) E.eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
     if (!E.hostStreamsValid) {
-        E.hostStreams.resize(E.packedBytes + 1);      // (only here: zero-filling megabytes has no place on the round's critical path)
+        if (E.hostStreams.reserve(E.packedBytes + 1)) return fail(SWSEM_ENOMEM, "cannot pin %llu B of host memory", (unsigned long long) E.packedBytes);
         if (E.packedBytes) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, E.packedBytes, hipMemcpyDeviceToHost, h->stream3));
         HIPCHK(hipStreamSynchronize(h->stream3));
         E.hostStreamsValid = true;

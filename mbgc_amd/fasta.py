@@ -5,7 +5,7 @@ import numpy as np
 
 from . import binding
 
-EXPORTS = "mbgc_fasta_create mbgc_fasta_destroy mbgc_fasta_last_error mbgc_fasta_parse_batch_dev mbgc_fasta_parse_host".split()
+EXPORTS = "mbgc_fasta_create mbgc_fasta_destroy mbgc_fasta_last_error mbgc_fasta_parse_batch_dev mbgc_fasta_parse_host mbgc_fasta_host_alloc mbgc_fasta_host_free mbgc_fasta_upload".split()
 
 
 class Record(C.Structure):

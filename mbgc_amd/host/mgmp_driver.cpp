@@ -5,8 +5,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <fstream>
+#include <functional>
+#include <thread>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 
 using PgTools::TextMatch;
@@ -41,6 +47,11 @@ static void writeUInt64Frugal(std::string &dest, uint64_t value) {
     }
 }
 
+static double nowSeconds() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+// where the host's wall time goes (MBGC_HIP_TIMES=1 prints it with "matching finished"): reading + inflating files,
+// upload + device parse, taking the streams over
+static double g_tRead = 0, g_tParse = 0, g_tCollect = 0, g_tWait = 0;
+
 // ---------------------------------------------------------------- input stage
 // mgmpInOpen / whole-file read (MGMP.cpp:7-14; gz inflate is the host's libdeflate in the reference and is not part
 // of this repo) + kseq_read_lossless_fasta on the device (include/mbgc_fasta.h), status handling of
@@ -50,18 +61,8 @@ static void writeUInt64Frugal(std::string &dest, uint64_t value) {
 // used up, output buffer sized by the ISIZE trailer and doubled when short; here: zlib on the host — DEFLATE's bit-serial
 // Huffman decoding has no place on the device, and a round's files inflate on the host while the GPU matches the round
 // before)
-static bool readWholeFile(const std::string &path, std::string &dest) {
-    std::ifstream f(path, std::ios::binary | std::ios::ate);
-    if (!f) return false;
-    const std::streamoff n = f.tellg();
-    f.seekg(0);
+static void inflateGzip(const std::string &gz, std::string &dest) {
     const size_t at = dest.size();
-    dest.resize(at + (size_t) n);
-    if (n) f.read(&dest[at], n);
-    if (!f) return false;
-    if (n < 18 || (uint8_t) dest[at] != 0x1f || (uint8_t) dest[at + 1] != 0x8b) return true;   // GZIP_ID1, GZIP_ID2
-    std::string gz(dest, at);
-    dest.resize(at);
     uint32_t isize;
     memcpy(&isize, gz.data() + gz.size() - 4, 4);
     size_t cap = isize ? isize : gz.size() * 4, out = 0;
@@ -93,6 +94,28 @@ static bool readWholeFile(const std::string &path, std::string &dest) {
     }
     inflateEnd(&z);
     dest.resize(at + out);
+}
+
+static bool isGzip(const uint8_t *p, size_t n) { return n >= 18 && p[0] == 0x1f && p[1] == 0x8b; }     // GZIP_ID1, GZIP_ID2
+
+// mgmpInOpen (matching/input_with_libdeflate_wrapper.cpp:51-124): the whole file, and when it starts with the gzip magic,
+// its members inflated one after the other (the reference: libdeflate_gzip_decompress_ex in a loop until the input is
+// used up, output buffer sized by the ISIZE trailer and doubled when short; here: zlib on the host — DEFLATE's bit-serial
+// Huffman decoding has no place on the device, and a round's files inflate on the host while the GPU matches the round
+// before)
+static bool readWholeFile(const std::string &path, std::string &dest) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) return false;
+    const std::streamoff n = f.tellg();
+    f.seekg(0);
+    const size_t at = dest.size();
+    dest.resize(at + (size_t) n);
+    if (n) f.read(&dest[at], n);
+    if (!f) return false;
+    if (!isGzip((const uint8_t *) dest.data() + at, (size_t) n)) return true;
+    const std::string gz(dest, at);
+    dest.resize(at);
+    inflateGzip(gz, dest);
     return true;
 }
 
@@ -107,6 +130,8 @@ static void validate_kseq_status(const std::string &fileName, int status) {
 
 MultipleGenomeMatchingProcessor::~MultipleGenomeMatchingProcessor() {
     if (matcher && rawDev) matcher->devFree(rawDev);
+    if (ahead.active) ahead.done.wait();
+    if (fasta && staged.pin) mbgc_fasta_host_free(fasta, staged.pin);
     if (fasta) mbgc_fasta_destroy(fasta);
     delete matcher;
 }
@@ -125,11 +150,19 @@ void MultipleGenomeMatchingProcessor::readG0(const std::string &path, std::vecto
     if (!readWholeFile(path, data)) { fprintf(stderr, "cannot open file %s\n", path.c_str()); exit(EXIT_FAILURE); }
     if (fileSize) *fileSize = data.size();
     std::string seq(data.size(), '\0');
-    records.resize(data.size() / 2 + 2);
     uint64_t seqBytes = 0, nrec = 0, lineLen = 0;
     int status = 0;
-    if (mbgc_fasta_parse_host(fasta, (const uint8_t *) data.data(), data.size(), params->uppercaseDNA, (uint8_t *) &seq[0], &seqBytes,
-                              records.data(), records.size(), &nrec, &lineLen, &status) != 0) {
+    // (the record table starts small and grows to what the parser asks for: one entry per two input bytes, the bound,
+    // is gigabytes of zeroed memory for a round's files)
+    if (records.size() < 4096) records.resize(4096);
+    int rc = mbgc_fasta_parse_host(fasta, (const uint8_t *) data.data(), data.size(), params->uppercaseDNA, (uint8_t *) &seq[0], &seqBytes,
+                                   records.data(), records.size(), &nrec, &lineLen, &status);
+    if (rc == -104) {
+        records.resize(nrec + nrec / 4 + 16);
+        rc = mbgc_fasta_parse_host(fasta, (const uint8_t *) data.data(), data.size(), params->uppercaseDNA, (uint8_t *) &seq[0], &seqBytes,
+                                   records.data(), records.size(), &nrec, &lineLen, &status);
+    }
+    if (rc != 0) {
         fprintf(stderr, "input stage: %s\n", mbgc_fasta_last_error());
         exit(EXIT_FAILURE);
     }
@@ -143,22 +176,99 @@ void MultipleGenomeMatchingProcessor::readG0(const std::string &path, std::vecto
     }
 }
 
+// files [f0, f1) of the list, each whole (inflated when gzip), back to back in page-locked memory: the sizes first (a
+// gzip file's is known once it is inflated), then every plain file read straight to its place, by up to 8 threads
+void MultipleGenomeMatchingProcessor::readFiles(StagedFiles &S, uint32_t f0, uint32_t f1) {
+    S.error.clear();
+    const size_t nf = f1 - f0;
+    std::vector<int> fd(nf, -1);
+    std::vector<uint64_t> size(nf, 0);
+    std::vector<std::string> inflated(nf);
+    std::vector<std::string> errors(nf);
+    auto parallel = [&](const std::function<void(size_t)> &body) {
+        std::atomic<size_t> next{0};
+        auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < nf;) body(i); };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < std::min<size_t>(8, nf); t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    };
+    parallel([&](size_t i) {
+        const std::string &path = fileNames[f0 + i];
+        fd[i] = open(path.c_str(), O_RDONLY);
+        struct stat st;
+        if (fd[i] < 0 || fstat(fd[i], &st) != 0) { errors[i] = "cannot open file " + path; return; }
+        size[i] = (uint64_t) st.st_size;
+        uint8_t head[18];
+        if (size[i] >= 18 && pread(fd[i], head, 18, 0) == 18 && isGzip(head, 18)) {
+            std::string gz(size[i], '\0');
+            size_t got = 0;
+            while (got < gz.size()) { const ssize_t k = pread(fd[i], &gz[got], gz.size() - got, (off_t) got); if (k <= 0) break; got += (size_t) k; }
+            if (got != gz.size()) { errors[i] = "Problem reading from file: " + path; return; }
+            inflateGzip(gz, inflated[i]);
+            size[i] = inflated[i].size();
+            close(fd[i]); fd[i] = -1;
+        }
+    });
+    for (size_t i = 0; i < nf; i++) if (!errors[i].empty()) { S.error = errors[i]; break; }
+    S.fileOff.assign(1, 0);
+    for (size_t i = 0; i < nf; i++) S.fileOff.push_back(S.fileOff.back() + size[i]);
+    const size_t n = S.fileOff.back();
+    if (S.error.empty() && n + 64 > S.cap) {                 // grow-only
+        if (S.pin) mbgc_fasta_host_free(fasta, S.pin);
+        S.pin = nullptr;
+        S.cap = n + n / 4 + 64;
+        void *p = nullptr;
+        if (mbgc_fasta_host_alloc(fasta, S.cap, &p) != 0) { S.error = std::string("input stage: ") + mbgc_fasta_last_error(); S.cap = 0; }
+        S.pin = (uint8_t *) p;
+    }
+    if (S.error.empty())
+        parallel([&](size_t i) {
+            uint8_t *dst = S.pin + S.fileOff[i];
+            if (fd[i] < 0) { memcpy(dst, inflated[i].data(), inflated[i].size()); return; }
+            size_t got = 0;
+            while (got < size[i]) { const ssize_t k = pread(fd[i], dst + got, size[i] - got, (off_t) got); if (k <= 0) break; got += (size_t) k; }
+            if (got != size[i]) errors[i] = "Problem reading from file: " + fileNames[f0 + i];
+        });
+    for (size_t i = 0; i < nf; i++) {
+        if (fd[i] >= 0) close(fd[i]);
+        if (S.error.empty() && !errors[i].empty()) S.error = errors[i];
+    }
+}
+
+void MultipleGenomeMatchingProcessor::loadRound(uint32_t f0, uint32_t f1, RoundBatch &B, uint32_t nextF0, uint32_t nextF1, RoundBatch *nextB) {
+    const double t0 = nowSeconds();
+    bool have = false;
+    if (ahead.active) {
+        ahead.done.wait();
+        ahead.active = false;
+        have = ahead.f0 == f0 && ahead.f1 == f1 && ahead.B == &B;
+    }
+    g_tWait += nowSeconds() - t0;
+    if (!have) prepareRound(f0, f1, B);
+    if (nextB && nextF1 > nextF0) {
+        ahead.f0 = nextF0; ahead.f1 = nextF1; ahead.B = nextB; ahead.active = true;
+        ahead.done = std::async(std::launch::async, [this, nextF0, nextF1, nextB] { prepareRound(nextF0, nextF1, *nextB); });
+    }
+}
+
 // files [f0, f1) of the list -> their contigs back to back in B.seqDev; contig c belongs to target targetBase + (file - f0)
-void MultipleGenomeMatchingProcessor::loadRound(uint32_t f0, uint32_t f1, RoundBatch &B) {
+void MultipleGenomeMatchingProcessor::prepareRound(uint32_t f0, uint32_t f1, RoundBatch &B) {
     openInputStage();
     const int nf = (int) (f1 - f0);
     if (nf <= 0) {                                           // (a rank without targets in a short last round)
         B.offsets.assign(1, 0); B.targetOf.clear(); B.bytes = 0;
         return;
     }
-    rawFiles.clear();
-    std::vector<uint64_t> fileOff(1, 0);
-    for (uint32_t f = f0; f < f1; f++) {
-        if (!readWholeFile(fileNames[f], rawFiles)) { fprintf(stderr, "cannot open file %s\n", fileNames[f].c_str()); exit(EXIT_FAILURE); }
-        fileOff.push_back(rawFiles.size());
-    }
-    totalFilesLength += rawFiles.size();
-    const size_t n = rawFiles.size();
+    const double tRead0 = nowSeconds();
+    StagedFiles *S = &staged;
+    readFiles(*S, f0, f1);
+    if (!S->error.empty()) { fprintf(stderr, "%s\n", S->error.c_str()); exit(EXIT_FAILURE); }
+    const std::vector<uint64_t> &fileOff = S->fileOff;
+    const double tParse0 = nowSeconds();
+    g_tRead += tParse0 - tRead0;
+    totalFilesLength += fileOff.back();
+    const size_t n = fileOff.back();
     if (n + 64 > rawCap) {                                   // grow-only: freeing device memory waits for the whole device
         if (rawDev) matcher->devFree(rawDev);
         rawCap = n + n / 4 + 64;
@@ -169,12 +279,18 @@ void MultipleGenomeMatchingProcessor::loadRound(uint32_t f0, uint32_t f1, RoundB
         B.seqCap = n + n / 4 + 64;
         B.seqDev = matcher->devAlloc(B.seqCap);
     }
-    matcher->devUpload(rawDev, rawFiles.data(), n);
+    if (mbgc_fasta_upload(fasta, rawDev, S->pin, n) != 0) { fprintf(stderr, "input stage: %s\n", mbgc_fasta_last_error()); exit(EXIT_FAILURE); }
     std::vector<uint64_t> seqBase(nf + 1), recBase(nf + 1), lineLen(nf);
     std::vector<int> status(nf);
-    if (records.size() < n / 2 + 2) records.resize(n / 2 + 2);
-    if (mbgc_fasta_parse_batch_dev(fasta, rawDev, fileOff.data(), nf, params->uppercaseDNA, B.seqDev, B.seqCap, seqBase.data(),
-                                   records.data(), records.size(), recBase.data(), lineLen.data(), status.data()) != 0) {
+    if (records.size() < 4096) records.resize(4096);
+    int rc = mbgc_fasta_parse_batch_dev(fasta, rawDev, fileOff.data(), nf, params->uppercaseDNA, B.seqDev, B.seqCap, seqBase.data(),
+                                        records.data(), records.size(), recBase.data(), lineLen.data(), status.data());
+    if (rc == -104) {                                        // the table was too small: the parser said how many records there are
+        records.resize(recBase[nf] + recBase[nf] / 4 + 16);
+        rc = mbgc_fasta_parse_batch_dev(fasta, rawDev, fileOff.data(), nf, params->uppercaseDNA, B.seqDev, B.seqCap, seqBase.data(),
+                                        records.data(), records.size(), recBase.data(), lineLen.data(), status.data());
+    }
+    if (rc != 0) {
         fprintf(stderr, "input stage: %s\n", mbgc_fasta_last_error());
         exit(EXIT_FAILURE);
     }
@@ -190,6 +306,7 @@ void MultipleGenomeMatchingProcessor::loadRound(uint32_t f0, uint32_t f1, RoundB
         }
     }
     B.bytes = seqBase[nf];
+    g_tParse += nowSeconds() - tParse0;
 }
 
 // ---------------------------------------------------------------- MultipleGenomeMatchingProcessor
@@ -235,9 +352,10 @@ void MultipleGenomeMatchingProcessor::loadG0Ref(const std::string &refName) {
 }
 
 void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
-    RoundBatch B;
+    RoundBatch two[2];                                                                          // the file being matched, the file arriving
     for (uint32_t i = 0; i < filesCount; i++) {
-        loadRound(i, i + 1, B);                                                                 // MGMP.cpp:247-250
+        RoundBatch &B = two[i & 1];
+        loadRound(i, i + 1, B, i + 1, std::min(filesCount, i + 2), &two[(i + 1) & 1]);          // MGMP.cpp:247-250
         const size_t startPos = matcher->getLoadedRefLength();                                 // :251
         unmatchedFractionFactors.push_back(params->currentUnmatchedFractionFactor < 256 ? params->currentUnmatchedFractionFactor : 0);
         unmatchedFractionFactors.push_back((uint8_t) params->unmatchedFractionRCFactor);
@@ -257,7 +375,8 @@ void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
         }
         processAfterTargetWithParallelIO(startPos);                                            // :306
     }
-    if (B.seqDev) matcher->devFree(B.seqDev);
+    if (ahead.active) { ahead.done.wait(); ahead.active = false; }
+    for (auto &B : two) if (B.seqDev) matcher->devFree(B.seqDev);
 }
 
 // A round whose first pass gave up a contig as dissimilar (MGMP.cpp:382-388: "discard, wait until the earlier targets
@@ -372,25 +491,27 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
     if (bench)
         for (uint32_t r = 0; r < nRounds; r++) {
             slots[r].t0 = r * R; slots[r].t1 = std::min(targetsCount, (r + 1) * R);
-            loadRound(1 + slots[r].t0, 1 + slots[r].t1, slots[r]);
+            loadRound(1 + slots[r].t0, 1 + slots[r].t1, slots[r], 1 + std::min(targetsCount, (r + 1) * R), 1 + std::min(targetsCount, (r + 2) * R),
+                      r + 1 < nRounds ? &slots[r + 1] : nullptr);
         }
     struct Deferred { bool valid = false; RoundBatch *B = nullptr; } prev;   // emission whose streams have not been taken yet
     uint8_t *extTmp = nullptr; size_t extCap = 0;                           // contig + reverse complement extension strings
     int predicted = -1;                                                     // what every contig of the last round decided (-1: no prediction)
     auto collect = [&](RoundBatch &B, bool newerBegun) {                    // per-target stream merge, ENC.cpp:542-556
+        const double tc0 = nowSeconds();
         if (newerBegun) matcher->emitSelect(true);
+        size_t c = 0;                                                       // (the contigs of a round are in target order)
         for (uint32_t t = B.t0; t < B.t1; t++) {
-            for (size_t c = 0; c < B.targetOf.size(); c++)
-                if (B.t0 + B.targetOf[c] == t) {
-                    EmittedStreams es;
-                    if (!bench) matcher->emitTake((int) c, es);             // bench: the bytes stay packed in HBM, as in bench.py
-                    takeRoundStreams(t, es);
-                    processAfterSequence(t);
-                }
-            processAfterTarget(t);
-            appendTargetStreams(t);
+            for (; c < B.targetOf.size() && B.t0 + B.targetOf[c] == t; c++) {
+                if (bench) continue;                                        // bench: the bytes stay packed in HBM, as in bench.py
+                swsem_streams_t st = {};
+                matcher->emitView((int) c, st);
+                appendContigInOrder(st);
+            }
+            if (!bench) endTargetInOrder();
         }
         if (newerBegun) matcher->emitSelect(false);
+        g_tCollect += nowSeconds() - tc0;
     };
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
     double tStart = 0;
@@ -398,7 +519,8 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
         RoundBatch &B = slots[bench ? r : r % 3];
         if (!bench) {
             B.t0 = r * R; B.t1 = std::min(targetsCount, (r + 1) * R);
-            loadRound(1 + B.t0, 1 + B.t1, B);
+            loadRound(1 + B.t0, 1 + B.t1, B, 1 + std::min(targetsCount, (r + 1) * R), 1 + std::min(targetsCount, (r + 2) * R),
+                      r + 1 < nRounds ? &slots[(r + 1) % 3] : nullptr);
         } else if ((int) r == params->benchWarmup) {
             if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); prev.valid = false; }
             matcher->synchronize();
@@ -529,7 +651,9 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
     if (extTmp) matcher->devFree(extTmp);
 }
 
+
 void MultipleGenomeMatchingProcessor::performMatching() {
+    const double t0 = nowSeconds();
     if (params->sequentialMatching) processTargetsWithParallelIO();
     else if (targetsCount && params->exchange) processTargetsRoundsSharded();
     else if (targetsCount) processTargetsRounds();
@@ -538,6 +662,14 @@ void MultipleGenomeMatchingProcessor::performMatching() {
         exit(EXIT_FAILURE);
     }
     refFinalTotalLength = matcher->getRefLength();
+    matcher->synchronize();
+    // (the reference prints its clock since start here, MGMP.cpp:604; this is the matching phase alone: reading, inflating
+    // and parsing the target files, match-finding, processMatches, loadRef)
+    if (!params->benchMode && (!params->exchange || mbgc_xchg_rank(params->exchange) == 0))
+        fprintf(stderr, "matching finished - %.0f [ms]\n", (nowSeconds() - t0) * 1e3);
+    if (getenv("MBGC_HIP_TIMES"))
+        fprintf(stderr, "  input thread: reading files %.0f ms, upload + parse %.0f ms; main thread: waiting for it %.0f ms, taking the streams over %.0f ms\n",
+                g_tRead * 1e3, g_tParse * 1e3, g_tWait * 1e3, g_tCollect * 1e3);
 }
 
 // ---------------------------------------------------------------- MBGC_Encoder
@@ -580,6 +712,28 @@ void MBGC_Encoder::takeRoundStreams(uint32_t targetIdx, EmittedStreams &s) {
     extensionsMismatchesAll += s.extensionsMismatches;
     totalMatchedAll += s.totalMatched;
     removedGapBreakingMatchesAll += s.removedGapBreakingMatches;
+}
+
+// takeRoundStreams + processAfterSequence, then processAfterTarget + appendTargetStreams, for targets that arrive in target
+// order: the bytes are appended where appendTargetStreams would put them (ENC.cpp:543-556, :489-496) without the stop in
+// the per-target strings
+void MBGC_Encoder::appendContigInOrder(const swsem_streams_t &st) {
+    literals.append((const char *) st.data[SWSEM_LIT], st.size[SWSEM_LIT]);
+    literals.push_back(SEQ_SEPARATOR_MARK);
+    mapOff.append((const char *) st.data[SWSEM_OFF], st.size[SWSEM_OFF]);
+    mapOff5thByte.append((const char *) st.data[SWSEM_OFF5], st.size[SWSEM_OFF5]);
+    mapLen.append((const char *) st.data[SWSEM_LEN], st.size[SWSEM_LEN]);
+    gapDeltas.append((const char *) st.data[SWSEM_GAP], st.size[SWSEM_GAP]);
+    gapMismatchesFlags.append((const char *) st.data[SWSEM_FLAGS], st.size[SWSEM_FLAGS]);
+    unmatchedCharsAll += st.unmatchedChars;
+    extensionsMatchedCharsAll += st.extensionsMatchedChars;
+    extensionsMismatchesAll += st.extensionsMismatches;
+    totalMatchedAll += st.totalMatched;
+    removedGapBreakingMatchesAll += st.removedGapBreakingMatches;
+}
+
+void MBGC_Encoder::endTargetInOrder() {
+    if (params->emit.enableExtensionsWithMismatches) gapMismatchesFlags.push_back(FILE_SEPARATOR_MARK);
 }
 
 void MBGC_Encoder::processAfterSequence(uint32_t targetIdx) {

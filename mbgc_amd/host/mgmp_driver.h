@@ -9,6 +9,7 @@
 // host exactly as in the reference; everything that touches sequence bytes runs through the C ABI.
 #pragma once
 #include <cstdint>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -92,12 +93,23 @@ protected:
     void processTargetsRoundsSharded();                                                 // the rounds with their targets sharded over the ranks of params->exchange (mgmp_sharded.cpp)
     // input stage (MGMP.cpp:7-35,349-372 on the device parser)
     mbgc_fasta_t *fasta = nullptr;
-    std::string rawFiles;
+    // The files of a round in page-locked host memory, read (and inflated) by several threads. The round named as "next"
+    // is read, uploaded and parsed by a thread of its own while the GPU and the host work on the current one (the
+    // reference reads ahead with its IO threads too, MGMP.cpp:232-313 "WithParallelIO").
+    struct StagedFiles {
+        uint8_t *pin = nullptr; size_t cap = 0;
+        std::vector<uint64_t> fileOff;
+        std::string error;
+    } staged;
+    struct Ahead { std::future<void> done; uint32_t f0 = 0, f1 = 0; RoundBatch *B = nullptr; bool active = false; } ahead;
+    void readFiles(StagedFiles &S, uint32_t f0, uint32_t f1);
+    void prepareRound(uint32_t f0, uint32_t f1, RoundBatch &B);                         // read + upload + device parse, synchronous
     uint8_t *rawDev = nullptr; size_t rawCap = 0;
     std::vector<mbgc_fasta_record_t> records;
     void openInputStage();
     void readG0(const std::string &path, std::vector<Contig> &out, uint64_t *fileSize);
-    void loadRound(uint32_t t0, uint32_t t1, RoundBatch &B);
+    // files [f0, f1) parsed into B; [nextF0, nextF1) into *nextB = what will be asked for next (prepared meanwhile)
+    void loadRound(uint32_t f0, uint32_t f1, RoundBatch &B, uint32_t nextF0 = 0, uint32_t nextF1 = 0, RoundBatch *nextB = nullptr);
 
     // hooks, MGMP.h:79-115
     virtual void initStreamsForG0Ref() = 0;
@@ -113,6 +125,10 @@ protected:
     virtual void noteTargetLoaded(uint32_t targetIdx, size_t matcherLoaderStartPos, size_t loadedRefLengthAfter) = 0;
     virtual void appendTargetStreams(uint32_t targetIdx) = 0;
     virtual void takeRoundStreams(uint32_t targetIdx, EmittedStreams &s) = 0;           // per-target stream append in round mode
+    // the same when the round's targets arrive in target order (the round loop's collection): a contig's streams straight
+    // from the handle's buffer to the collection's streams, then processAfterSequence / processAfterTarget's marks
+    virtual void appendContigInOrder(const swsem_streams_t &st) = 0;
+    virtual void endTargetInOrder() = 0;
     virtual const swsem_emit_params_t &emitParams() const = 0;
     virtual const std::vector<size_t> &loadedPositions() const = 0;
     virtual bool lazyMode() const = 0;
@@ -138,6 +154,8 @@ class MBGC_Encoder : public MultipleGenomeMatchingProcessor {
     void noteTargetLoaded(uint32_t targetIdx, size_t matcherLoaderStartPos, size_t loadedRefLengthAfter) override;   // :557-563
     void appendTargetStreams(uint32_t targetIdx) override;                              // :543-556
     void takeRoundStreams(uint32_t targetIdx, EmittedStreams &s) override;
+    void appendContigInOrder(const swsem_streams_t &st) override;
+    void endTargetInOrder() override;
     const swsem_emit_params_t &emitParams() const override { return params->emit; }
     const std::vector<size_t> &loadedPositions() const override { return refExtLoadedPosArr; }
     bool lazyMode() const override { return params->lazyDecompressionSupport; }

@@ -78,7 +78,9 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
         matcher->setEmitHostCopy(false);
         for (uint32_t q = 0; q < nRounds; q++) {
             rankRange(q, g, slots[q].t0, slots[q].t1);
-            loadRound(1 + slots[q].t0, 1 + slots[q].t1, slots[q]);
+            uint32_t n0, n1;
+            rankRange(q + 1, g, n0, n1);
+            loadRound(1 + slots[q].t0, 1 + slots[q].t1, slots[q], 1 + n0, 1 + n1, q + 1 < nRounds ? &slots[q + 1] : nullptr);
         }
     }
 
@@ -175,7 +177,9 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
         RoundBatch &B = slots[bench ? q : q % 3];
         if (!bench) {
             rankRange(q, g, B.t0, B.t1);
-            loadRound(1 + B.t0, 1 + B.t1, B);
+            uint32_t n0, n1;
+            rankRange(q + 1, g, n0, n1);
+            loadRound(1 + B.t0, 1 + B.t1, B, 1 + n0, 1 + n1, q + 1 < nRounds ? &slots[(q + 1) % 3] : nullptr);
         } else if ((int) q == params->benchWarmup) {
             if (prev.valid) { if (prev.onDevice) matcher->emitEnd(); collect(prev, false); prev.valid = false; }
             matcher->synchronize();

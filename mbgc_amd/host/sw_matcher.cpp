@@ -156,6 +156,8 @@ void SlidingWindowSparseEMMatcher::emitCounters(std::vector<uint64_t> &out, int 
     check(swsem_emit_counters(h, out.data()), "processMatches");
 }
 
+void SlidingWindowSparseEMMatcher::emitView(int k, swsem_streams_t &view) { check(swsem_emit_result(h, k, &view), "processMatches"); }
+
 void SlidingWindowSparseEMMatcher::emitEnd() { check(swsem_emit_batch_end(h), "processMatches"); }
 
 void SlidingWindowSparseEMMatcher::finalizeTargets(const std::vector<const uint8_t *> &extDev, const std::vector<uint64_t> &extLen,

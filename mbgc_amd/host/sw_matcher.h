@@ -85,6 +85,7 @@ public:
     void setEmitHostCopy(bool on);                                          // off: the streams stay in HBM until emitTake asks for them
     void emitSelect(bool previous);
     void emitTake(int k, EmittedStreams &out);                              // streams of contig k of the selected emission (waits for it)
+    void emitView(int k, swsem_streams_t &view);                            // the same without a copy: pointers into the handle's host buffer, valid until the next emission call
     // the selected emission as one packed device blob ((contig, stream) major; sizes[n*6]) and its counters without the bytes
     // (n*6: unmatchedChars, extensionsMatchedChars, extensionsMismatches, totalMatched, removedGapBreakingMatches, matches)
     uint64_t emitPack(uint8_t *dstDev, uint64_t cap, std::vector<uint64_t> *sizes, int n);
