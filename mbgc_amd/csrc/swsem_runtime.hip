@@ -652,7 +652,8 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         // Block chains are latency-bound and a launch lasts as long as its slowest wave: the blocks are sized so
         // that all of them are resident at once and there are as many as that allows.
         // Fewer, longer blocks leave wave slots empty; more of them run in two generations and lengthen the
-        // sequential stitch. At least 8 units (8192 positions), so that the warm-up stays a small part of a block.
+        // sequential stitch. At least 2 units: a small batch (one target of the sequential schedule) fills few wave slots
+        // whatever the block length, and then short chains are what is fast (1024 warm-up positions per 2048 of its own).
         uint64_t allUnits = 0;                          // in units of RBU positions
         for (int c = 0; c < n; c++) {
             const uint64_t len = offsets[c + 1] - offsets[c];
@@ -661,7 +662,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         h->chainsPerWave = (h->simt && !h->seqResolve && h->K <= K_MAX4) ? (uint32_t) GC : 1u;
         const uint64_t waves = h->chainsPerWave > 1 ? (uint64_t) h->waveSlots / RESOLVE_WAVES_PER_SIMD * RESOLVE4_WAVES_PER_SIMD : h->waveSlots;
         const uint64_t slots = std::max<uint64_t>(1, waves * h->chainsPerWave * 19 / 20);
-        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(64, std::max<uint64_t>(8, (allUnits + slots - 1) / slots));
+        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(64, std::max<uint64_t>(2, (allUnits + slots - 1) / slots));   // (a small batch — one target of the sequential schedule — runs short chains: it is their length that takes the time)
     }
     for (int c = 0; c < n; c++) {
         Contig &cg = h->contigs[c];
