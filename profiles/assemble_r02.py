@@ -19,8 +19,9 @@ def line(name):
 for src, dst in (("bench_full.json", "r02_bench_full_path.json"), ("bench_matcher.json", "r02_bench_matcher_only.json"),
                  ("bench_40bit.json", "r02_bench_40bit_sizing.json"), ("bench_one_chain_per_wave.json", "r02_bench_one_chain_per_wave.json"),
                  ("bench_from_host.json", "r02_bench_from_host.json"), ("bench_rocprof.json", "r02_bench_under_rocprof.json"),
-                 ("cpp_host.json", "r02_cpp_host_bench.json"), ("rcmatch.json", "r02_rcmatch_bench.json"), ("input_stage.json", "r02_input_stage.json")):
+                 ("cpp_end_to_end.json", "r02_cpp_host_end_to_end.json"), ("bench_n2_gloo.json", "r02_bench_two_ranks_one_gpu_gloo.json"), ("rcmatch.json", "r02_rcmatch_bench.json"), ("input_stage.json", "r02_input_stage.json")):
     json.dump(line(src), open(P + dst, "w"), indent=1)
+shutil.copy(O + "cpp_host.json", P + "r02_cpp_host_bench.json")            # two lines: the plain loop, the sharded loop with one rank over RCCL
 shutil.copy(O + "kernel_stats.csv", P + "r02_bench_kernel_stats.csv")
 shutil.copy(O + "timed.json", P + "r02_bench_timed_kernel_avgs.json")
 full = line("bench_full.json")
