@@ -275,6 +275,16 @@ def main():
     backend = os.environ.get("MBGC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # MBGC_ROUNDS_FORCE_EXCHANGE=1 (diagnostics): one rank, but through every collective of the N > 1 protocol — RCCL itself
+    # on a one-GPU box, and what the exchange costs a rank before a second GPU is there
+    forced = world == 1 and os.environ.get("MBGC_ROUNDS_FORCE_EXCHANGE", "0") == "1"
+    if forced:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                **({"device_id": dev} if backend == "nccl" else {}))
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -436,14 +446,16 @@ def main():
             "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps,
             "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
         }
-        if world > 1:
+        if world > 1 or forced:
             out["rccl_ranks_seen"] = dist.get_world_size()
             out["extension_allgathers_started_ahead"] = {"started": runner.pregathers[0], "used": runner.pregathers[1]}
             out["round_finalizes_queued_on_device_verdicts"] = {"tried": runner.spec_rounds[0], "applied": runner.spec_rounds[1]}
+        if runner.trace is not None:
+            out["host_ms_per_round"] = {k: round(v * 1e3 / (steps + warm), 3) for k, v in runner.trace.items()}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit, max_ref)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

@@ -30,6 +30,10 @@ const char *mbgc_xchg_last_error(void);
 /* RCCL: rank 0 makes two ids (bulk and control communicator) and gets them to the others by any means */
 int mbgc_xchg_unique_ids(uint8_t ids[2 * MBGC_XCHG_ID_BYTES]);
 int mbgc_xchg_create_rccl(mbgc_xchg_t **out, const uint8_t ids[2 * MBGC_XCHG_ID_BYTES], int rank, int world, int device);
+/* ranks that share a node may give the RCCL exchange a shared mapping as well (as for mbgc_xchg_create_hostmem): the small
+ * host-to-host exchanges (mbgc_xchg_allgather_i64) then go through it — a collective on the device would wait for compute
+ * units whenever the round's finalize holds them, and the host reading its result with it. Call on every rank, after create. */
+int mbgc_xchg_set_host_control(mbgc_xchg_t *x, void *shared, uint64_t sharedBytes);
 /* host shared memory: `shared` = a MAP_SHARED mapping of sharedBytes >= mbgc_xchg_hostmem_min_bytes(world), zero-filled
  * before the first rank is created, the same pages in every rank; larger mappings move more bytes per step */
 uint64_t mbgc_xchg_hostmem_min_bytes(int world);

@@ -198,6 +198,10 @@ int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out);
 void swsem_emit_set_host_copy(swsem_t *h, int on);
 int swsem_emit_unmatched(swsem_t *h, uint64_t *unmatched /* [n of the last swsem_emit_batch] */);
 int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *sizes, uint64_t *total);
+/* The same copy queued on `stream` (a hipStream_t; NULL = the handle's main stream) instead of waited for: the caller's
+ * consumer must be ordered behind it on that stream. For callers that must not block while the device is busy with the
+ * round's finalize (the copy would wait for compute units, and the host with it). */
+int swsem_emit_pack_dev_on(swsem_t *h, uint8_t *dst_dev, uint64_t cap, void *stream);
 /* the counters processMatches adds up (MBGC_Encoder.cpp:293-306), per contig of the selected emission, without its bytes:
  * unmatchedChars, extensionsMatchedChars, extensionsMismatches, totalMatched, removedGapBreakingMatches, matches. Waits
  * for the emission like swsem_emit_result. */

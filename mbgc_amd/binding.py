@@ -21,7 +21,7 @@ swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circula
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
-swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_emit_counters swsem_debug_copy_ref swsem_debug_write_ref swsem_debug_copy_ht
+swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_emit_pack_dev_on swsem_emit_counters swsem_debug_copy_ref swsem_debug_write_ref swsem_debug_copy_ht
 swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_download swsem_dev_copy swsem_decode_contigs_dev swsem_emit_verify""".split()
 
 
@@ -122,6 +122,8 @@ def lib():
         L.swsem_emit_set_host_copy.argtypes = [vp, ci]
         L.swsem_emit_set_host_copy.restype = None
         L.swsem_emit_pack_dev.argtypes = [vp, vp, u64, pu64, pu64]
+        L.swsem_emit_pack_dev_on.argtypes = [vp, vp, u64, vp]
+        L.swsem_emit_counters.argtypes = [vp, pu64]
         L.swsem_emit_unmatched.argtypes = [vp, pu64]
         L.swsem_emit_verify.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), pu64]
         L.swsem_decode_contigs_dev.argtypes = [vp, C.POINTER(EmitParams), ci, vp, pu64, C.POINTER(C.c_int64)]
@@ -355,7 +357,11 @@ class SlidingWindowSparseEMMatcher:
         _chk(lib().swsem_emit_pack_dev(self.h, None, 0, sizes.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(tot)))
         return sizes.reshape(n, 6), tot.value
 
-    def emit_pack_dev(self, dst_ptr, cap):
+    def emit_pack_dev(self, dst_ptr, cap, stream=None):
+        """stream: queue the copy there (0 = the handle's main stream) instead of waiting for it"""
+        if stream is not None:
+            _chk(lib().swsem_emit_pack_dev_on(self.h, dst_ptr, cap, C.c_void_p(stream)))
+            return None
         tot = C.c_uint64()
         _chk(lib().swsem_emit_pack_dev(self.h, dst_ptr, cap, None, C.byref(tot)))
         return tot.value

@@ -118,6 +118,14 @@ int mbgc_xchg_create_rccl(mbgc_xchg_t **out, const uint8_t ids[2 * MBGC_XCHG_ID_
     return 0;
 }
 
+int mbgc_xchg_set_host_control(mbgc_xchg_t *x, void *shared, uint64_t sharedBytes) {
+    if (!x || !shared || sharedBytes < mbgc_xchg_hostmem_min_bytes(x->world)) return fail("mbgc_xchg_set_host_control: bad arguments");
+    x->sh = (Shared *) shared;
+    x->area = (uint8_t *) shared + sizeof(Shared);
+    x->areaBytes = sharedBytes - sizeof(Shared);
+    return x->barrier();
+}
+
 uint64_t mbgc_xchg_hostmem_min_bytes(int world) { return sizeof(Shared) + (uint64_t) world * 4096; }
 
 int mbgc_xchg_create_hostmem(mbgc_xchg_t **out, void *shared, uint64_t sharedBytes, int rank, int world, int device) {
@@ -159,7 +167,7 @@ int mbgc_xchg_world(const mbgc_xchg_t *x) { return x->world; }
 
 int mbgc_xchg_allgather_i64(mbgc_xchg_t *x, const int64_t *mine, uint64_t k, int64_t *all) {
     if (k == 0) return 0;
-    if (x->rccl) {
+    if (x->rccl && !x->sh) {
         HIPX(hipSetDevice(x->device));
         if (x->ints(k * (x->world + 1))) return -1;
         memcpy(x->hInts, mine, k * sizeof(int64_t));

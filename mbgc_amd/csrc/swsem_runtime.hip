@@ -96,6 +96,7 @@ struct swsem {
     std::vector<InsertPiece> edgePieces;   // flush_inserts: the samples left to the launch behind the copies
     bool insertBeside = true;              // insertion hashes from the copies' sources, the copies run beside it (SWSEM_INSERT_BESIDE=0: one after the other)
     hipStream_t streamLoad = nullptr;      // ... on this stream
+    int prioLow = 0, prioHigh = 0;         // the device's stream priority range
     hipEvent_t evLoadFork = nullptr, evLoadDone = nullptr;
     std::vector<CopyPiece> pendingCopies;    // ... and its byte writes: device-to-device copies,
     std::vector<BytePiece> pendingBytes;     // then single bytes (separators), each list in program order
@@ -496,7 +497,9 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     const uint64_t *d = h->dTables.p;
     hipStream_t cs = h->stream;                                    // the copies' stream
     if (beside) {
-        if (!h->streamLoad && (hipStreamCreateWithFlags(&h->streamLoad, hipStreamNonBlocking) != hipSuccess ||
+        // (its own priority class: the runtime deals the streams of one class over a handful of hardware queues, and a copy
+        // that lands on the queue of the emission's second phase runs behind 2 ms of its kernels — seen in a kernel trace)
+        if (!h->streamLoad && (hipStreamCreateWithPriority(&h->streamLoad, hipStreamNonBlocking, h->prioHigh) != hipSuccess ||
                                hipEventCreateWithFlags(&h->evLoadFork, hipEventDisableTiming) != hipSuccess ||
                                hipEventCreateWithFlags(&h->evLoadDone, hipEventDisableTiming) != hipSuccess))
             return fail(SWSEM_EHIP, "hipStreamCreate failed");
@@ -852,6 +855,10 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     h->samplingPos = (uint64_t) k1;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     h->ownStream = true;
+    {
+        int least = 0, greatest = 0;                        // numerically: least >= greatest
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) { h->prioLow = least; h->prioHigh = greatest; }
+    }
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->slot[0].evDone, hipEventDisableTiming) != hipSuccess ||
@@ -1468,6 +1475,16 @@ int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *si
         HIPCHK(hipStreamSynchronize(h->stream3));
     }
     if (total) *total = E.packedBytes;
+    return SWSEM_OK;
+}
+
+int swsem_emit_pack_dev_on(swsem_t *h, uint8_t *dst_dev, uint64_t cap, void *stream) {
+    HIPCHK(hipSetDevice(h->device));
+    swsem::EmitSlot &E = h->sel();
+    { int e = end_slot(h, (int) (&E - h->slot)); if (e) return e; }       // (the emission has finished: its event was waited for)
+    if (!E.packedBytes) return SWSEM_OK;
+    if (!dst_dev || E.packedBytes > cap) return fail(SWSEM_EINVAL, "swsem_emit_pack_dev_on: buffer too small");
+    HIPCHK(hipMemcpyAsync(dst_dev, E.dEArena.p, E.packedBytes, hipMemcpyDeviceToDevice, stream ? (hipStream_t) stream : h->stream));
     return SWSEM_OK;
 }
 

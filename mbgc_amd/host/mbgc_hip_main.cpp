@@ -102,7 +102,8 @@ int main(int argc, char **argv) {
     size_t sharedBytes = 0;
     const bool explicitExchange = gpus > 1 || transport == "hostmem";
     if (explicitExchange || getenv("MBGC_HIP_EXCHANGE")) {
-        sharedBytes = sizeof(Bootstrap) + (transport == "hostmem" ? std::max<size_t>(shmMb << 20, mbgc_xchg_hostmem_min_bytes(gpus)) : 0);
+        sharedBytes = sizeof(Bootstrap) + (transport == "hostmem" ? std::max<size_t>(shmMb << 20, mbgc_xchg_hostmem_min_bytes(gpus))
+                                                                   : std::max<size_t>(1 << 20, mbgc_xchg_hostmem_min_bytes(gpus)));   // rccl: the hosts' control exchanges
         void *m = mmap(nullptr, sharedBytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);      // (zero-filled)
         if (m == MAP_FAILED) { perror("mmap"); return EXIT_FAILURE; }
         boot = g_boot = (Bootstrap *) m;
@@ -123,7 +124,8 @@ int main(int argc, char **argv) {
             } else {
                 while (!boot->idsReady.load() && !boot->failed.load()) usleep(1000);
             }
-            if (mbgc_xchg_create_rccl(&params.exchange, boot->ids, rank, gpus, params.device)) {
+            if (mbgc_xchg_create_rccl(&params.exchange, boot->ids, rank, gpus, params.device) ||
+                mbgc_xchg_set_host_control(params.exchange, (uint8_t *) m + sizeof(Bootstrap), sharedBytes - sizeof(Bootstrap))) {
                 fprintf(stderr, "exchange (rank %d): %s\n", rank, mbgc_xchg_last_error());
                 return EXIT_FAILURE;
             }

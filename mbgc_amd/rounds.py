@@ -12,6 +12,7 @@ feeds the (unchanged, host-side) PPMd/LZMA backend: RCCL over xGMI on GPUs, gloo
 PyTorch is plumbing only: device buffers, the process group and the collectives."""
 import contextlib
 import os
+import time
 
 import numpy as np
 import torch
@@ -53,6 +54,21 @@ class RoundRunner:
                  policy=None, keep_streams=True):
         self.m, self.rank, self.world, self.group = matcher, rank, world, group
         self.device = torch.device(device)
+        # the exchange path is taken with several ranks — or with one, on request (MBGC_ROUNDS_FORCE_EXCHANGE=1): every
+        # collective of the protocol then runs, over the backend at hand, with this rank as the only party (how RCCL itself
+        # is exercised on a one-GPU box)
+        self.multi = world > 1 or os.environ.get("MBGC_ROUNDS_FORCE_EXCHANGE", "0") == "1"
+        self.trace = {} if os.environ.get("MBGC_ROUNDS_TRACE") else None      # host seconds per part of run_round (diagnostics)
+        # The handful of numbers a round's ranks exchange travel between the HOSTS (a gloo group over loopback: the ranks of
+        # this protocol share a node): a collective on the device would have to wait for compute units whenever the round's
+        # finalize holds them, and the host reading its result with it (1.1 ms per round, measured with one rank).
+        self._ctl_group, self._ctl_dev = group, self.device
+        if self.multi and self.device.type == "cuda" and os.environ.get("MBGC_ROUNDS_HOST_CONTROL", "1") != "0":
+            import torch.distributed as dist
+            if dist.get_backend(group) != "gloo":
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                self._ctl_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend="gloo")
+            self._ctl_dev = torch.device("cpu")
         # The protocol mixes the handle's launches with torch operations on the same buffers (reverse complements
         # written by the handle and concatenated by torch, concatenations read by the handle's copies): both must
         # run on one stream, or they race.
@@ -79,6 +95,8 @@ class RoundRunner:
         self._next_key = None                        # the buffer this rank announced for the next round (see _post_announce)
         self._ann = None                             # the announcement exchange in flight
         self._ctl = None                             # its stream
+        self._bulk = None                            # the stream early extension all-gathers are issued from
+        self._ev_tops = [None, None]                 # main-stream events: where the last round / this round began
         self._gate = self._gate_host = self._gate_ev = None     # the speculative finalize's word, several ranks (see _world_speculation)
         self.spec_rounds = [0, 0]                    # several ranks: speculative finalizes tried / applied (diagnostics)
         if self.p is not None:
@@ -91,7 +109,7 @@ class RoundRunner:
     # ---- exchange -----------------------------------------------------------------------------
     def _allgather_bytes(self, local):
         """local: 1-D uint8 tensor on self.device -> list (by rank) of 1-D uint8 tensors."""
-        if self.world == 1:
+        if not self.multi:
             return [local]
         import torch.distributed as dist
         n = torch.tensor([local.numel()], dtype=torch.int64, device=self.device)
@@ -106,17 +124,30 @@ class RoundRunner:
         return [out[r * mx: r * mx + sizes[r]] for r in range(self.world)]
 
     def _allgather_ints(self, vals, fixed=False):
-        """fixed: every rank is known to pass the same number of values (one collective instead of sizes + data)"""
-        t = torch.tensor(list(vals), dtype=torch.int64, device=self.device)
-        if fixed and self.world > 1:
-            import torch.distributed as dist
-            out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=self.device)
-            dist.all_gather_into_tensor(out, t, group=self.group)
-            flat = out.tolist()
+        """fixed: every rank is known to pass the same number of values (one collective instead of sizes + data). The
+        values come from the host and go back to it: over the control group (host to host) when there is one, else on the
+        side stream, so that reading the result waits for this exchange alone and not for what the main stream holds."""
+        import torch.distributed as dist
+        with self._side():
+            t = torch.tensor(list(vals), dtype=torch.int64, device=self._ctl_dev)
+            if not self.multi:
+                return [t.tolist()]
             k = t.numel()
-            return [flat[r * k: (r + 1) * k] for r in range(self.world)]
-        parts = self._allgather_bytes(t.view(torch.uint8))
-        return [p.view(torch.int64).tolist() for p in parts]
+            if not fixed:
+                n = torch.tensor([k], dtype=torch.int64, device=self._ctl_dev)
+                ns = torch.empty(self.world, dtype=torch.int64, device=self._ctl_dev)
+                dist.all_gather_into_tensor(ns, n, group=self._ctl_group)
+                ns = ns.tolist()
+                k = max(max(ns), 1)
+                pad = torch.zeros(k, dtype=torch.int64, device=self._ctl_dev)
+                pad[: t.numel()] = t
+                t = pad
+            else:
+                ns = [k] * self.world
+            out = torch.empty(self.world * k, dtype=torch.int64, device=self._ctl_dev)
+            dist.all_gather_into_tensor(out, t, group=self._ctl_group)
+            flat = out.tolist()
+            return [flat[r * k: r * k + ns[r]] for r in range(self.world)]
 
     def _side(self):
         """the stream of the small exchanges that must not wait for what the main stream has queued"""
@@ -132,7 +163,7 @@ class RoundRunner:
         its extension all-gather and its speculative finalize are set up from these numbers. Every rank takes part in
         every round (-1 = nothing to say); next_batch = (buffer, offsets[, target of every contig])."""
         self._next_key = None
-        if self.world == 1:
+        if not self.multi:
             return
         import torch.distributed as dist
         vals = [-1] * (2 + T)
@@ -148,9 +179,9 @@ class RoundRunner:
                         lens[t] += int(no[c + 1]) - int(no[c])
                     vals[1], vals[2: 2 + tn] = tn, lens
         with self._side():
-            t = torch.tensor(vals, dtype=torch.int64, device=self.device)
-            out = torch.empty(self.world * len(vals), dtype=torch.int64, device=self.device)
-            work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+            t = torch.tensor(vals, dtype=torch.int64, device=self._ctl_dev)
+            out = torch.empty(self.world * len(vals), dtype=torch.int64, device=self._ctl_dev)
+            work = dist.all_gather_into_tensor(out, t, group=self._ctl_group, async_op=True)
         self._ann = (work, out, t, len(vals))
 
     def _take_announce(self):
@@ -173,7 +204,7 @@ class RoundRunner:
         round's decisions come out the same on every rank, and falls back to the ordinary exchange otherwise."""
         self._pre = None
         announced = [a[0] for a in ann] if ann is not None and min(a[0] for a in ann) >= 0 else None
-        if self.world == 1 or not self._gpred or self.p is None or os.environ.get("MBGC_ROUNDS_PREGATHER", "1") == "0":
+        if not self.multi or not self._gpred or self.p is None or os.environ.get("MBGC_ROUNDS_PREGATHER", "1") == "0":
             return
         ncont = len(offsets) - 1
         lens = None
@@ -207,14 +238,29 @@ class RoundRunner:
         mx = max(max(sizes), 1)
         if announced is None:
             lens = None
-        if qbuf.numel() == mx and not poisoned:
-            pad = qbuf
-        else:
-            pad = torch.zeros(mx, dtype=torch.uint8, device=self.device)
-            if not poisoned:
-                pad[: qbuf.numel()] = qbuf
-        out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
-        work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
+        # A buffer that was named a round ago existed then: its all-gather need not queue behind what the main stream
+        # holds now (the last round's finalize) — it is issued from a stream that only waits for the point where the last
+        # round began, and runs beside that finalize and this round's match-finding from the start.
+        early = (self.device.type == "cuda" and announced is not None and not poisoned and self._ev_tops[0] is not None and
+                 os.environ.get("MBGC_ROUNDS_EARLY_GATHER", "1") != "0")
+        if early:
+            if self._bulk is None:
+                self._bulk = torch.cuda.Stream(self.device)
+            self._bulk.wait_event(self._ev_tops[0])
+        with (torch.cuda.stream(self._bulk) if early else contextlib.nullcontext()):
+            if qbuf.numel() == mx and not poisoned:
+                pad = qbuf
+            else:
+                pad = torch.zeros(mx, dtype=torch.uint8, device=self.device)
+                if not poisoned:
+                    pad[: qbuf.numel()] = qbuf
+            out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
+            work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
+        if early:                                       # (allocated under the side stream, consumed on the main one)
+            main = torch.cuda.current_stream(self.device)
+            out.record_stream(main)
+            if pad is not qbuf:
+                pad.record_stream(main)
         self._pre = dict(work=work, out=out, pad=pad, mx=mx, sizes=sizes, poisoned=poisoned, lens=lens)
         self.pregathers[0] += 1
 
@@ -233,8 +279,16 @@ class RoundRunner:
         ntot = T * self.world
         first = self.targets_done                   # global index of the round's first target
         locks = [m.acquire_lock() for _ in range(ntot)]                     # MGMP.cpp:353-358
+        if self.multi and self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()                                 # "this round begins here" on the main stream (see _pregather)
+            self._ev_tops = [self._ev_tops[1], ev]
+        tr = self.trace
+        t0 = time.perf_counter() if tr is not None else 0
         self._pregather(qbuf, offsets, targets, T, self._take_announce())
         self._post_announce(next_batch, T)
+        if tr is not None:
+            tr["top"] = tr.get("top", 0) + time.perf_counter() - t0
         lock_of = [locks[self.rank * T + targets[c]] for c in range(ncont)]
         pending = list(range(ncont))                # contigs still to be matched + emitted
         counts = np.zeros(ncont, dtype=np.uint64)
@@ -247,8 +301,12 @@ class RoundRunner:
         spec_applied = False
         while True:
             if pending:
+                t0 = time.perf_counter() if tr is not None else 0
                 self._match(qbuf, [(int(offsets[c]), int(offsets[c + 1])) for c in pending],
                             [lock_of[c] for c in pending], min_len)
+                if tr is not None:
+                    t1 = time.perf_counter()
+                    tr["match"] = tr.get("match", 0) + t1 - t0
                 spec_applied = False
                 if self.p is not None:
                     tgt = [first + self.rank * T + targets[c] for c in pending]
@@ -282,6 +340,8 @@ class RoundRunner:
                         m.emit_batch_begin(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
                                            [self.targets_done + finalized] * len(pending), tgt, self.loaded, n=len(pending))
                     un = m.emit_unmatched(len(pending))
+                    if tr is not None:
+                        tr["emit_begin"] = tr.get("emit_begin", 0) + time.perf_counter() - t1
                     emitted_here = True
                 else:
                     un = [int(offsets[c + 1] - offsets[c]) for c in pending]     # matcher only: always extend
@@ -301,9 +361,9 @@ class RoundRunner:
             # "discard, wait until the earlier targets are loaded, retry")
             first_skip_local = min([self.rank * T + targets[c] for c in skipped_local], default=ntot)
             merged = None
-            if self.world > 1 and first_pass and spec_applied:
+            if self.multi and first_pass and spec_applied:
                 first_skip = ntot                   # every rank's pass 1 came out as predicted: there is nothing to tell
-            elif self.world > 1 and first_pass:
+            elif self.multi and first_pass:
                 # first pass over the whole round: the skip index travels together with what this rank would load if
                 # nobody skips (one exchange instead of two on the path between pass 1 and the round's finalize)
                 if skipped_local:
@@ -315,7 +375,7 @@ class RoundRunner:
                 first_skip = min(v[0] for v in got)
                 if first_skip == ntot:
                     merged = (pieces, [v[1: 1 + T] for v in got], [v[-1] for v in got])
-            elif self.world > 1:
+            elif self.multi:
                 first_skip = min(x[0] for x in self._allgather_ints([first_skip_local], fixed=True))
             else:
                 first_skip = first_skip_local
@@ -338,7 +398,10 @@ class RoundRunner:
             # the previous round's streams: the second phase of its emission ran beside everything above (two
             # emissions may be in flight) and is collected only now, with this round's finalize already queued
             if self._deferred is not None:
+                t0 = time.perf_counter() if tr is not None else 0
                 self.flush(previous=self.p is not None and emitted_here)
+                if tr is not None:
+                    tr["flush"] = tr.get("flush", 0) + time.perf_counter() - t0
             if finalized >= ntot:
                 break
             # retry: the skipping contig itself, and every contig of the targets after it
@@ -367,12 +430,16 @@ class RoundRunner:
                 self._wait_gathers()
             return
         packs, last, targets, T, offsets, _ = d
+        tr = self.trace
+        t0 = time.perf_counter() if tr is not None else 0
         if last is not None:
             if previous:
                 self.m.emit_select(True)
-            packs.append(self._pack(*last, reuse=(self.world == 1 and not packs)))
+            packs.append(self._pack(*last, reuse=(not self.multi and not packs)))
             if previous:
                 self.m.emit_select(False)
+        if tr is not None:
+            tr["flush.pack"] = tr.get("flush.pack", 0) + time.perf_counter() - t0
         self._collect_streams(packs, targets, T, offsets)
         if not previous:
             self._wait_gathers()
@@ -394,7 +461,7 @@ class RoundRunner:
 
     def _pack(self, ks, cs, n_emitted, reuse=False):
         sizes, total = self.m.emit_pack_sizes(n_emitted)
-        if self.world == 1 and not self.keep_streams:
+        if not self.multi and not self.keep_streams:
             # nobody takes the bytes over: they stay where the emission packed them (the handle's arena), only
             # their sizes are accounted
             return dict(cs=cs, ks=ks, sizes=sizes, starts=None, buf=None)
@@ -407,7 +474,12 @@ class RoundRunner:
             buf = self._pack_buf
         else:
             buf = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
-        self.m.emit_pack_dev(buf.data_ptr(), buf.numel())
+        if self.multi and self.device.type == "cuda":
+            # queued on the main stream, where the gather that consumes it is ordered: a copy waited for here would wait for
+            # compute units while the round's finalize holds them, and the host with it
+            self.m.emit_pack_dev(buf.data_ptr(), buf.numel(), stream=torch.cuda.current_stream(self.device).cuda_stream)
+        else:
+            self.m.emit_pack_dev(buf.data_ptr(), buf.numel())
         starts = np.zeros(n_emitted * 6 + 1, dtype=np.int64)
         starts[1:] = np.cumsum(sizes.reshape(-1))
         return dict(cs=cs, ks=ks, sizes=sizes, starts=starts, buf=buf)
@@ -424,7 +496,7 @@ class RoundRunner:
         Returns (pieces, whole): per target (device pointer, bytes, tensor keeping them alive or None, offset in qbuf or -1);
         whole = the extensions are exactly this rank's queries, target after target (what _pregather assumed)."""
         m = self.m
-        my = [t for t in range(lo, hi) if t // T == self.rank] if self.world > 1 else range(lo, hi)
+        my = [t for t in range(lo, hi) if t // T == self.rank] if self.multi else range(lo, hi)
         by_target = {}
         for c, lt in enumerate(targets):
             by_target.setdefault(lt, []).append(c)
@@ -448,7 +520,7 @@ class RoundRunner:
             else:                                   # several strings of one target are loaded as one text
                 ext = torch.cat([x[2] if x[2] is not None else qbuf[x[3]: x[3] + x[1]] for x in parts])
                 pieces.append((ext.data_ptr(), ext.numel(), ext, -1))
-        whole = (self.world > 1 and lo == 0 and hi == T * self.world and len(pieces) == T and
+        whole = (self.multi and lo == 0 and hi == T * self.world and len(pieces) == T and
                  all(x[2] is None and x[1] > 0 for x in pieces) and sum(x[1] for x in pieces) == qbuf.numel() and
                  all(pieces[i][3] + pieces[i][1] == pieces[i + 1][3] for i in range(len(pieces) - 1)) and pieces[0][3] == 0)
         if self._pre is not None and self._pre.get("poisoned"):
@@ -467,7 +539,7 @@ class RoundRunner:
             pieces, whole = self._build_pieces(qbuf, offsets, targets, T, unmatched, lo, hi)
         # finalize_targets returns with its copies queued: their sources must outlive this function
         self._keep.extend(x[2] for x in pieces if x[2] is not None)
-        if self.world == 1:
+        if not self.multi:
             self._finalize_many([x[0] for x in pieces], [x[1] for x in pieces], [locks[t] for t in range(lo, hi)])
             return
         whole_round = lo == 0 and hi == T * self.world                                     # then: T targets on every rank
@@ -505,7 +577,7 @@ class RoundRunner:
         """(ext pointers, ext lengths) per target under the prediction, or None when this emission cannot carry a
         speculative finalize: not the whole round on a single GPU, no uniform prediction yet, or targets whose
         contigs are not one contiguous span of qbuf."""
-        if (self.world != 1 or self._pred_ext is None or finalized or len(pending) != ncont or
+        if (self.multi or self._pred_ext is None or finalized or len(pending) != ncont or
                 not hasattr(self.m, "emit_batch_begin_spec")):
             return None
         ptrs, lens, base = [0] * T, [0] * T, qbuf.data_ptr()
@@ -530,7 +602,7 @@ class RoundRunner:
         the conditions are facts every rank holds, so that all of them enter the verdict's reduction or none does (a
         rank whose own buffer is not what it announced takes part with a veto)."""
         pre = self._pre
-        if self.world == 1 or pre is None or pre["lens"] is None or not hasattr(self.m, "emit_batch_begin_spec"):
+        if not self.multi or pre is None or pre["lens"] is None or not hasattr(self.m, "emit_batch_begin_spec"):
             return None
         if self._gate is None:
             self._gate = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -568,7 +640,7 @@ class RoundRunner:
 
     def _learn(self, offsets, unmatched, skipped):
         """prediction for the next round: what every contig of this one decided, if they all decided alike"""
-        if self.p is None or self.world != 1:
+        if self.p is None or self.multi:
             return
         ext, rc = set(), False
         for c, un in enumerate(unmatched):
@@ -605,7 +677,7 @@ class RoundRunner:
 
     def _collect_streams(self, packs, targets, T, offsets):
         """per-target stream merge in target order on rank 0 (MBGC_Encoder.cpp:542-556)."""
-        if self.world == 1 and not self.keep_streams:
+        if not self.multi and not self.keep_streams:
             self.stream_bytes += sum(int(pk["sizes"][pk["ks"]].sum()) for pk in packs if pk["ks"])
             return
         # order this rank's emitted contigs by contig index, pack their six streams into one tensor
@@ -623,11 +695,14 @@ class RoundRunner:
             local = packs[0]["buf"][: int(packs[0]["starts"][-1])]     # one emission, nothing dropped: already packed in order
         else:
             local = torch.cat(chunks) if chunks else torch.empty(0, dtype=torch.uint8, device=self.device)
-        if self.world > 1:
+        if self.multi:
             # one exchange of the per-contig sizes, which also carries the byte count the big gather needs; the gather
             # itself is asynchronous unless this rank wants the bytes now (it is waited for at the next collection)
             import torch.distributed as dist
+            t0 = time.perf_counter() if self.trace is not None else 0
             all_meta = self._allgather_ints(meta + [int(local.numel()), -1])
+            if self.trace is not None:
+                self.trace["flush.meta"] = self.trace.get("flush.meta", 0) + time.perf_counter() - t0
             sizes = [m_[-2] for m_ in all_meta]
             all_meta = [m_[:-2] + [-1] for m_ in all_meta]
             self._wait_gathers()

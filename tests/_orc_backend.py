@@ -110,7 +110,7 @@ class OracleDeviceMatcher:
                 sizes[k] = [len(em.stream(i)) for i in range(6)]
         return sizes, int(sizes.sum())
 
-    def emit_pack_dev(self, dst, cap):
+    def emit_pack_dev(self, dst, cap, stream=None):
         blob = b"".join(em.stream(i) for un, em in self._selected() if un != _orc.SKIPPED for i in range(6))
         assert len(blob) <= cap
         if blob:
