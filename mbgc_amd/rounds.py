@@ -12,6 +12,7 @@ feeds the (unchanged, host-side) PPMd/LZMA backend: RCCL over xGMI on GPUs, gloo
 PyTorch is plumbing only: device buffers, the process group and the collectives."""
 import contextlib
 import os
+import sys
 import time
 
 import numpy as np
@@ -65,10 +66,14 @@ class RoundRunner:
         self._ctl_group, self._ctl_dev = group, self.device
         if self.multi and self.device.type == "cuda" and os.environ.get("MBGC_ROUNDS_HOST_CONTROL", "1") != "0":
             import torch.distributed as dist
-            if dist.get_backend(group) != "gloo":
-                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-                self._ctl_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend="gloo")
-            self._ctl_dev = torch.device("cpu")
+            try:
+                if dist.get_backend(group) != "gloo":
+                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                    self._ctl_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend="gloo")
+                self._ctl_dev = torch.device("cpu")
+            except Exception as e:                   # (no host-side group to be had: the device-side exchanges still work)
+                print("mbgc_amd.rounds: no gloo control group (%s); small exchanges stay on the device" % e, file=sys.stderr)
+                self._ctl_group, self._ctl_dev = group, self.device
         # The protocol mixes the handle's launches with torch operations on the same buffers (reverse complements
         # written by the handle and concatenated by torch, concatenations read by the handle's copies): both must
         # run on one stream, or they race.
