@@ -82,11 +82,15 @@ def test_single_process_runner_equals_reference_loop(div, cpt):
     assert m.loaded_ref_length() == loaded and np.array_equal(m.ht(), ht)
 
 
-def _worker(rank, world, port, outdir, div, cpt, announce=0, n=9):
+def _worker_n(rank, world, port, outdir, div, per_rank, announce, n):
+    _worker(rank, world, port, outdir, div, 1, announce, n, per_rank)
+
+
+def _worker(rank, world, port, outdir, div, cpt, announce=0, n=9, per_rank=2):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     gs = collection(n, 60_000, div, seed=17)
-    runner, m = run_rank(rank, world, gs, 2, cpt, announce=announce)
+    runner, m = run_rank(rank, world, gs, per_rank, cpt, announce=announce)
     np.save(os.path.join(outdir, "ht%d.npy" % rank), m.ht())
     open(os.path.join(outdir, "pregathers%d" % rank), "w").write("%d %d" % tuple(runner.pregathers))
     open(os.path.join(outdir, "spec%d" % rank), "w").write("%d %d" % tuple(runner.spec_rounds))
@@ -155,3 +159,26 @@ def test_world_size_2_gloo_with_announced_buffers(tmp_path, announce):
         assert sp[0] == "2 0", sp                      # tried with rank 1's veto: applied on neither rank
         # round 2: started, found poisoned, everybody falls back — and nobody predicts for round 3; round 4: the same again
         assert (started, used) == (2, 0)
+
+
+@pytest.mark.parametrize("world,per_rank,n,div,announce", [(3, 2, 13, 0.002, 1), (4, 1, 13, 0.06, 0), (3, 1, 10, 0.012, 1)])
+def test_more_ranks_gloo(tmp_path, world, per_rank, n, div, announce):
+    """3 and 4 ranks (rank-major target order inside a round, the veto-free speculative path with three parties, retries
+    that cut a round between two ranks) == one process with rounds of world x per_rank"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_n, args=(world, port, str(tmp_path), div, per_rank, announce, n), nprocs=world, join=True)
+    gs = collection(n, 60_000, div, seed=17)
+    res, ht, _ = reference_result(gs, world * per_rank, 1)
+    for k, v in res["streams"].items():
+        assert (tmp_path / k).read_bytes() == v, k
+    assert (tmp_path / "locks").read_bytes() == res["locks"]
+    assert (tmp_path / "refext").read_bytes() == res["refExtSize"]
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("ht%d.npy" % r)), ht), r
+    sp = [(tmp_path / ("spec%d" % r)).read_text() for r in range(world)]
+    assert len(set(sp)) == 1
+    if div == 0.002:
+        assert int(sp[0].split()[1]) >= 1, sp
