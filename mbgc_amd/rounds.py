@@ -225,7 +225,7 @@ class RoundRunner:
             poisoned = not usable or self._next_key != (qbuf.data_ptr(), qbuf.numel()) or qbuf.numel() != sizes[self.rank]
             # every rank's bytes per target, if all of them named T targets that add up to their buffers: what the
             # speculative finalize of the round needs (_world_speculation)
-            if all(a[1] is not None and len(a[1]) == T and sum(a[1]) == a[0] for a in ann):
+            if all(a[1] is not None and len(a[1]) == T and sum(a[1]) == a[0] and min(a[1], default=0) > 0 for a in ann):   # (a target without bytes: its rank may have nothing to emit, and then cannot take part)
                 lens = [a[1] for a in ann]
                 mine = [0] * T
                 for c, t in enumerate(targets):

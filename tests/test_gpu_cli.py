@@ -210,3 +210,40 @@ def test_backend_section_is_read_back_by_the_reference(tmp_path):
             assert got == bytes([128, 8] * 3)                           # one pair per file in the -t1 schedule (MGMP.cpp:252-255)
         else:
             assert got == (tmp_path / ("lm." + name)).read_bytes(), name
+
+
+def test_rounds_of_a_larger_collection_equal_the_oracle_loop(tmp_path):
+    """41 files of 1 Mbp in rounds of 8 through the pipelined host (read-ahead thread, three round slots, two emissions in
+    flight, the speculative finalize from the third round on) against the oracle-driven reference loop"""
+    base = synth.base_codes(1_000_000, 58)
+    gs = [synth.genome(base, i, 0.006) for i in range(41)]
+    paths = []
+    for i, g in enumerate(gs):
+        p = tmp_path / ("g%02d.fa" % i)
+        p.write_bytes(synth.fasta_bytes(g, i))
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    run_tool(["c", "-R", "8", "list.txt", "out"], str(tmp_path))
+    lim, _ = _driver.ref_length_limit(len(gs), gs[0].size)
+    o = _orc.OracleMatcher(lim)
+    res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], 8)
+    got = {k: (tmp_path / ("out." + k)).read_bytes() for k in ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags", "locksPos", "refExtSize")}
+    assert got["literals"] == gs[0].tobytes() + b"\xa2" + res["streams"]["literals"]
+    for k in ("mapOff", "mapOff5th", "mapLen", "gapDelta", "flags"):
+        assert got[k] == res["streams"][k], k
+    assert got["locksPos"] == res["locks"] and got["refExtSize"] == res["refExtSize"]
+    o.close()
+
+
+def test_a_missing_file_in_a_later_round_is_reported(tmp_path):
+    """the read-ahead thread meets a file that does not exist: the tool says so (MGMP.cpp:7-14's message) and fails"""
+    base = synth.base_codes(30_000, 59)
+    paths = []
+    for i in range(7):
+        p = tmp_path / ("g%02d.fa" % i)
+        p.write_bytes(synth.fasta_bytes(synth.genome(base, i, 0.01), i))
+        paths.append(str(p))
+    paths.insert(5, str(tmp_path / "nowhere.fa"))
+    (tmp_path / "l.txt").write_text("\n".join(paths) + "\n")
+    r = subprocess.run([TOOL, "c", "-R", "2", "l.txt", "o"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "cannot open file" in r.stderr and "nowhere.fa" in r.stderr, r.stderr
