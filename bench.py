@@ -445,6 +445,7 @@ def main():
             "ms_per_step_after_wrap": round(float(np.mean(post)), 4) if post else None, "steps_after_wrap": len(post),
             "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps,
             "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
+            **({"step_ms": [round(t, 3) for t in step_ms]} if os.environ.get("MBGC_BENCH_STEP_MS") else {}),
         }
         if world > 1 or forced:
             out["rccl_ranks_seen"] = dist.get_world_size()

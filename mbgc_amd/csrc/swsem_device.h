@@ -41,6 +41,10 @@ struct RefView {
     int fpCheck;              // fingerprints may be used to reject entries (see ht_value): 0 no, 1 every entry is as hashed, 2 by epoch
     uint32_t eCur, ePrev;     // first epoch of the current / of the previous lap of the circular buffer (fpCheck == 2)
     uint32_t curMax, prevMin; // entry values (position >> k1ord) up to curMax lie wholly below the loading position, from prevMin on at or above it
+    // per sampling slot (position >> k1ord): the lap (as lap_tag) in which the slot was last sampled ON the grid, 0: never, or
+    // its K-mer's bytes changed afterwards. tagCur / tagPrev: the tags of the current / previous lap (0: there is none).
+    const uint16_t *tags;
+    uint32_t tagCur, tagPrev;
     int K, k1ord, skipMargin;
     uint32_t minLen;
 };
@@ -64,15 +68,25 @@ __device__ __forceinline__ uint32_t hash_step(uint32_t h, uint32_t k, uint32_t j
     return (h ^ (k + j)) * 171717u;
 }
 
+// The fingerprint's own hash of the same dwords (fp_step per dword from FP_SEED; its top F bits are the fingerprint): the
+// reference's hash has 32 bits and the bucket index takes 27-29 of them, which would leave a fingerprint of 3-5 bits — and
+// a visit of the reference for every 8th-32nd lookup that finds a foreign K-mer's entry, more with every lap as the table
+// fills (measured: the step grew from 3.3 to 4.4 ms over three laps). A function of the K-mer's bytes like the other one.
+constexpr uint32_t FP_SEED = 0x811C9DC5u;
+__device__ __forceinline__ uint32_t fp_step(uint32_t f, uint32_t k) {
+    return (f ^ k) * 0x9E3779B1u;
+}
+
 // Table entry: (epoch << (32 + F)) | (position >> k1ord) << F | fingerprint, F = fpBits. atomicMax on it
 // gives the reference's last-writer-wins (later load phases carry larger epochs, later positions of one
-// phase larger values). The fingerprint is the top F bits of the K-mer's 32-bit hash — the bucket index
-// is its low bits — so an entry left by a different K-mer is told apart without touching the reference
+// phase larger values). The fingerprint is the top F bits of the K-mer's second hash (fp_step) — the bucket index
+// is the low bits of the first — so an entry left by a different K-mer is told apart without touching the reference
 // (the reference finds out with memcmp, .cpp:298, and moves on without any other effect). That is exact
 // as long as the bytes an entry was hashed from are still the bytes at its position, i.e. until the
 // buffer wraps (or a separator replaces an already hashed byte): from then on a stale entry may point
 // at new text that does equal the query, the reference would match it, and the filter is switched off
 // (fpCheck = 0; entries keep their layout).
+// (`hash` here and in ht_value: the K-mer's SECOND hash)
 __device__ __forceinline__ ht_entry ht_key(uint32_t epoch, uint32_t value, uint32_t hash, int fpBits) {
     return ((ht_entry) epoch << (32 + fpBits)) | ((ht_entry) value << fpBits) | (ht_entry) (fpBits ? hash >> (32 - fpBits) : 0u);
 }
@@ -99,6 +113,19 @@ __device__ __forceinline__ uint32_t ht_value(const RefView &v, ht_entry e, uint3
         if (trusted) return 0u;
     }
     return (uint32_t) (e >> v.fpBits);
+}
+
+// An untrusted entry (stale: its text has been overwritten since it was written) must be followed — the reference compares
+// bytes — unless the comparison is known to fail: when the slot it points at was sampled again, on the grid, by the very
+// load that wrote the text now standing there, that sample went to the bucket of the NEW K-mer with a newer epoch; had that
+// been this bucket, the stale entry would be gone. So the text there hashes elsewhere, hence differs from every K-mer that
+// hashes here, and memcmp (.cpp:298) fails without any other effect. lap_want gives the tag such a sampling left: the
+// current lap's for slots wholly below the loading position, the previous lap's for slots at or above it, none for a slot
+// that straddles it. (After many laps about 40 % of the buckets hold stale entries: each costs one 2-byte lookup here
+// instead of a 256-byte visit.)
+__host__ __device__ __forceinline__ uint32_t lap_tag(int lap) { return 1u + (uint32_t) lap % 65535u; }
+__device__ __forceinline__ uint32_t lap_want(const RefView &v, uint32_t val) {
+    return val <= v.curMax ? v.tagCur : (val >= v.prevMin ? v.tagPrev : 0u);
 }
 
 // window test of SlidingWindowSparseEMMatcher.cpp:212-222. Returns false when the entry is rejected.

@@ -93,16 +93,18 @@ __global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restri
 // (the tail runs after the main loop on the CPU, so it wins collisions against it).
 __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                 uint64_t S, uint64_t nMain, uint64_t T, uint64_t nTail, int k1,
-                                                int k1ord, int K, uint32_t mask, uint32_t epoch, int fpBits) {
+                                                int k1ord, int K, uint32_t mask, uint32_t epoch, int fpBits,
+                                                uint16_t *__restrict__ tags, uint32_t tag) {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nMain + nTail) return;
     const bool tail = t >= nMain;
     const uint64_t p = tail ? T + (t - nMain) * (uint64_t) k1 : S + t * (uint64_t) k1;
+    if (tags && (p & ((1ull << k1ord) - 1)) == 0) tags[p >> k1ord] = (uint16_t) tag;      // sampled on the grid in this lap (lap_want)
     const uint8_t *s = ref + p;
-    uint32_t h = (uint32_t) K;
+    uint32_t h = (uint32_t) K, f = FP_SEED;
     const int nw = K / 4;
-    for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
-    const ht_entry key = ht_key(epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
+    for (int j = 0; j < nw; j++) { const uint32_t w = ld_u32(s + 4 * j); h = hash_step(h, w, (uint32_t) j); f = fp_step(f, w); }
+    const ht_entry key = ht_key(epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), f, fpBits);
     atomicMax(&ht[h & mask], key);
 }
 
@@ -115,12 +117,12 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
 // itself, so the insertion need not wait for the copy (which runs beside it on a stream of its own); the samples whose
 // window reaches outside [lo, hi) — into the previous text, a separator — are left to a small launch over the buffer
 // once the copy has landed (the host lists them as runs of their own).
-struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, pad; const uint8_t *src; uint64_t lo, hi; };
+struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, tag; const uint8_t *src; uint64_t lo, hi; };   // tag: lap_tag of the lap being loaded
 template<bool FROM_SRC>
 __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                       const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first,
                                                       int np, int k1, int k1ord, int K, uint32_t mask, int fpBits,
-                                                      const uint32_t *__restrict__ gate) {
+                                                      const uint32_t *__restrict__ gate, uint16_t *__restrict__ tags) {
     if (gate && *gate == 0) return;
     const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g0 >= first[np]) return;
@@ -139,10 +141,11 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
         if (!pc.src || p < pc.lo || p + (uint64_t) K > pc.hi) return;
         s = pc.src + (p - pc.lo);
     }
-    uint32_t h = (uint32_t) K;
+    if (tags && (p & ((1ull << k1ord) - 1)) == 0) tags[p >> k1ord] = (uint16_t) pc.tag;    // sampled on the grid in this lap (lap_want)
+    uint32_t h = (uint32_t) K, f = FP_SEED;
     const int nw = K / 4;
-    for (int j = 0; j < nw; j++) h = hash_step(h, ld_u32(s + 4 * j), (uint32_t) j);
-    const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), h, fpBits);
+    for (int j = 0; j < nw; j++) { const uint32_t w = ld_u32(s + 4 * j); h = hash_step(h, w, (uint32_t) j); f = fp_step(f, w); }
+    const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), f, fpBits);
 #ifndef SWSEM_INSERT_NOREAD
     if (ht[h & mask] >= key) return;                   // (entries only grow: a stale read shows a smaller one at worst, then the atomic decides)
 #endif
@@ -152,7 +155,9 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
 // The K-mer starting at p is about to lose its last byte to a separator (loadSeparator at the window's end, .cpp:439-451)
 // after it may have been hashed: if the table still holds its sample, the entry keeps its position — the reference
 // would still follow it — but its epoch becomes 0 = "do not trust the fingerprint" (ht_value).
-__global__ void k_mark_stale(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht, uint64_t p, int K, int k1ord, uint32_t mask, int fpBits) {
+__global__ void k_mark_stale(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht, uint64_t p, int K, int k1ord, uint32_t mask, int fpBits,
+                             uint16_t *__restrict__ tags) {
+    if (tags) tags[p >> k1ord] = 0;                    // that slot's bytes are about to change without a new sample
     uint32_t h = (uint32_t) K;
     for (int j = 0; j < K / 4; j++) h = hash_step(h, ld_u32(ref + p + 4 * j), (uint32_t) j);
     const ht_entry e = ht[h & mask];
@@ -561,7 +566,7 @@ constexpr int RESOLVE_WAVES_PER_SIMD = SWSEM_RESOLVE_WAVES;
 // ds_bpermute and shifts them into place. The chains wait on memory most of the time, so the multiplications
 // are free there, while a hash array written ahead by its own kernel costs that kernel (0.27 ms per round of
 // 80 M positions, at the multiplier's quarter rate) and 4 bytes of HBM traffic per position each way.
-__device__ __forceinline__ uint32_t window_hash(const RefView &v, const uint8_t *q, int32_t s, int32_t cnt, int32_t lane) {
+__device__ __forceinline__ uint32_t window_hash(const RefView &v, const uint8_t *q, int32_t s, int32_t cnt, int32_t lane, uint32_t &fpHash) {
     const uintptr_t A = (uintptr_t) (q + s);
     const uint32_t sh = (uint32_t) (A & 3);
     const uint32_t *A0 = (const uint32_t *) (A & ~(uintptr_t) 3);
@@ -569,13 +574,16 @@ __device__ __forceinline__ uint32_t window_hash(const RefView &v, const uint8_t 
     const uint32_t a = (uint32_t) lane < ndw ? A0[lane] : 0u;
     const uint32_t o = sh + (uint32_t) lane, wi = o >> 2, sft = o & 3u;
     const int nw = v.K / 4;
-    uint32_t h = (uint32_t) v.K;
+    uint32_t h = (uint32_t) v.K, f = FP_SEED;
     uint32_t lo = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (wi << 2), (int) a);
     for (int x = 0; x < nw; x++) {
         const uint32_t hi = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((wi + (uint32_t) x + 1u) << 2), (int) a);
-        h = hash_step(h, __builtin_amdgcn_alignbyte(hi, lo, sft), (uint32_t) x);
+        const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sft);
+        h = hash_step(h, w, (uint32_t) x);
+        f = fp_step(f, w);
         lo = hi;
     }
+    fpHash = f;
     return h;
 }
 
@@ -608,9 +616,10 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
 #endif
             const int32_t pos = s + lane;
             uint32_t e = 0;
-            const uint32_t hv = window_hash(v, q, s, p1 - s < WL ? p1 - s : WL, lane);
+            uint32_t hf;
+            const uint32_t hv = window_hash(v, q, s, p1 - s < WL ? p1 - s : WL, lane, hf);
             if (lane < WL && pos < p1) {
-                e = ht_value<LAPS>(v, v.ht[hv & v.mask], hv);
+                e = ht_value<LAPS>(v, v.ht[hv & v.mask], hf);
                 if (e != 0) {
                     uint64_t lo, hi;
                     if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;

@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
             wb = scan;
             cnt = p1 - wb < WN4 ? p1 - wb : WN4;
             const int nw = K / 4;
-            uint32_t h = (uint32_t) K;
+            uint32_t h = (uint32_t) K, f = FP_SEED;
             // the window's bytes: from the chain's query cache in LDS (the 256 bytes around the last visit, or the last
             // chunk fetched here) when they are all there, else from memory — one more round trip, and the cache is
             // refilled from the window on so that the windows that follow find their bytes
@@ -221,7 +221,9 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                 uint32_t lo = w[0];
                 for (int x = 0; x < nw; x++) {
                     const uint32_t hi = w[x + 1];
-                    h = hash_step(h, __builtin_amdgcn_alignbyte(hi, lo, sft), (uint32_t) x);
+                    const uint32_t wd = __builtin_amdgcn_alignbyte(hi, lo, sft);
+                    h = hash_step(h, wd, (uint32_t) x);
+                    f = fp_step(f, wd);
                     lo = hi;
                 }
             } else {
@@ -237,7 +239,9 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                 uint32_t lo = gread(a, wi);
                 for (int x = 0; x < nw; x++) {
                     const uint32_t hi = gread(a, wi + (uint32_t) x + 1u);
-                    h = hash_step(h, __builtin_amdgcn_alignbyte(hi, lo, sft), (uint32_t) x);
+                    const uint32_t wd = __builtin_amdgcn_alignbyte(hi, lo, sft);
+                    h = hash_step(h, wd, (uint32_t) x);
+                    f = fp_step(f, wd);
                     lo = hi;
                 }
                 *(uint4 *) (qcache[grp] + 16u * gl) = chunk;
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                 const uint32_t nwhole = (n - (uint32_t) wb) >> 4;
                 qhi = wb + 16 * (int32_t) (nwhole < (uint32_t) GL ? nwhole : (uint32_t) GL);
             }
-            hsh = h;
+            hsh = f;                                               // (what the consume step needs of the hashes: the fingerprint's)
             if ((int32_t) gl < cnt) hte = v.ht[h & v.mask];
         }
 
@@ -257,6 +261,17 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                 if (e != 0) {
                     uint64_t wlo, whi;
                     if (!window_ok(v, lock, (uint64_t) e << v.k1ord, wlo, whi)) e = 0;
+                    else if (LAPS && v.tags) {
+                        // a stale entry — older than the text at the slot it points at, whatever its fingerprint (the same
+                        // K-mer once stood there: collections share most of theirs) — whose slot was sampled again by the
+                        // load that wrote the present text cannot verify (lap_want): two bytes of the slot's tag here
+                        // instead of a visit's iteration and its 256 bytes
+                        const uint32_t ep = (uint32_t) (hte >> (32 + v.fpBits));
+                        if (ep != 0 && !(e <= v.curMax ? ep >= v.eCur : (e >= v.prevMin && ep >= v.ePrev))) {
+                            const uint32_t want = lap_want(v, e);
+                            if (want != 0 && v.tags[e] == want) e = 0;
+                        }
+                    }
                 }
             }
             went = e;

@@ -86,7 +86,7 @@ struct swsem {
     bool sep_end_done(int sep) const { return pos1 == sepEndPos && laps == sepEndLaps && sep == sepEndVal; }
     void sep_end_set(int64_t at, int sep) { sepEndPos = at; sepEndLaps = laps; sepEndVal = sep; }
     bool pristine = true;                  // the loader has only moved forward (wraps included: told by epochs); false after swsem_set_position
-    int fpBits = 0;                        // fingerprint bits of a table entry: what the bucket index leaves of the 32-bit hash, at most 8
+    int fpBits = 0;                        // fingerprint bits of a table entry
     uint64_t hostProbes = 0;               // query positions of the batch
     bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
     bool specMode = false;                 // a speculative finalize is being queued: nothing may be written outside its gated launches
@@ -215,6 +215,8 @@ struct swsem {
     CopySegs segs;                         // small copies staged for one launch (stage_copy / flush_copies)
     hipStream_t segStream = nullptr;
 
+    uint16_t *tags = nullptr;              // per sampling slot: lap_tag of its last on-grid sampling (swsem_device.h, lap_want)
+    bool useTags = true;                   // SWSEM_LAP_TAGS=0: every stale entry is visited (the table image and the results are the same)
     uint64_t refLength() const { return laps ? maxRefLength : (uint64_t) pos1; }
     RefView view() const {
         RefView v;
@@ -223,6 +225,7 @@ struct swsem {
         // (position << k1ord) + K + 1 <= pos1  <=>  value <= curMax;   (position << k1ord) >= pos1  <=>  value >= prevMin
         v.curMax = pos1 >= (int64_t) K + 1 ? (uint32_t) (((uint64_t) pos1 - K - 1) >> k1ord) : 0u;
         v.prevMin = (uint32_t) ((((uint64_t) pos1) + (1ull << k1ord) - 1) >> k1ord); v.K = K; v.k1ord = k1ord; v.skipMargin = skipMargin; v.minLen = minLen;
+        v.tags = useTags ? tags : nullptr; v.tagCur = swk::lap_tag(laps); v.tagPrev = laps ? swk::lap_tag(laps - 1) : 0u;
         return v;
     }
     // event pairs are recycled: creating events by the hundred makes the runtime grow its signal pool now and
@@ -279,7 +282,7 @@ void init_params(swsem *h) {
         h->hash_size = ((uint32_t) 1) << (i++);
     } while (i <= 31 && h->hash_size < h->maxRefLength / (uint64_t) h->k1);
     h->mask = h->hash_size - 1;
-    h->fpBits = std::min(8, 32 - (int) __builtin_ctz(h->hash_size));
+    h->fpBits = 10;                        // of the K-mer's second hash (swsem_device.h, fp_step); 22 bits are left for the epoch
 }
 
 void build_lut(uint8_t *lut) {
@@ -306,13 +309,13 @@ int insert_samples(swsem *h, const uint8_t *src = nullptr, uint64_t lo = 0, uint
     const uint64_t total = nMain + nTail;
     if (total && h->deferInserts) {
         InsertPiece pc;
-        pc.S = (uint64_t) S; pc.nMain = nMain; pc.T = (uint64_t) T; pc.nTail = nTail; pc.epoch = h->epoch; pc.pad = 0;
+        pc.S = (uint64_t) S; pc.nMain = nMain; pc.T = (uint64_t) T; pc.nTail = nTail; pc.epoch = h->epoch; pc.tag = swk::lap_tag(h->laps);
         pc.src = src; pc.lo = lo; pc.hi = hi;                       // reference positions [lo, hi) will hold src[0 .. hi - lo)
         h->pendingPieces.push_back(pc);
     } else if (total) {
         h->mark(SWSEM_K_INSERT, true);
         k_insert<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch, h->fpBits);
+            h->ref, h->ht, (uint64_t) S, nMain, (uint64_t) T, nTail, h->k1, h->k1ord, h->K, h->mask, h->epoch, h->fpBits, h->tags, swk::lap_tag(h->laps));
         h->mark(SWSEM_K_INSERT, false);
         HIPCHK(hipGetLastError());
     }
@@ -449,7 +452,7 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
                 auto push = [&](int64_t t0, int64_t t1) {           // [t0, t1)
                     if (t1 <= t0) return;
                     InsertPiece e = {};
-                    e.S = base + (uint64_t) t0 * (uint64_t) k1; e.nMain = (uint64_t) (t1 - t0); e.epoch = epoch;
+                    e.S = base + (uint64_t) t0 * (uint64_t) k1; e.nMain = (uint64_t) (t1 - t0); e.epoch = epoch; e.tag = pc.tag;
                     edge.push_back(e);
                 };
                 if (b < a) push(0, (int64_t) n);
@@ -519,15 +522,15 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
         h->mark(SWSEM_K_INSERT, true);
         const dim3 grid((unsigned) ((tFirst[np] + 255) / 256));
         const InsertPiece *dp = (const InsertPiece *) (d + (tPieces - tab.data()));
-        if (beside) k_insert_multi<true><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, dp, d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
-        else k_insert_multi<false><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, dp, d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
+        if (beside) k_insert_multi<true><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, dp, d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
+        else k_insert_multi<false><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, dp, d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
         h->mark(SWSEM_K_INSERT, false);
     }
     if (beside) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->evLoadDone, 0));
         if (ne && tEFirst[ne])
             k_insert_multi<false><<<dim3((unsigned) ((tEFirst[ne] + 255) / 256)), dim3(256), 0, h->stream>>>(
-                h->ref, h->ht, (const InsertPiece *) (d + (tEdge - tab.data())), d + (tEFirst - tab.data()), (int) ne, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate);
+                h->ref, h->ht, (const InsertPiece *) (d + (tEdge - tab.data())), d + (tEFirst - tab.data()), (int) ne, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
     }
     HIPCHK(hipGetLastError());
     h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear();
@@ -869,10 +872,13 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_ORDER")) h->orderMode = strcmp(e, "contig") == 0 ? 0 : 1;
+    if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
+    const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
+        hipMalloc((void **) &h->tags, nSlots * sizeof(uint16_t)) != hipSuccess ||
         hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
         hipMalloc((void **) &h->lut, 256) != hipSuccess) {
         swsem_destroy(h);
@@ -883,6 +889,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     build_lut(lut);
     HIPCHK(hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(h->ht, 0, (size_t) h->hash_size * sizeof(ht_entry), h->stream));
+    HIPCHK(hipMemsetAsync(h->tags, 0, nSlots * sizeof(uint16_t), h->stream));
     // start1[0] = 0 (.cpp:335); the rest of the buffer is written before it is ever read, the slack
     // past the end is zeroed because the reference's own reads run a few bytes over (:224, ENC:337)
     // the whole buffer starts out as zeros (the reference reads — harmlessly — bytes it has not loaded yet, e.g. the one at the
@@ -902,6 +909,7 @@ void swsem_destroy(swsem_t *h) {
     if (h->stream3) (void) hipStreamSynchronize(h->stream3);
     h->drain_events();
     if (h->ref) (void) hipFree(h->ref);
+    if (h->tags) (void) hipFree(h->tags);
     if (h->ht) (void) hipFree(h->ht);
     if (h->lut) (void) hipFree(h->lut);
     h->stage.release(); h->dContigs.release(); 
@@ -1016,7 +1024,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
         if (h->specMode) return SWSEM_ESPEC;                      // an ungated write in the middle: give the speculation up
         if (h->deferInserts) { int r = flush_inserts(h); if (r) return r; }
         if (h->pos1 >= (int64_t) h->K + REF_SHIFT)
-            k_mark_stale<<<1, 1, 0, h->stream>>>(h->ref, h->ht, (uint64_t) (h->pos1 - h->K), h->K, h->k1ord, h->mask, h->fpBits);
+            k_mark_stale<<<1, 1, 0, h->stream>>>(h->ref, h->ht, (uint64_t) (h->pos1 - h->K), h->K, h->k1ord, h->mask, h->fpBits, h->tags);
         k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->pos1 - 1, (uint8_t) sep);
         h->sep_end_set(h->pos1, sep);
     } else if (h->deferInserts) {
@@ -1161,6 +1169,10 @@ int swsem_debug_write_ref(swsem_t *h, uint64_t from, uint64_t n, const uint8_t *
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipStreamSynchronize(h->stream2));
     HIPCHK(hipMemcpy(h->ref + from, in, n, hipMemcpyHostToDevice));
+    {   // the bytes of these slots changed without a sample: their tags say so
+        const uint64_t s0 = from >= (uint64_t) h->K ? (from - h->K + 1) >> h->k1ord : 0, s1 = (from + n + ((1ull << h->k1ord) - 1)) >> h->k1ord;
+        if (h->tags && s1 > s0) HIPCHK(hipMemset(h->tags + s0, 0, (s1 - s0) * sizeof(uint16_t)));
+    }
     return SWSEM_OK;
 }
 
