@@ -128,6 +128,16 @@ __device__ __forceinline__ uint32_t lap_want(const RefView &v, uint32_t val) {
     return val <= v.curMax ? v.tagCur : (val >= v.prevMin ? v.tagPrev : 0u);
 }
 
+// value e of entry hte has passed the window test: is it a stale entry whose slot's tag settles that it cannot verify?
+template <bool LAPS>
+__device__ __forceinline__ bool stale_settled(const RefView &v, ht_entry hte, uint32_t e) {
+    if (!LAPS || !v.tags) return false;
+    const uint32_t ep = (uint32_t) (hte >> (32 + v.fpBits));
+    if (ep == 0 || (e <= v.curMax ? ep >= v.eCur : (e >= v.prevMin && ep >= v.ePrev))) return false;   // marked by k_mark_stale / as young as the text
+    const uint32_t want = lap_want(v, e);
+    return want != 0 && v.tags[e] == want;
+}
+
 // window test of SlidingWindowSparseEMMatcher.cpp:212-222. Returns false when the entry is rejected.
 __device__ __forceinline__ bool window_ok(const RefView &v, uint64_t lock, uint64_t c, uint64_t &lo, uint64_t &hi) {
     const uint64_t swStart = v.pos1;

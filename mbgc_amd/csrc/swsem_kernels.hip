@@ -619,10 +619,12 @@ __device__ void run_chain_lazy(const RefView &v, const Contig &cg, const uint8_t
             uint32_t hf;
             const uint32_t hv = window_hash(v, q, s, p1 - s < WL ? p1 - s : WL, lane, hf);
             if (lane < WL && pos < p1) {
-                e = ht_value<LAPS>(v, v.ht[hv & v.mask], hf);
+                const ht_entry hte = v.ht[hv & v.mask];
+                e = ht_value<LAPS>(v, hte, hf);
                 if (e != 0) {
                     uint64_t lo, hi;
                     if (!window_ok(v, cg.lock, (uint64_t) e << v.k1ord, lo, hi)) e = 0;
+                    else if (stale_settled<LAPS>(v, hte, e)) e = 0;
                 }
             }
             w = e;

@@ -261,17 +261,11 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                 if (e != 0) {
                     uint64_t wlo, whi;
                     if (!window_ok(v, lock, (uint64_t) e << v.k1ord, wlo, whi)) e = 0;
-                    else if (LAPS && v.tags) {
-                        // a stale entry — older than the text at the slot it points at, whatever its fingerprint (the same
-                        // K-mer once stood there: collections share most of theirs) — whose slot was sampled again by the
-                        // load that wrote the present text cannot verify (lap_want): two bytes of the slot's tag here
-                        // instead of a visit's iteration and its 256 bytes
-                        const uint32_t ep = (uint32_t) (hte >> (32 + v.fpBits));
-                        if (ep != 0 && !(e <= v.curMax ? ep >= v.eCur : (e >= v.prevMin && ep >= v.ePrev))) {
-                            const uint32_t want = lap_want(v, e);
-                            if (want != 0 && v.tags[e] == want) e = 0;
-                        }
-                    }
+                    // a stale entry — older than the text at the slot it points at, whatever its fingerprint (the same K-mer
+                    // once stood there: collections share most of theirs) — whose slot was sampled again by the load that
+                    // wrote the present text cannot verify (lap_want): two bytes of the slot's tag here instead of a visit's
+                    // iteration and its 256 bytes
+                    else if (stale_settled<LAPS>(v, hte, e)) e = 0;
                 }
             }
             went = e;
