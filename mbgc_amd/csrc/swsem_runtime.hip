@@ -145,6 +145,7 @@ struct swsem {
         std::vector<EmitOut> eout;
         hipEvent_t evDone = nullptr;
         bool outstanding = false, refGuarded = false;
+        bool donePending = false;            // evDone has not been recorded for this emission yet (its byte automata are queued behind the speculative finalize)
         const uint8_t *qdev = nullptr;       // query buffer the emission reads
         swsem_emit_params_t params;          // its parameters
         uint64_t emitPos1 = 0;               // loading position the emission started at
@@ -193,6 +194,8 @@ struct swsem {
     // so that the caller can queue the round's finalize and the next round's match-finding next to it
     hipStream_t stream2 = nullptr;
     hipEvent_t evP1 = nullptr;
+    hipEvent_t evFin = nullptr;            // behind the speculative finalize (see emit_begin_impl)
+    bool phase2Behind = true;              // SWSEM_PHASE2_BEHIND=0: the second phase's byte automata do not wait for the finalize
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 8;                       // length of a resolve block in units of RBU positions: chosen per batch (run_batch) unless SWSEM_RB fixes it
@@ -345,6 +348,7 @@ int ref_write_guard(swsem *h, uint64_t firstByte, uint64_t lastByte) {
         }
         const bool appendOnly = h->laps == 0 && firstByte >= E.emitPos1;   // nothing was ever written there: nothing to read
         if (!inside && !appendOnly) {
+            if (E.donePending) return SWSEM_ESPEC;                   // (only while a speculative finalize is being queued: it is given up)
             HIPCHK(hipStreamWaitEvent(h->stream, E.evDone, 0));
             E.refGuarded = true;
         }
@@ -872,6 +876,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_ORDER")) h->orderMode = strcmp(e, "contig") == 0 ? 0 : 1;
+    if (const char *e = getenv("SWSEM_PHASE2_BEHIND")) h->phase2Behind = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
@@ -931,6 +936,7 @@ void swsem_destroy(swsem_t *h) {
     if (h->stream3) { (void) hipStreamSynchronize(h->stream3); (void) hipStreamDestroy(h->stream3); }
     if (h->evMatched) (void) hipEventDestroy(h->evMatched);
     if (h->evP1) (void) hipEventDestroy(h->evP1);
+    if (h->evFin) (void) hipEventDestroy(h->evFin);
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1055,6 +1061,7 @@ static int finalize_impl(swsem_t *h, int n, const uint8_t *const *ext_dev, const
     h->deferInserts = false;
     if (r == SWSEM_ESPEC) { h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear(); return r; }
     const int r2 = flush_inserts(h, gate);
+    if (r2 == SWSEM_ESPEC) { h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear(); }
     return r ? r : r2;
 }
 
@@ -1366,16 +1373,37 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     h->mark(SWSEM_K_EMIT2, true, h->stream2);
     k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p);
     k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
-    k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
-    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
-    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
-    k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
-    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
-    k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
-    if ((r = download(h, E.pinE, E.dEOut.p, n * sizeof(EmitOut), h->stream2)) || (r = flush_copies(h))) return r;
-    HIPCHK(hipEventRecord(E.evDone, h->stream2));
+    // The byte automata (sizes .. write) are queued further down, behind the speculative finalize: with the pairing
+    // kernels and the finalize ending at about the same time (0.85 ms after pass 1 on the 4.35e9-byte sizing) it was a
+    // photo finish between k_emit_sizes and the next batch's resolve, and whichever started first was dealt the wave
+    // slots first — the resolve took 2.8 ms instead of 2.1 when it lost (steps of 3.1 and 3.9 ms alternating by the
+    // run). The automata now also wait for the finalize's last kernel: the resolve, next in that queue, starts first.
+    auto phase2b = [&](bool behindFinalize) -> int {
+        if (behindFinalize) {
+            if (!h->evFin) HIPCHK(hipEventCreateWithFlags(&h->evFin, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(h->evFin, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->evFin, 0));
+        }
+        h->mark(SWSEM_K_EMIT2, true, h->stream2);
+        k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
+        k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
+        k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
+        k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
+        k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
+        k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
+        h->mark(SWSEM_K_EMIT2, false, h->stream2);
+        HIPCHK(hipGetLastError());
+        int r2;
+        if ((r2 = download(h, E.pinE, E.dEOut.p, n * sizeof(EmitOut), h->stream2)) || (r2 = flush_copies(h))) return r2;
+        HIPCHK(hipEventRecord(E.evDone, h->stream2));
+        E.donePending = false;
+        return SWSEM_OK;
+    };
+    E.donePending = true;
+    const bool specAsked = spec && spec->ntargets > 0 && h->phase2Behind;
+    if (!specAsked) { if ((r = phase2b(false))) return r; }
     h->latest = si; h->selected = -1;
     E.outstanding = true; E.refGuarded = false; E.emitN = n; E.emitPos1 = (uint64_t) h->pos1; E.qdev = h->qdev; E.params = *p;
     E.emitLaps = h->laps;
@@ -1411,6 +1439,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
                        h->pristine = snap.pristine; h->locks = snap.locks; }
     }
+    if (specAsked) { if ((r = phase2b(queued))) return r; }
     HIPCHK(hipEventSynchronize(h->evP1));                           // pass 1 and its copies to the host (not what was queued after them)
     if (needCounts) take_counts(h);
     E.eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
