@@ -351,32 +351,57 @@ void MultipleGenomeMatchingProcessor::loadG0Ref(const std::string &refName) {
     initMatcher(refStr.data(), refStr.size(), basicRefLength);
 }
 
+// The sequential schedule (MGMP.cpp:232-313): every contig is matched against a reference that already holds the one
+// before it, so the contigs run one after the other — but only up to what the next one needs: a contig's match-finding
+// and processMatches' first pass (its return value decides the loadRef), then the loadRef; the stream bytes of contig c
+// are produced beside contig c + 1 (two emissions in flight) and appended, in order, one contig later.
 void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
-    RoundBatch two[2];                                                                          // the file being matched, the file arriving
+    RoundBatch three[3];                   // the file being matched, the file arriving, the file whose last contig's emission still reads its bytes
+    struct { bool valid = false; int fileSeps = 0; uint32_t buf = 0; } prev;                   // the contig whose streams are still to be taken
+    auto collectPrev = [&](bool newerBegun) {
+        if (prev.valid) {
+            if (newerBegun) matcher->emitSelect(true);
+            swsem_streams_t st = {};
+            matcher->emitView(0, st);
+            appendContigInOrder(st);                                                            // processMatches' appends + processAfterSequence (:276, :288)
+            if (newerBegun) matcher->emitSelect(false);
+        }
+        for (int k = 0; k < prev.fileSeps; k++) endTargetInOrder();                             // processAfterTarget (:306)
+        prev.valid = false; prev.fileSeps = 0;
+    };
+    const std::vector<uint64_t> noLock(1, UINT64_MAX);                                          // :274 (no lock in this mode)
     for (uint32_t i = 0; i < filesCount; i++) {
-        RoundBatch &B = two[i & 1];
-        loadRound(i, i + 1, B, i + 1, std::min(filesCount, i + 2), &two[(i + 1) & 1]);          // MGMP.cpp:247-250
+        RoundBatch &B = three[i % 3];
+        if (prev.valid && prev.buf == (i + 1) % 3) { matcher->emitEnd(); collectPrev(false); }  // (files without records in between: the arriving file would overwrite what that emission reads)
+        loadRound(i, i + 1, B, i + 1, std::min(filesCount, i + 2), &three[(i + 1) % 3]);        // MGMP.cpp:247-250
         const size_t startPos = matcher->getLoadedRefLength();                                 // :251
         unmatchedFractionFactors.push_back(params->currentUnmatchedFractionFactor < 256 ? params->currentUnmatchedFractionFactor : 0);
         unmatchedFractionFactors.push_back((uint8_t) params->unmatchedFractionRCFactor);
         for (size_t c = 0; c + 1 < B.offsets.size(); c++) {
             const size_t bSize = B.offsets[c + 1] - B.offsets[c];
             const uint8_t *seq = B.seqDev + B.offsets[c];
-            std::vector<uint64_t> counts;
-            matcher->matchRound(seq, {0, bSize}, params->k, {}, counts);                       // :274 (no lock in this mode)
+            std::vector<uint64_t> un, counts;
+            matcher->matchRoundBegin(seq, {0, bSize}, params->k, {});
+            matcher->emitRoundBegin(emitParams(), noLock, {(int) unmatchedFractionFactors[0]}, {processedTargetsCount}, {0}, loadedPositions(),
+                                    nullptr, un, counts);                                        // :276 (targetIdx 0 in this mode, ENC.cpp:202)
             resCount += counts[0];
-            const size_t currentUnmatched = processMatches(bSize, 0, SIZE_MAX);                // :276
+            totalDestLenAll += bSize;
+            collectPrev(true);
+            const size_t currentUnmatched = un[0];
             const bool loadContigToRef = params->isContigProperForRefExtension(bSize, currentUnmatched, params->currentUnmatchedFractionFactor);
             const bool loadContigRCToRef = params->rcInReference &&
                                            params->isContigProperForRefRCExtension(bSize, currentUnmatched, params->unmatchedFractionRCFactor);
             // :281-287: the contig, or the (always empty in release builds) literal extension
             matcher->loadRefDev(seq, loadContigToRef ? bSize : 0, loadContigRCToRef, params->refRegionSeparators, REF_REGION_SEPARATOR);
-            processAfterSequence(0);
+            prev.valid = true; prev.buf = i % 3;
         }
-        processAfterTargetWithParallelIO(startPos);                                            // :306
+        prev.fileSeps++;                                                                        // (behind the file's last contig)
+        afterTargetWithParallelIO(startPos);                                                    // :306 without processAfterTarget
     }
+    if (prev.valid) matcher->emitEnd();
+    collectPrev(false);
     if (ahead.active) { ahead.done.wait(); ahead.active = false; }
-    for (auto &B : two) if (B.seqDev) matcher->devFree(B.seqDev);
+    for (auto &B : three) if (B.seqDev) matcher->devFree(B.seqDev);
 }
 
 // A round whose first pass gave up a contig as dissimilar (MGMP.cpp:382-388: "discard, wait until the earlier targets
@@ -749,6 +774,11 @@ void MBGC_Encoder::processAfterTarget(uint32_t targetIdx) {
 
 void MBGC_Encoder::processAfterTargetWithParallelIO(size_t matcherLoaderStartPos) {
     processAfterTarget(0);
+    afterTargetWithParallelIO(matcherLoaderStartPos);
+}
+
+// ... its part that does not touch the literal / flag streams (the pipelined sequential loop appends those a contig later)
+void MBGC_Encoder::afterTargetWithParallelIO(size_t matcherLoaderStartPos) {
     if (params->lazyDecompressionSupport) {
         matcher->loadSeparator(REF_REGION_SEPARATOR);
         const size_t refExtSize = matcher->getLoadedRefLength() - matcherLoaderStartPos;

@@ -118,6 +118,7 @@ protected:
     virtual void processAfterSequence(uint32_t targetIdx) = 0;
     virtual void processAfterTarget(uint32_t targetIdx) = 0;
     virtual void processAfterTargetWithParallelIO(size_t matcherLoaderStartPos) = 0;
+    virtual void afterTargetWithParallelIO(size_t matcherLoaderStartPos) = 0;          // the same without processAfterTarget
     virtual void initParallelProcessing() = 0;
     virtual void finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t matcherLoaderStartPos) = 0;
     // the same in two halves, for the round pipeline: what is known when the target's extension has been queued (the
@@ -149,6 +150,7 @@ class MBGC_Encoder : public MultipleGenomeMatchingProcessor {
     void processAfterSequence(uint32_t targetIdx) override;                             // :489-491
     void processAfterTarget(uint32_t targetIdx) override;                               // :493-496
     void processAfterTargetWithParallelIO(size_t matcherLoaderStartPos) override;       // :498-509
+    void afterTargetWithParallelIO(size_t matcherLoaderStartPos) override;
     void initParallelProcessing() override;                                             // :516-528
     void finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t matcherLoaderStartPos) override;   // :542-564
     void noteTargetLoaded(uint32_t targetIdx, size_t matcherLoaderStartPos, size_t loadedRefLengthAfter) override;   // :557-563
