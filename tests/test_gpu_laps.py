@@ -24,7 +24,7 @@ def collection(n, length, div, seed):
     return [synth.genome(base, i, div) for i in range(n)]
 
 
-def run(tags):
+def run(tags, round_size=1):
     import torch
     from mbgc_amd import binding
     from mbgc_amd.rounds import RoundRunner, round_schedule
@@ -34,7 +34,7 @@ def run(tags):
     h.load_ref(gs[0], load_rc=True)
     runner = RoundRunner(h, 0, 1, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1))
     runner.start()
-    for rnd in round_schedule(len(gs) - 1, 4, 1):
+    for rnd in round_schedule(len(gs) - 1, round_size, 1):
         mine = [gs[1 + t] for t in rnd[0]]
         buf = torch.from_numpy(np.concatenate(mine)).to("cuda:0")
         offs = np.zeros(len(mine) + 1, dtype=np.uint64)
@@ -42,20 +42,20 @@ def run(tags):
         torch.cuda.synchronize()
         runner.run_round(buf, offs)
     runner.flush()
-    laps = (120 * 100_000 + 200_000) // LIM
     o = _orc.OracleMatcher(LIM)
-    res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], 4)
+    res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], round_size)
     for k, v in res["streams"].items():
         assert bytes(runner.streams[k]) == v, (k, tags)
     assert bytes(runner.locks_stream) == res["locks"] and bytes(runner.ref_ext_sizes) == res["refExtSize"]
     assert np.array_equal(h.ht(), o.ht())
-    assert laps >= 5
+    assert o.loaded_ref_length() > (5 if round_size == 1 else 2) * LIM      # (rounds of 4: the lock window clips most of every extension)
     o.close()
     h.close()
 
 
-def test_five_laps_equal_the_oracle_loop():
-    run(tags=True)
+@pytest.mark.parametrize("round_size", [1, 4])
+def test_five_laps_equal_the_oracle_loop(round_size):
+    run(True, round_size)
 
 
 def test_five_laps_without_lap_tags_in_a_child():

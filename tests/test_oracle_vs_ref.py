@@ -230,6 +230,38 @@ def test_emission_rounds_with_locks_and_wrap(refh, round_size):
     assert o.loaded_ref_length() > lim
 
 
+@pytest.mark.parametrize("round_size,laps", [(1, 5), (4, 2)])
+def test_five_laps_of_the_buffer(refh, round_size, laps):
+    """the collection of tests/test_gpu_laps.py (five laps of a 2.4 MB buffer with rounds of 1; with rounds of 4 the lock
+    window clips most of every extension and the loader gets less far): the restatement against the
+    reference itself — matches, streams, locks, extension sizes, table — so that what the device path is compared with
+    there (its lap tags drop stale entries without a visit) is the reference's own result"""
+    gs = small_collection(121, 100_000, 0.01, seed=71)
+    lim = 2_400_000
+    r, o = both(refh, lim)
+    targets = [[g] for g in gs[1:]]
+    ad = RefEmitAdapter(refh, r, n_targets=len(targets))
+    cnt = {"t": 0}
+
+    def make_ref():
+        class E:
+            def __init__(s): s.t = cnt["t"]; cnt["t"] += 1; s.v = ad.view(s.t)
+            def process(s, *a): return s.v.process(*a)
+            def put(s, which, data): ad.e.after_sequence(s.t) if which == 0 else ad.e.after_target(s.t)
+            def streams(s): return ad.e.streams(s.t)
+        return E()
+
+    a = _driver.encode_rounds(r, make_ref, [gs[0]], targets, round_size)
+    b = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], targets, round_size)
+    assert a["locks"] == b["locks"] and a["refExtSize"] == b["refExtSize"] and a["unmatched"] == b["unmatched"]
+    for x, y in zip(a["matches"], b["matches"]):
+        assert np.array_equal(x, y)
+    for k in a["streams"]:
+        assert a["streams"][k] == b["streams"][k], k
+    assert_same_state(r, o)
+    assert o.loaded_ref_length() > laps * lim
+
+
 LISTERIA = "/root/reference/example-scripts"
 
 
