@@ -451,6 +451,8 @@ def main():
             out["rccl_ranks_seen"] = dist.get_world_size()
             out["extension_allgathers_started_ahead"] = {"started": runner.pregathers[0], "used": runner.pregathers[1]}
             out["round_finalizes_queued_on_device_verdicts"] = {"tried": runner.spec_rounds[0], "applied": runner.spec_rounds[1]}
+            out["extension_exchanges_cut_to_the_loadable_head"] = {"rounds": runner.head_gathers[0], "bytes_asked_for": runner.head_gathers[1],
+                                                                   "bytes_of_those_rounds": runner.head_gathers[2]}
         if runner.trace is not None:
             out["host_ms_per_round"] = {k: round(v * 1e3 / (steps + warm), 3) for k, v in runner.trace.items()}
         if world == 1 and args.cpu_sample > 0:

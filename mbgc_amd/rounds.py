@@ -48,6 +48,17 @@ def frugal64(v):
     return out
 
 
+class _Works:
+    """several asynchronous collectives waited for as one"""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class RoundRunner:
     """matcher: mbgc_amd.binding.SlidingWindowSparseEMMatcher (or any object with the same surface)."""
 
@@ -96,6 +107,7 @@ class RoundRunner:
         self._gpred = False                          # several ranks: last round every target on every rank was loaded whole, without RC
         self._pre = None                             # extension all-gather started ahead under that prediction (see _pregather)
         self.pregathers = [0, 0]                     # started / used (diagnostics)
+        self.head_gathers = [0, 0, 0]                # extension exchanges cut to the round's loadable head: how many, bytes asked for, bytes of the whole round
         self._gathers = []                           # stream gathers still running (work, output, input)
         self._next_key = None                        # the buffer this rank announced for the next round (see _post_announce)
         self._ann = None                             # the announcement exchange in flight
@@ -201,7 +213,22 @@ class RoundRunner:
         return [(flat[r * k], flat[r * k + 2: r * k + 2 + flat[r * k + 1]] if flat[r * k + 1] >= 0 else None)
                 for r in range(self.world)]
 
-    def _pregather(self, qbuf, offsets, targets, T, ann):
+    def _loadable(self, locks):
+        """bytes of the round's extensions (target after target) that can be loaded at all, or None = all of them: once the
+        buffer has wrapped every target of the round holds the lock value loading position + window (.cpp:361-378), loadRef
+        clips at the oldest outstanding lock (:412-417, the rest of a text is dropped, :433) and the round's locks are
+        released one by one as its targets are loaded — so whatever lies beyond `window` bytes of the round is never read.
+        The same on every rank (the replicas' states are)."""
+        if not locks or os.environ.get("MBGC_ROUNDS_GATHER_ALL", "0") == "1":
+            return None
+        m = self.m
+        mx, pos1, lock = int(m.max_ref_length()), int(m.loading_position()), int(min(locks))
+        if lock >= mx or int(max(locks)) != lock:
+            return None
+        cap = lock - pos1 if lock > pos1 else lock + (mx - 1) - pos1
+        return cap + 4096 if cap > 0 else None
+
+    def _pregather(self, qbuf, offsets, targets, T, ann, loadable=None):
         """Several ranks: in a collection nearly every target ends up loaded into the reference whole, so the bytes the
         round's all-gather will carry are known before the round starts — they are the queries. When the last round went
         that way on every rank (a fact all ranks hold, so all of them decide alike), the all-gather is started here,
@@ -260,7 +287,30 @@ class RoundRunner:
                 if not poisoned:
                     pad[: qbuf.numel()] = qbuf
             out = torch.empty(self.world * mx, dtype=torch.uint8, device=self.device)
-            work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
+            need = None
+            if loadable is not None and announced is not None:
+                # only the head of the round can be loaded (see _loadable): rank r's bytes are wanted as far as they lie
+                # inside it, and travel as broadcasts from the few ranks that hold them instead of an all-gather of all
+                start, need = 0, []
+                for r in range(self.world):
+                    need.append(max(0, min(sizes[r], loadable - start)))
+                    start += sizes[r]
+            if need is not None and sum(need) < sum(sizes):
+                works = []
+                for r in range(self.world):
+                    if need[r] == 0:
+                        continue
+                    piece = out[r * mx: r * mx + need[r]]
+                    if r == self.rank:
+                        piece.copy_(pad[: need[r]])
+                    works.append(dist.broadcast(piece, src=r if self.group is None else dist.get_global_rank(self.group, r),
+                                                group=self.group, async_op=True))
+                work = _Works(works)
+                self.head_gathers[0] += 1
+                self.head_gathers[1] += sum(need)
+                self.head_gathers[2] += sum(sizes)
+            else:
+                work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
         if early:                                       # (allocated under the side stream, consumed on the main one)
             main = torch.cuda.current_stream(self.device)
             out.record_stream(main)
@@ -290,7 +340,7 @@ class RoundRunner:
             self._ev_tops = [self._ev_tops[1], ev]
         tr = self.trace
         t0 = time.perf_counter() if tr is not None else 0
-        self._pregather(qbuf, offsets, targets, T, self._take_announce())
+        self._pregather(qbuf, offsets, targets, T, self._take_announce(), self._loadable(locks))
         self._post_announce(next_batch, T)
         if tr is not None:
             tr["top"] = tr.get("top", 0) + time.perf_counter() - t0

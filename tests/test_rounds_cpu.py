@@ -23,8 +23,8 @@ def collection(n, length, div, seed):
     return [synth.genome(base, i, div) for i in range(n)]
 
 
-def reference_result(gs, round_size, contigs_per_target=1):
-    o = _orc.OracleMatcher(LIM)
+def reference_result(gs, round_size, contigs_per_target=1, lim=LIM):
+    o = _orc.OracleMatcher(lim)
     targets = [split(g, _cpt(contigs_per_target, t)) for t, g in enumerate(gs[1:])]
     res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], targets, round_size)
     return res, o.ht(), o.loaded_ref_length()
@@ -41,10 +41,10 @@ def split(g, k):
     return [g[cuts[i]:cuts[i + 1]] for i in range(k)]
 
 
-def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None, announce=0):
+def run_rank(rank, world, gs, per_rank, contigs_per_target, group=None, announce=0, lim=LIM):
     """announce: 0 = rounds are passed one by one; 1 = every round names the next one's buffer (next_batch), so the ranks
     tell each other its size ahead; 2 = rank 1 then passes a different buffer than it named (the others must cope)"""
-    m = _orc_backend.OracleDeviceMatcher(LIM)
+    m = _orc_backend.OracleDeviceMatcher(lim)
     m.set_sliding_window_size(16)
     m.load_ref(gs[0], load_rc=True)
     runner = RoundRunner(m, rank, world, group, "cpu", lazy=True, emit_params=_orc.emit_params(1))
@@ -82,18 +82,19 @@ def test_single_process_runner_equals_reference_loop(div, cpt):
     assert m.loaded_ref_length() == loaded and np.array_equal(m.ht(), ht)
 
 
-def _worker_n(rank, world, port, outdir, div, per_rank, announce, n):
-    _worker(rank, world, port, outdir, div, 1, announce, n, per_rank)
+def _worker_n(rank, world, port, outdir, div, per_rank, announce, n, lim=LIM):
+    _worker(rank, world, port, outdir, div, 1, announce, n, per_rank, lim)
 
 
-def _worker(rank, world, port, outdir, div, cpt, announce=0, n=9, per_rank=2):
+def _worker(rank, world, port, outdir, div, cpt, announce=0, n=9, per_rank=2, lim=LIM):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     gs = collection(n, 60_000, div, seed=17)
-    runner, m = run_rank(rank, world, gs, per_rank, cpt, announce=announce)
+    runner, m = run_rank(rank, world, gs, per_rank, cpt, announce=announce, lim=lim)
     np.save(os.path.join(outdir, "ht%d.npy" % rank), m.ht())
     open(os.path.join(outdir, "pregathers%d" % rank), "w").write("%d %d" % tuple(runner.pregathers))
     open(os.path.join(outdir, "spec%d" % rank), "w").write("%d %d" % tuple(runner.spec_rounds))
+    open(os.path.join(outdir, "head%d" % rank), "w").write("%d %d %d" % tuple(runner.head_gathers))
     if rank == 0:
         for k, v in runner.streams.items():
             open(os.path.join(outdir, k), "wb").write(bytes(v))
@@ -182,3 +183,28 @@ def test_more_ranks_gloo(tmp_path, world, per_rank, n, div, announce):
     assert len(set(sp)) == 1
     if div == 0.002:
         assert int(sp[0].split()[1]) >= 1, sp
+
+
+@pytest.mark.parametrize("world,per_rank", [(2, 2), (3, 2)])
+def test_after_the_wrap_only_the_loadable_head_of_a_round_travels(tmp_path, world, per_rank):
+    """a small buffer that wraps early: from then on a round's locks stand one window ahead of the loading position and
+    loadRef clips there (SlidingWindowSparseEMMatcher.cpp:361-378, :412-417), so the extension exchange asks every rank only
+    for the bytes that lie inside that head of the round (broadcasts instead of the all-gather) — same streams, same tables"""
+    import torch.multiprocessing as mp
+    n, lim = 1 + 6 * world * per_rank, 900_000
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_n, args=(world, port, str(tmp_path), 0.002, per_rank, 1, n, lim), nprocs=world, join=True)
+    gs = collection(n, 60_000, 0.002, seed=17)
+    res, ht, _ = reference_result(gs, world * per_rank, 1, lim)
+    for k, v in res["streams"].items():
+        assert (tmp_path / k).read_bytes() == v, k
+    assert (tmp_path / "locks").read_bytes() == res["locks"]
+    assert (tmp_path / "refext").read_bytes() == res["refExtSize"]
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("ht%d.npy" % r)), ht), r
+    hd = [(tmp_path / ("head%d" % r)).read_text() for r in range(world)]
+    assert len(set(hd)) == 1
+    k, asked, whole = (int(x) for x in hd[0].split())
+    assert k >= 1 and asked < whole, hd
