@@ -48,6 +48,11 @@ int mbgc_xchg_allgather_i64(mbgc_xchg_t *x, const int64_t *mine, uint64_t k, int
 /* every rank gives bytesPerRank device bytes, dst_dev receives world*bytesPerRank (rank-major). Asynchronous, on the
  * exchange's bulk stream; src and dst must stay untouched until one of the waits below. */
 int mbgc_xchg_allgather_bytes_begin(mbgc_xchg_t *x, const uint8_t *src_dev, uint64_t bytesPerRank, uint8_t *dst_dev);
+/* the same when only part of every rank's bytes is wanted: rank r gives the first need[r] of its bytes (0: none), dst_dev
+ * receives them at r * stride — broadcasts from the ranks that have something to give. After the buffer has wrapped a round
+ * can load one window of bytes (its locks stand there, loadRef clips: SlidingWindowSparseEMMatcher.cpp:361-378, :412-417),
+ * so only the head of the round's extensions need travel. Asynchronous like _allgather_bytes_begin; same waits. */
+int mbgc_xchg_bcast_heads_begin(mbgc_xchg_t *x, const uint8_t *src_dev, const uint64_t *need, uint64_t stride, uint8_t *dst_dev);
 int mbgc_xchg_stream_wait_bytes(mbgc_xchg_t *x, void *stream);      /* `stream` (hipStream_t) waits for the last all-gather */
 int mbgc_xchg_wait_bytes(mbgc_xchg_t *x);                           /* the host does */
 /* *word_dev := min over the ranks, queued on `stream` (a hipStream_t of the caller's) behind what it holds */

@@ -211,6 +211,36 @@ int mbgc_xchg_allgather_bytes_begin(mbgc_xchg_t *x, const uint8_t *src_dev, uint
     return 0;
 }
 
+int mbgc_xchg_bcast_heads_begin(mbgc_xchg_t *x, const uint8_t *src_dev, const uint64_t *need, uint64_t stride, uint8_t *dst_dev) {
+    HIPX(hipSetDevice(x->device));
+    if (x->rccl) {
+        NCCLX(ncclGroupStart());
+        for (int r = 0; r < x->world; r++)
+            if (need[r]) NCCLX(ncclBroadcast(src_dev, dst_dev + (uint64_t) r * stride, need[r], ncclUint8, r, x->bulk, x->sBulk));
+        NCCLX(ncclGroupEnd());
+        HIPX(hipEventRecord(x->evBytes, x->sBulk));
+        return 0;
+    }
+    uint64_t most = 0;
+    for (int r = 0; r < x->world; r++) most = need[r] > most ? need[r] : most;
+    const uint64_t per = x->areaBytes / x->world;
+    for (uint64_t at = 0; at < most; at += per) {
+        const uint64_t mineLeft = need[x->rank] > at ? need[x->rank] - at : 0, n = mineLeft < per ? mineLeft : per;
+        if (n) {
+            HIPX(hipMemcpyAsync(x->area + (uint64_t) x->rank * per, src_dev + at, n, hipMemcpyDeviceToHost, x->sCtl));
+            HIPX(hipStreamSynchronize(x->sCtl));
+        }
+        if (x->barrier()) return -1;
+        for (int r = 0; r < x->world; r++) {
+            const uint64_t left = need[r] > at ? need[r] - at : 0, m = left < per ? left : per;
+            if (m) HIPX(hipMemcpyAsync(dst_dev + (uint64_t) r * stride + at, x->area + (uint64_t) r * per, m, hipMemcpyHostToDevice, x->sCtl));
+        }
+        HIPX(hipStreamSynchronize(x->sCtl));
+        if (x->barrier()) return -1;
+    }
+    return 0;
+}
+
 int mbgc_xchg_stream_wait_bytes(mbgc_xchg_t *x, void *stream) {
     if (x->rccl) HIPX(hipStreamWaitEvent((hipStream_t) stream, x->evBytes, 0));
     return 0;                                             // (host memory: the all-gather had completed when _begin returned)

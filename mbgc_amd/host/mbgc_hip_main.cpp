@@ -72,6 +72,7 @@ int main(int argc, char **argv) {
         else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (a == "--exchange" && i + 1 < argc) transport = argv[++i];
         else if (a == "--shm-mb" && i + 1 < argc) shmMb = (size_t) atol(argv[++i]);
+        else if (a == "--ref-factor" && i + 1 < argc) params.referenceFactor = atoi(argv[++i]);   // MGMP_Params.h:205 (tests: a buffer small enough to wrap)
         else if (a == "--backend" && i + 1 < argc) backend = argv[++i];
         else if (a == "--backend-threads" && i + 1 < argc) backendThreads = atoi(argv[++i]);
         else pos.push_back(a);
@@ -188,5 +189,6 @@ int main(int argc, char **argv) {
     printf("extensions matched chars: %zu\n", enc.extensionsMatchedCharsAll);
     printf("final unmatched chars: %zu\n", enc.unmatchedChars() - enc.extensionsMatchedCharsAll);
     if (params.exchange) printf("rounds finalized on the ranks' device-side verdicts: %d\n", params.specRounds);
+    if (params.exchange) printf("rounds whose extension exchange carried only the loadable head: %d\n", params.headRounds);
     return finish(0);
 }

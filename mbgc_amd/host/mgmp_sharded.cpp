@@ -226,7 +226,28 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
             const uint8_t *src = B.seqDev;
             if (B.seqCap < mx) { ensure(padDev, mx); matcher->devCopy(padDev.p, B.seqDev, B.bytes); matcher->synchronize(); src = padDev.p; }
             ensure(ext, (size_t) N * mx);
-            xc(mbgc_xchg_allgather_bytes_begin(X, src, mx, ext.p));
+            // After the wrap the round's locks stand one window ahead of the loading position and loadRef clips there
+            // (SlidingWindowSparseEMMatcher.cpp:361-378, :412-417): what lies beyond that head of the round — target after
+            // target — is never read, and only the ranks that hold a part of the head send it.
+            const uint64_t lock = roundLocks[0], maxRef = matcher->getMaxRefLength(), pos1 = matcher->getLoadingPosition();
+            bool sameLocks = true;
+            for (uint32_t j = 1; j < ntot; j++) sameLocks &= roundLocks[j] == lock;
+            std::vector<uint64_t> need(N, 0);
+            uint64_t wanted = 0, all = 0;
+            if (sameLocks && lock < maxRef) {
+                const uint64_t cap = (lock > pos1 ? lock - pos1 : lock + (maxRef - 1) - pos1) + 4096;
+                uint64_t start = 0;
+                for (uint32_t r = 0; r < N; r++) {
+                    need[r] = start < cap ? std::min<uint64_t>(rankBytes[r], cap - start) : 0;
+                    start += rankBytes[r];
+                    wanted += need[r]; all += rankBytes[r];
+                }
+            }
+            if (all && wanted < all) {
+                xc(mbgc_xchg_bcast_heads_begin(X, src, need.data(), mx, ext.p));
+                params->headRounds++;
+            } else
+                xc(mbgc_xchg_allgather_bytes_begin(X, src, mx, ext.p));
         }
         std::vector<uint64_t> locks(ncont), un, counts;
         std::vector<int> factors(ncont);

@@ -84,3 +84,17 @@ def test_bench_mode_with_ranks(tmp_path):
     d = json.loads(out.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["rounds"] == 3 and d["bases"] == 12 * 300_000 and d["value"] > 0
     assert d["rounds_finalized_on_device_verdicts"] >= 1
+
+
+def test_a_wrapping_buffer_and_the_head_of_the_round(tmp_path):
+    """a buffer that wraps several times (--ref-factor 1: 4 MiB for 1 Mbp genomes): after the wrap a round's locks stand
+    one window ahead of the loading position, loadRef clips there, and the ranks exchange only that head of the round's
+    extensions (mbgc_xchg_bcast_heads_begin) — streams equal to the single-GPU rounds'"""
+    write_collection(tmp_path, 25, 1_000_000, 0.003, 1, seed=67)
+    one = run_tool(["c", "--ref-factor", "1", "-R", "4", "list.txt", "one"], str(tmp_path))
+    many = run_tool(["c", "--ref-factor", "1", "--gpus", "2", "--exchange", "hostmem", "--shm-mb", "1", "-R", "2", "list.txt", "many"], str(tmp_path))
+    a, b = dumps(tmp_path, "one"), dumps(tmp_path, "many")
+    for k in STREAMS:
+        assert a[k] == b[k], k
+    heads = int([x for x in many.splitlines() if x.startswith("rounds whose extension exchange carried only the loadable head")][0].split(":")[1])
+    assert heads >= 2, many
