@@ -42,6 +42,9 @@ typedef struct {
 
 const char *swsem_last_error(void);
 int swsem_device_count(void);
+/* NUMA node of the host memory closest to the device (its PCIe function's numa_node in sysfs), -1 when unknown: a host
+ * that reads files into page-locked memory for this device keeps its threads there */
+int swsem_device_numa_node(int device);
 
 /* SlidingWindowExpSparseEMMatcher::SlidingWindowExpSparseEMMatcher, SlidingWindowSparseEMMatcher.cpp:494-519
  * (+ base ctor :325-359, initParams :74-104). maxRefLength is explicit: the 60 %-of-RAM cap of

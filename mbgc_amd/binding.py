@@ -16,7 +16,7 @@ SKIPPED = 2 ** 64 - 1
 STREAM_NAMES = ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags")
 KERNEL_FAMILIES = ("load", "insert", "probe", "emit2", "resolve", "stitch", "emit")
 
-EXPORTS = """swsem_last_error swsem_device_count swsem_create swsem_destroy swsem_set_stream swsem_synchronize
+EXPORTS = """swsem_last_error swsem_device_count swsem_device_numa_node swsem_create swsem_destroy swsem_set_stream swsem_synchronize
 swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circular_buffer swsem_get_ref_length
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev

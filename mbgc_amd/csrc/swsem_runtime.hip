@@ -9,6 +9,7 @@
 #include "swsem_decode.hip"
 
 #include <algorithm>
+#include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -838,6 +839,20 @@ int swsem_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int swsem_device_numa_node(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int) sizeof bus, device) != hipSuccess) return -1;
+    for (char *c = bus; *c; c++) *c = (char) tolower((unsigned char) *c);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
 }
 
 int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, int skipMargin, int device) {

@@ -145,6 +145,7 @@ int main(int argc, char **argv) {
         }
         return rc;
     };
+    MultipleGenomeMatchingProcessor::bindHostThreadsToDeviceNode(params.device);
     MBGC_Encoder enc(&params);
     enc.encode(files);
     if (rank != 0) return finish(0);

@@ -10,6 +10,8 @@
 #include <functional>
 #include <thread>
 #include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -50,7 +52,7 @@ static void writeUInt64Frugal(std::string &dest, uint64_t value) {
 static double nowSeconds() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 // where the host's wall time goes (MBGC_HIP_TIMES=1 prints it with "matching finished"): reading + inflating files,
 // upload + device parse, taking the streams over
-static double g_tRead = 0, g_tParse = 0, g_tCollect = 0, g_tWait = 0;
+static double g_tRead = 0, g_tParse = 0, g_tCollect = 0, g_tWait = 0, g_tCollectWait = 0, g_tAppend = 0, g_tAppendWait = 0, g_tPrepareSync = 0, g_tReadWait = 0, g_tMatch = 0, g_tEmit = 0, g_tFinalize = 0;
 
 // ---------------------------------------------------------------- input stage
 // mgmpInOpen / whole-file read (MGMP.cpp:7-14; gz inflate is the host's libdeflate in the reference and is not part
@@ -130,8 +132,10 @@ static void validate_kseq_status(const std::string &fileName, int status) {
 
 MultipleGenomeMatchingProcessor::~MultipleGenomeMatchingProcessor() {
     if (matcher && rawDev) matcher->devFree(rawDev);
+    if (matcher && retryExt) matcher->devFree(retryExt);
     if (ahead.active) ahead.done.wait();
-    if (fasta && staged.pin) mbgc_fasta_host_free(fasta, staged.pin);
+    if (readAhead.active) readAhead.done.wait();
+    for (StagedFiles &S : staged) if (fasta && S.pin) mbgc_fasta_host_free(fasta, S.pin);
     if (fasta) mbgc_fasta_destroy(fasta);
     delete matcher;
 }
@@ -179,6 +183,7 @@ void MultipleGenomeMatchingProcessor::readG0(const std::string &path, std::vecto
 // files [f0, f1) of the list, each whole (inflated when gzip), back to back in page-locked memory: the sizes first (a
 // gzip file's is known once it is inflated), then every plain file read straight to its place, by up to 8 threads
 void MultipleGenomeMatchingProcessor::readFiles(StagedFiles &S, uint32_t f0, uint32_t f1) {
+    const double tRead0 = nowSeconds();
     S.error.clear();
     const size_t nf = f1 - f0;
     std::vector<int> fd(nf, -1);
@@ -189,7 +194,8 @@ void MultipleGenomeMatchingProcessor::readFiles(StagedFiles &S, uint32_t f0, uin
         std::atomic<size_t> next{0};
         auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < nf;) body(i); };
         std::vector<std::thread> pool;
-        for (size_t t = 1; t < std::min<size_t>(8, nf); t++) pool.emplace_back(work);
+        static const size_t readers = getenv("MBGC_HIP_READERS") ? (size_t) std::max(1, atoi(getenv("MBGC_HIP_READERS"))) : 8;
+        for (size_t t = 1; t < std::min<size_t>(readers, nf); t++) pool.emplace_back(work);
         work();
         for (auto &t : pool) t.join();
     };
@@ -234,6 +240,37 @@ void MultipleGenomeMatchingProcessor::readFiles(StagedFiles &S, uint32_t f0, uin
         if (fd[i] >= 0) close(fd[i]);
         if (S.error.empty() && !errors[i].empty()) S.error = errors[i];
     }
+    g_tRead += nowSeconds() - tRead0;                        // (one reader at a time)
+}
+
+void MultipleGenomeMatchingProcessor::startReadAhead(uint32_t f0, uint32_t f1, int slot) {
+    openInputStage();
+    readAhead.f0 = f0; readAhead.f1 = f1; readAhead.slot = slot; readAhead.active = true;
+    StagedFiles *S = &staged[slot];
+    readAhead.done = std::async(std::launch::async, [this, S, f0, f1] { readFiles(*S, f0, f1); });
+}
+
+void MultipleGenomeMatchingProcessor::bindHostThreadsToDeviceNode(int device) {
+    if (getenv("MBGC_HIP_NUMA") && !atoi(getenv("MBGC_HIP_NUMA"))) return;
+    const int node = swsem_device_numa_node(device);
+    if (node < 0) return;
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) { fclose(f); return; }
+    int a, b, any = 0;
+    while (fscanf(f, "%d", &a) == 1) {                       // "0-63,128-191"
+        b = a;
+        int c = fgetc(f);
+        if (c == '-') { if (fscanf(f, "%d", &b) != 1) break; c = fgetc(f); }
+        for (int k = a; k <= b && k < CPU_SETSIZE; k++) if (CPU_ISSET(k, &allowed)) { CPU_SET(k, &want); any++; }
+        if (c != ',') break;
+    }
+    fclose(f);
+    if (any >= 4) sched_setaffinity(0, sizeof want, &want);  // (never down to a handful of CPUs: the readers need theirs)
 }
 
 void MultipleGenomeMatchingProcessor::loadRound(uint32_t f0, uint32_t f1, RoundBatch &B, uint32_t nextF0, uint32_t nextF1, RoundBatch *nextB) {
@@ -245,28 +282,46 @@ void MultipleGenomeMatchingProcessor::loadRound(uint32_t f0, uint32_t f1, RoundB
         have = ahead.f0 == f0 && ahead.f1 == f1 && ahead.B == &B;
     }
     g_tWait += nowSeconds() - t0;
-    if (!have) prepareRound(f0, f1, B);
+    if (!have) { const double tp0 = nowSeconds(); prepareRound(f0, f1, B, nextF0, nextF1); g_tPrepareSync += nowSeconds() - tp0; }
     if (nextB && nextF1 > nextF0) {
+        // the round after the next one: the callers' rounds are ranges of equal length at equal distance (a wrong guess
+        // costs a read that nobody takes)
+        const uint64_t stride = nextF0 - f0, count = nextF1 - nextF0;
+        const uint32_t afterF0 = (uint32_t) std::min<uint64_t>(filesCount, nextF0 + stride);
+        const uint32_t afterF1 = (uint32_t) std::min<uint64_t>(filesCount, nextF0 + stride + count);
         ahead.f0 = nextF0; ahead.f1 = nextF1; ahead.B = nextB; ahead.active = true;
-        ahead.done = std::async(std::launch::async, [this, nextF0, nextF1, nextB] { prepareRound(nextF0, nextF1, *nextB); });
+        ahead.done = std::async(std::launch::async, [this, nextF0, nextF1, nextB, afterF0, afterF1] { prepareRound(nextF0, nextF1, *nextB, afterF0, afterF1); });
     }
 }
 
 // files [f0, f1) of the list -> their contigs back to back in B.seqDev; contig c belongs to target targetBase + (file - f0)
-void MultipleGenomeMatchingProcessor::prepareRound(uint32_t f0, uint32_t f1, RoundBatch &B) {
+void MultipleGenomeMatchingProcessor::prepareRound(uint32_t f0, uint32_t f1, RoundBatch &B, uint32_t afterF0, uint32_t afterF1) {
     openInputStage();
     const int nf = (int) (f1 - f0);
     if (nf <= 0) {                                           // (a rank without targets in a short last round)
         B.offsets.assign(1, 0); B.targetOf.clear(); B.bytes = 0;
         return;
     }
-    const double tRead0 = nowSeconds();
-    StagedFiles *S = &staged;
-    readFiles(*S, f0, f1);
+    const double tWait0 = nowSeconds();
+    StagedFiles *S = nullptr;
+    if (readAhead.active) {
+        readAhead.done.wait();
+        readAhead.active = false;
+        if (readAhead.f0 == f0 && readAhead.f1 == f1) S = &staged[readAhead.slot];
+    }
+    g_tReadWait += nowSeconds() - tWait0;
+    if (!S) { S = &staged[staged[1].cap > staged[0].cap ? 1 : 0]; readFiles(*S, f0, f1); }   // (the buffer that has been allocated)
     if (!S->error.empty()) { fprintf(stderr, "%s\n", S->error.c_str()); exit(EXIT_FAILURE); }
+    // (measured on the MI355X hosts: a round's read and the upload before it slow each other down by as much as running
+    // them together saves — 83 + 82 ms one after the other, 138 and 122 ms side by side, for 3.2 GB — so the read of the
+    // round after the next one runs beside the upload only when asked for; the very first round's read is started before
+    // the matcher is built, MBGC_Encoder::encode)
+    static const bool readBeside = getenv("MBGC_HIP_READ_BESIDE") && atoi(getenv("MBGC_HIP_READ_BESIDE"));
+    if (readBeside && afterF1 > afterF0 && afterF0 >= f1) {  // the files after these, into the other staging buffer, meanwhile
+        startReadAhead(afterF0, afterF1, S == &staged[0] ? 1 : 0);
+    }
     const std::vector<uint64_t> &fileOff = S->fileOff;
     const double tParse0 = nowSeconds();
-    g_tRead += tParse0 - tRead0;
     totalFilesLength += fileOff.back();
     const size_t n = fileOff.back();
     if (n + 64 > rawCap) {                                   // grow-only: freeing device memory waits for the whole device
@@ -407,38 +462,44 @@ void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
 // A round whose first pass gave up a contig as dissimilar (MGMP.cpp:382-388: "discard, wait until the earlier targets
 // are loaded, retry"): the deterministic form of that wait, with blocking calls — match + emit what is pending, load
 // the targets in front of the first given-up contig, redo everything from that contig on. Locks are held by the caller.
-void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B) {
+void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B, size_t expectTaken) {
     const std::vector<uint64_t> &offsets = B.offsets;
     const size_t ncont = B.targetOf.size();
     const uint32_t r0 = B.t0, r1 = B.t1;
     auto targetOf = [&](size_t c) { return B.t0 + B.targetOf[c]; };
     uint8_t *dev = B.seqDev;
-    std::vector<int> pending(ncont);
-    for (size_t c = 0; c < ncont; c++) pending[c] = (int) c;
+    size_t p0 = 0;                                                                              // contigs [p0, ncont) are pending
     std::vector<uint64_t> unmatched(ncont, SIZE_MAX);
     std::vector<EmittedStreams> emitted(ncont);
     uint32_t finalized = r0;                                                                    // == processedTargetsCount
+    // The pending contigs are matched against the reference as it stands, and the ones in front of the first given-up
+    // contig are taken. They are tried a stretch at a time — as many as twice what the last pass took, then twice that —
+    // and the pass stops at the first stretch that holds a given-up contig: what lies behind it would be matched again
+    // anyway (the first round of a collection of similar genomes takes one target per pass until the reference holds
+    // enough of them; matching all of the round's remaining targets in every pass would be 800 target scans for 40).
+    size_t took = std::min(ncont, expectTaken);                                                 // (the caller's first pass has seen where the first one is)
     while (true) {
         int cut = (int) ncont;                                                                  // first contig that has to be retried
-        if (!pending.empty()) {
-            // contigs from the first pending one on are consecutive in the buffer (everything after a cut is redone)
-            const int c0 = pending.front();
+        size_t stretch = std::max<size_t>(2, 2 * took), at = p0;
+        took = 0;
+        while (at < ncont && cut == (int) ncont) {
+            const size_t n = std::min(stretch, ncont - at);
             std::vector<uint64_t> offs, locks, counts;
             std::vector<int> factors;
             std::vector<int64_t> processed, tidx;
-            for (int c : pending) {
-                offs.push_back(offsets[c] - offsets[c0]);
+            for (size_t c = at; c < at + n; c++) {
+                offs.push_back(offsets[c] - offsets[at]);
                 locks.push_back(matchingLocksPos[targetOf(c)]);
                 factors.push_back(unmatchedFractionFactors[2 * targetOf(c)]);
                 processed.push_back(processedTargetsCount);
                 tidx.push_back(targetOf(c));
             }
-            offs.push_back(offsets[pending.back() + 1] - offsets[c0]);
-            matcher->matchRound(dev + offsets[c0], offs, params->k, locks, counts);            // :379
+            offs.push_back(offsets[at + n] - offsets[at]);
+            matcher->matchRound(dev + offsets[at], offs, params->k, locks, counts);            // :379
             std::vector<EmittedStreams> out;
             matcher->emitRound(emitParams(), locks, factors, processed, tidx, loadedPositions(), out);   // :381
-            for (size_t k = 0; k < pending.size(); k++) {
-                const int c = pending[k];
+            for (size_t k = 0; k < n; k++) {
+                const int c = (int) (at + k);
                 if (out[k].unmatchedChars == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) {   // :382-388
                     cut = std::min(cut, c);
                     continue;
@@ -447,8 +508,11 @@ void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B) {
                     unmatched[c] = out[k].unmatchedChars;
                     resCount += counts[k];
                     emitted[c] = std::move(out[k]);
+                    took++;
                 }
             }
+            at += n;
+            stretch *= 2;
         }
         // targets before the one holding the cut are complete: load their extensions in order (:433-468)
         const uint32_t upto = cut < (int) ncont ? targetOf(cut) : r1;
@@ -462,7 +526,12 @@ void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B) {
                     if (params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor)) extLen += len;
                 }
             if (extLen) {
-                uint8_t *ext = matcher->devAlloc(extLen);
+                if (extLen > retryExtCap) {                                                     // grow-only: freeing device memory waits for the whole device
+                    if (retryExt) matcher->devFree(retryExt);
+                    retryExtCap = extLen + extLen / 4 + 64;
+                    retryExt = matcher->devAlloc(retryExtCap);
+                }
+                uint8_t *ext = retryExt;
                 size_t pos = 0;
                 for (size_t c = 0; c < ncont; c++)
                     if (targetOf(c) == t) {
@@ -477,7 +546,6 @@ void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B) {
                         }
                     }
                 matcher->loadRefDev(ext, extLen, false, params->refRegionSeparators, REF_REGION_SEPARATOR);   // :441-443
-                matcher->devFree(ext);
             }
             // the target's streams: contig by contig, then the target separator
             for (size_t c = 0; c < ncont; c++)
@@ -492,8 +560,7 @@ void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B) {
         }
         finalized = upto;
         if (cut >= (int) ncont) break;
-        pending.clear();
-        for (int c = cut; c < (int) ncont; c++) pending.push_back(c);
+        p0 = (size_t) cut;
     }
 }
 
@@ -522,25 +589,54 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
     struct Deferred { bool valid = false; RoundBatch *B = nullptr; } prev;   // emission whose streams have not been taken yet
     uint8_t *extTmp = nullptr; size_t extCap = 0;                           // contig + reverse complement extension strings
     int predicted = -1;                                                     // what every contig of the last round decided (-1: no prediction)
-    auto collect = [&](RoundBatch &B, bool newerBegun) {                    // per-target stream merge, ENC.cpp:542-556
+    // per-target stream merge, ENC.cpp:542-556: the views of a round's streams (page-locked memory of the emission slot)
+    // are appended to the collection's strings by a thread of its own, while the next round is matched — the slot's
+    // memory belongs to the emission after the next one, so the appends are waited for before that one begins
+    std::future<void> appending;
+    auto appendsDone = [&] { if (appending.valid()) appending.get(); };
+    auto collect = [&](RoundBatch &B, bool newerBegun) {
         const double tc0 = nowSeconds();
+        appendsDone();
         if (newerBegun) matcher->emitSelect(true);
+        if (!bench && !B.targetOf.empty()) { swsem_streams_t st = {}; matcher->emitView(0, st); }   // (waits for the emission and its copy)
+        g_tCollectWait += nowSeconds() - tc0;
+        auto views = std::make_shared<std::vector<swsem_streams_t>>();
+        auto perTarget = std::make_shared<std::vector<uint32_t>>();
         size_t c = 0;                                                       // (the contigs of a round are in target order)
         for (uint32_t t = B.t0; t < B.t1; t++) {
+            uint32_t k = 0;
             for (; c < B.targetOf.size() && B.t0 + B.targetOf[c] == t; c++) {
                 if (bench) continue;                                        // bench: the bytes stay packed in HBM, as in bench.py
                 swsem_streams_t st = {};
                 matcher->emitView((int) c, st);
-                appendContigInOrder(st);
+                views->push_back(st);
+                k++;
             }
-            if (!bench) endTargetInOrder();
+            perTarget->push_back(k);
         }
         if (newerBegun) matcher->emitSelect(false);
+        if (!bench)
+            appending = std::async(std::launch::async, [this, views, perTarget] {
+                const double ta0 = nowSeconds();
+                size_t v = 0;
+                for (uint32_t k : *perTarget) {
+                    for (uint32_t i = 0; i < k; i++) appendContigInOrder((*views)[v++]);
+                    endTargetInOrder();
+                }
+                g_tAppend += nowSeconds() - ta0;
+            });
         g_tCollect += nowSeconds() - tc0;
     };
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
     double tStart = 0;
+    const char *perRound = getenv("MBGC_HIP_TIMES");
+    double tRound = nowSeconds();
     for (uint32_t r = 0; r < nRounds; r++) {
+        if (perRound && perRound[0] == '2') {
+            const double t = nowSeconds();
+            if (r) fprintf(stderr, "  round %u: %.1f ms\n", r - 1, (t - tRound) * 1e3);
+            tRound = t;
+        }
         RoundBatch &B = slots[bench ? r : r % 3];
         if (!bench) {
             B.t0 = r * R; B.t1 = std::min(targetsCount, (r + 1) * R);
@@ -559,6 +655,8 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             matchingLocksPos[t] = matcher->acquireWorkerMatchingLockPos();                      // :353-358
         }
         if (ncont == 0) {                                                                       // files without a record
+            if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); prev.valid = false; }
+            appendsDone();
             for (uint32_t t = B.t0; t < B.t1; t++) {
                 const size_t startPos = matcher->getLoadedRefLength();
                 processAfterTarget(t);
@@ -584,7 +682,9 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             if (!tHas[lt]) { tBeg[lt] = B.offsets[c]; tHas[lt] = 1; }
             tEnd[lt] = B.offsets[c + 1];
         }
+        const double tm0 = nowSeconds();
         matcher->matchRoundBegin(B.seqDev, B.offsets, params->k, locks);                        // :379
+        g_tMatch += nowSeconds() - tm0;
         // the round's finalize under the prediction "every contig decides as the last round's did"
         std::vector<const uint8_t *> extDev(T, nullptr);
         std::vector<uint64_t> extLen(T, 0), loadedAfter(T, 0);
@@ -602,15 +702,23 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             spec.factor = params->currentUnmatchedFractionFactor; spec.rcFactor = params->rcInReference ? params->unmatchedFractionRCFactor : 0;
         }
         const size_t before = matcher->getLoadedRefLength();
+        const double ta0 = nowSeconds();
+        appendsDone();                                                      // (this emission's slot is the one those views point into)
+        const double te0 = nowSeconds();
+        g_tAppendWait += te0 - ta0;
         const bool applied = matcher->emitRoundBegin(emitParams(), locks, factors, processed, tidx, loadedPositions(),
                                                      useSpec ? &spec : nullptr, un, counts);   // :381
+        g_tEmit += nowSeconds() - te0;
         bool skipped = false;
         for (size_t c = 0; c < ncont; c++) skipped |= un[c] == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY;
         if (skipped) {                                                      // (nothing was applied: the library checks the same condition)
             if (prev.valid) { collect(*prev.B, true); prev.valid = false; }
+            appendsDone();
             matcher->emitEnd();
             predicted = -1;
-            processRoundWithRetries(B);
+            size_t firstGivenUp = 0;
+            while (firstGivenUp < ncont && un[firstGivenUp] != PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) firstGivenUp++;
+            processRoundWithRetries(B, firstGivenUp);
             continue;
         }
         for (size_t c = 0; c < ncont; c++) resCount += counts[c];
@@ -651,7 +759,9 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
                     }
                 if (at > start) { extDev[t] = extTmp + start; extLen[t] = at - start; }
             }
+            const double tf0 = nowSeconds();
             matcher->finalizeTargets(extDev, extLen, params->refRegionSeparators, REF_REGION_SEPARATOR, lazyMode(), tlocks, loadedAfter);   // :440-457
+            g_tFinalize += nowSeconds() - tf0;
         }
         size_t startPos = before;
         for (uint32_t t = 0; t < T; t++) {
@@ -665,6 +775,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
         predicted = (!anyRC && (allExt || noneExt)) ? (allExt ? 1 : 0) : -1;
     }
     if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); }
+    appendsDone();
     matcher->synchronize();
     if (bench) {
         params->benchSeconds = now() - tStart;
@@ -693,8 +804,9 @@ void MultipleGenomeMatchingProcessor::performMatching() {
     if (!params->benchMode && (!params->exchange || mbgc_xchg_rank(params->exchange) == 0))
         fprintf(stderr, "matching finished - %.0f [ms]\n", (nowSeconds() - t0) * 1e3);
     if (getenv("MBGC_HIP_TIMES"))
-        fprintf(stderr, "  input thread: reading files %.0f ms, upload + parse %.0f ms; main thread: waiting for it %.0f ms, taking the streams over %.0f ms\n",
-                g_tRead * 1e3, g_tParse * 1e3, g_tWait * 1e3, g_tCollect * 1e3);
+        fprintf(stderr, "  reader threads: reading files %.0f ms; input thread: waiting for them %.0f ms, upload + parse %.0f ms; main thread: waiting for it %.0f ms, taking the streams over %.0f ms"
+                        " (%.0f of them waiting for the bytes; appends on their thread %.0f ms, waited for %.0f ms); rounds prepared by the main thread itself %.0f ms; match-finding calls %.0f ms, processMatches' first pass %.0f ms, loadRef calls %.0f ms\n",
+                g_tRead * 1e3, g_tReadWait * 1e3, g_tParse * 1e3, g_tWait * 1e3, g_tCollect * 1e3, g_tCollectWait * 1e3, g_tAppend * 1e3, g_tAppendWait * 1e3, g_tPrepareSync * 1e3, g_tMatch * 1e3, g_tEmit * 1e3, g_tFinalize * 1e3);
 }
 
 // ---------------------------------------------------------------- MBGC_Encoder
@@ -742,7 +854,29 @@ void MBGC_Encoder::takeRoundStreams(uint32_t targetIdx, EmittedStreams &s) {
 // takeRoundStreams + processAfterSequence, then processAfterTarget + appendTargetStreams, for targets that arrive in target
 // order: the bytes are appended where appendTargetStreams would put them (ENC.cpp:543-556, :489-496) without the stop in
 // the per-target strings
+// (room for what is coming: a stream's string grows to what the targets so far project for the whole collection —
+// doubling through hundreds of megabytes copies them and touches fresh pages again and again)
+static const uintptr_t HUGE_PAGE = 2u << 20;
+static void makeRoom(std::string &s, size_t add, uint32_t targetsDone, uint32_t targetsAll) {
+    const size_t need = s.size() + add;
+    if (need <= s.capacity()) return;
+    size_t want = std::max(need, 2 * s.capacity());
+    if (targetsDone && targetsAll > targetsDone) {
+        const size_t projected = need / targetsDone * targetsAll + need / 8;
+        want = std::max(want, std::min(projected, 16 * need));
+    }
+    s.reserve(want);
+    // (fresh memory in 2 MB pages where the system lets a program ask for them: 4 KB page faults cost more than the copy)
+    const uintptr_t a = ((uintptr_t) s.data() + s.size() + (HUGE_PAGE - 1)) & ~(uintptr_t) (HUGE_PAGE - 1), b = ((uintptr_t) s.data() + s.capacity()) & ~(uintptr_t) (HUGE_PAGE - 1);
+    if (b > a) madvise((void *) a, b - a, MADV_HUGEPAGE);
+}
+
 void MBGC_Encoder::appendContigInOrder(const swsem_streams_t &st) {
+    makeRoom(literals, st.size[SWSEM_LIT] + 1, targetsAppended + 1, targetsCount);
+    makeRoom(mapOff, st.size[SWSEM_OFF], targetsAppended + 1, targetsCount);
+    makeRoom(mapLen, st.size[SWSEM_LEN], targetsAppended + 1, targetsCount);
+    makeRoom(gapDeltas, st.size[SWSEM_GAP], targetsAppended + 1, targetsCount);
+    makeRoom(gapMismatchesFlags, st.size[SWSEM_FLAGS] + 1, targetsAppended + 1, targetsCount);
     literals.append((const char *) st.data[SWSEM_LIT], st.size[SWSEM_LIT]);
     literals.push_back(SEQ_SEPARATOR_MARK);
     mapOff.append((const char *) st.data[SWSEM_OFF], st.size[SWSEM_OFF]);
@@ -758,6 +892,7 @@ void MBGC_Encoder::appendContigInOrder(const swsem_streams_t &st) {
 }
 
 void MBGC_Encoder::endTargetInOrder() {
+    targetsAppended++;
     if (params->emit.enableExtensionsWithMismatches) gapMismatchesFlags.push_back(FILE_SEPARATOR_MARK);
 }
 
@@ -826,6 +961,10 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
     }
     if (filesCount == 1) params->sequentialMatching = true;                                     // no targets for the round loop
     params->emit.lazyDecompressionSupport = params->lazyDecompressionSupport;
+    // the first round's files are read (and their page-locked buffer allocated) while the reference file is parsed and the
+    // matcher's reference buffer and table are set up
+    if (!params->sequentialMatching && !params->exchange)
+        startReadAhead(1, std::min<uint32_t>(filesCount, 1 + (uint32_t) std::max(1, params->roundSize)), 1);
     loadG0Ref(fileNames[0]);
     params->emit.enable40bitReference = params->enable40bitReference;
     if (params->lazyDecompressionSupport) refExtLoadedPosArr.emplace_back(matcher->getLoadingPosition());   // ENC.cpp:789-791

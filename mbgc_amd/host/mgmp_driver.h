@@ -90,22 +90,27 @@ protected:
     void performMatching();                                                             // :568-606
     void processTargetsWithParallelIO();                                                // :232-313  (-t1)
     void processTargetsRounds();                                                        // :340-468 as deterministic rounds
-    void processRoundWithRetries(RoundBatch &B);                                        // a round holding a dissimilar contig (:382-388), blocking calls
+    void processRoundWithRetries(RoundBatch &B, size_t expectTaken = SIZE_MAX);                                        // a round holding a dissimilar contig (:382-388), blocking calls
     void processTargetsRoundsSharded();                                                 // the rounds with their targets sharded over the ranks of params->exchange (mgmp_sharded.cpp)
     // input stage (MGMP.cpp:7-35,349-372 on the device parser)
     mbgc_fasta_t *fasta = nullptr;
     // The files of a round in page-locked host memory, read (and inflated) by several threads. The round named as "next"
     // is read, uploaded and parsed by a thread of its own while the GPU and the host work on the current one (the
     // reference reads ahead with its IO threads too, MGMP.cpp:232-313 "WithParallelIO").
+    // The thread that uploads and parses round r + 1 has the files of round r + 2 read meanwhile (two staging buffers).
     struct StagedFiles {
         uint8_t *pin = nullptr; size_t cap = 0;
         std::vector<uint64_t> fileOff;
         std::string error;
-    } staged;
+    } staged[2];
     struct Ahead { std::future<void> done; uint32_t f0 = 0, f1 = 0; RoundBatch *B = nullptr; bool active = false; } ahead;
+    struct ReadAhead { std::future<void> done; uint32_t f0 = 0, f1 = 0; int slot = 0; bool active = false; } readAhead;
     void readFiles(StagedFiles &S, uint32_t f0, uint32_t f1);
-    void prepareRound(uint32_t f0, uint32_t f1, RoundBatch &B);                         // read + upload + device parse, synchronous
+    void startReadAhead(uint32_t f0, uint32_t f1, int slot);                            // files [f0, f1) into staged[slot], on a thread of its own
+    // read (unless read ahead) + upload + device parse, synchronous; [afterF0, afterF1) = the files to read meanwhile
+    void prepareRound(uint32_t f0, uint32_t f1, RoundBatch &B, uint32_t afterF0 = 0, uint32_t afterF1 = 0);
     uint8_t *rawDev = nullptr; size_t rawCap = 0;
+    uint8_t *retryExt = nullptr; size_t retryExtCap = 0;                                // extension strings of processRoundWithRetries
     std::vector<mbgc_fasta_record_t> records;
     void openInputStage();
     void readG0(const std::string &path, std::vector<Contig> &out, uint64_t *fileSize);
@@ -137,6 +142,10 @@ protected:
 
 public:
     explicit MultipleGenomeMatchingProcessor(MGMP_Params *p) : params(p) {}
+    // the calling thread (and the threads it starts from now on) onto the CPUs of the NUMA node the device hangs on:
+    // the files travel page cache -> page-locked memory -> device, and page-locked memory is allocated next to the device
+    // (MBGC_HIP_NUMA=0 leaves the threads where they are)
+    static void bindHostThreadsToDeviceNode(int device);
     virtual ~MultipleGenomeMatchingProcessor();
 };
 
@@ -144,6 +153,7 @@ class MBGC_Encoder : public MultipleGenomeMatchingProcessor {
     MBGC_Params *params;
     std::vector<size_t> refExtLoadedPosArr;                                             // MBGC_Encoder.h:48
     std::vector<EmittedStreams> targetStreams;                                          // per-target streams (round mode)
+    uint32_t targetsAppended = 0;                                                       // targets whose streams arrived in order
 
     void initStreamsForG0Ref() override;                                                // ENC.cpp:25-32
     void processG0RefContig(const char *seq, size_t len) override;                      // :34-37

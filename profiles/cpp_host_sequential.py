@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""`mbgc-hip c -t1` and `-m 3` (the sequential schedule: every target is matched against a reference that already holds
-the one before it, MGMP.cpp:232-313) on synthetic 5 Mbp genomes: the tool's own "matching finished" clock.
+"""`mbgc-hip c` from FASTA files in the page cache to the streams in host memory, on synthetic 5 Mbp genomes: `-t1` and
+`-m 3` (the sequential schedule: every target is matched against a reference that already holds the one before it,
+MGMP.cpp:232-313) and rounds of 40 — the tool's own "matching finished" clock, the rounds' wall times (MBGC_HIP_TIMES=2)
+and where the host threads' time went.
 usage: cpp_host_sequential.py [targets=128]"""
 import json
 import os
@@ -29,12 +31,21 @@ out = {}
 for name, args in (("t1", ["-t1"]), ("m3", ["-m", "3"]), ("rounds_of_40", ["-R", "40"])):
     t0 = time.time()
     r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c"] + args + [os.path.join(d, "list.txt"), os.path.join(d, "out")],
-                       capture_output=True, text=True, env=dict(os.environ, MBGC_HIP_TIMES="1"))
+                       capture_output=True, text=True, env=dict(os.environ, MBGC_HIP_TIMES="2"))
     wall = time.time() - t0
     sys.stderr.write(r.stderr[-600:])
     m = re.search(r"matching finished - (\d+) \[ms\]", r.stderr)
     ms = int(m.group(1)) if m else None
     out[name] = dict(rc=r.returncode, wall_s=round(wall, 2), matching_ms=ms,
                      gbases_per_s=round(n * 5e6 / (ms / 1e3) / 1e9, 3) if ms else None)
+    rounds = [float(x) for x in re.findall(r"round \d+: ([0-9.]+) ms", r.stderr)]
+    if rounds:
+        tail = sorted(rounds[len(rounds) // 2:])
+        out[name]["round_ms"] = rounds
+        out[name]["round_ms_median_of_second_half"] = tail[len(tail) // 2]
+        out[name]["gbases_per_s_at_that_round_time"] = round(40 * 5e6 / (tail[len(tail) // 2] / 1e3) / 1e9, 2)
+    where = [x.strip() for x in r.stderr.splitlines() if "reader threads:" in x]
+    if where:
+        out[name]["host_threads"] = where[-1]
 print(json.dumps(dict(targets=n, genome_len=5_000_000, runs=out)))
 subprocess.run(["rm", "-rf", d])
