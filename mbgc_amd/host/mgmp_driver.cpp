@@ -243,11 +243,25 @@ void MultipleGenomeMatchingProcessor::readFiles(StagedFiles &S, uint32_t f0, uin
     g_tRead += nowSeconds() - tRead0;                        // (one reader at a time)
 }
 
-void MultipleGenomeMatchingProcessor::startReadAhead(uint32_t f0, uint32_t f1, int slot) {
+static bool readBesideUpload() {
+    // MBGC_HIP_READ_BESIDE=0: a round's files are read by the thread that then uploads and parses them, nothing beside it
+    static const bool on = !getenv("MBGC_HIP_READ_BESIDE") || atoi(getenv("MBGC_HIP_READ_BESIDE"));
+    return on;
+}
+
+void MultipleGenomeMatchingProcessor::startReadAhead(uint32_t f0, uint32_t f1, int slot, bool bothBuffers) {
     openInputStage();
     readAhead.f0 = f0; readAhead.f1 = f1; readAhead.slot = slot; readAhead.active = true;
-    StagedFiles *S = &staged[slot];
-    readAhead.done = std::async(std::launch::async, [this, S, f0, f1] { readFiles(*S, f0, f1); });
+    StagedFiles *S = &staged[slot], *O = &staged[1 - slot];
+    readAhead.done = std::async(std::launch::async, [this, S, O, f0, f1, bothBuffers] {
+        readFiles(*S, f0, f1);
+        // (page-locking a round's worth of memory takes tens of milliseconds and holds up the uploads queued meanwhile: the
+        // second staging buffer is made here, beside the matcher's construction, not beside the first round)
+        if (bothBuffers && S->error.empty() && O->cap < S->cap) {
+            void *p = nullptr;
+            if (mbgc_fasta_host_alloc(fasta, S->cap, &p) == 0) { O->pin = (uint8_t *) p; O->cap = S->cap; }
+        }
+    });
 }
 
 void MultipleGenomeMatchingProcessor::bindHostThreadsToDeviceNode(int device) {
@@ -312,12 +326,7 @@ void MultipleGenomeMatchingProcessor::prepareRound(uint32_t f0, uint32_t f1, Rou
     g_tReadWait += nowSeconds() - tWait0;
     if (!S) { S = &staged[staged[1].cap > staged[0].cap ? 1 : 0]; readFiles(*S, f0, f1); }   // (the buffer that has been allocated)
     if (!S->error.empty()) { fprintf(stderr, "%s\n", S->error.c_str()); exit(EXIT_FAILURE); }
-    // (measured on the MI355X hosts: a round's read and the upload before it slow each other down by as much as running
-    // them together saves — 83 + 82 ms one after the other, 138 and 122 ms side by side, for 3.2 GB — so the read of the
-    // round after the next one runs beside the upload only when asked for; the very first round's read is started before
-    // the matcher is built, MBGC_Encoder::encode)
-    static const bool readBeside = getenv("MBGC_HIP_READ_BESIDE") && atoi(getenv("MBGC_HIP_READ_BESIDE"));
-    if (readBeside && afterF1 > afterF0 && afterF0 >= f1) {  // the files after these, into the other staging buffer, meanwhile
+    if (readBesideUpload() && afterF1 > afterF0 && afterF0 >= f1) {  // the files after these, into the other staging buffer, meanwhile
         startReadAhead(afterF0, afterF1, S == &staged[0] ? 1 : 0);
     }
     const std::vector<uint64_t> &fileOff = S->fileOff;
@@ -862,8 +871,8 @@ static void makeRoom(std::string &s, size_t add, uint32_t targetsDone, uint32_t 
     if (need <= s.capacity()) return;
     size_t want = std::max(need, 2 * s.capacity());
     if (targetsDone && targetsAll > targetsDone) {
-        const size_t projected = need / targetsDone * targetsAll + need / 8;
-        want = std::max(want, std::min(projected, 16 * need));
+        const size_t projected = need / targetsDone * targetsAll * 3 / 2;              // (untouched pages cost nothing)
+        want = std::max(want, std::min(projected, (targetsDone < 8 ? 16 : 64) * need));   // (one target says little about a thousand)
     }
     s.reserve(want);
     // (fresh memory in 2 MB pages where the system lets a program ask for them: 4 KB page faults cost more than the copy)
@@ -930,6 +939,7 @@ void MBGC_Encoder::initParallelProcessing() { targetStreams.assign(targetsCount,
 void MBGC_Encoder::finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t matcherLoaderStartPos) {
     appendStreams(*this, targetStreams[targetIdx]);                                             // ENC.cpp:543-556
     targetStreams[targetIdx] = EmittedStreams();
+    targetsAppended++;
     if (params->lazyDecompressionSupport) {
         matcher->loadSeparator(REF_REGION_SEPARATOR);
         const size_t refExtSize = matcher->getLoadedRefLength() - matcherLoaderStartPos;
@@ -950,6 +960,7 @@ void MBGC_Encoder::noteTargetLoaded(uint32_t targetIdx, size_t matcherLoaderStar
 void MBGC_Encoder::appendTargetStreams(uint32_t targetIdx) {
     appendStreams(*this, targetStreams[targetIdx]);                                             // ENC.cpp:543-556
     targetStreams[targetIdx] = EmittedStreams();
+    targetsAppended++;
 }
 
 void MBGC_Encoder::encode(const std::vector<std::string> &files) {
@@ -964,7 +975,7 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
     // the first round's files are read (and their page-locked buffer allocated) while the reference file is parsed and the
     // matcher's reference buffer and table are set up
     if (!params->sequentialMatching && !params->exchange)
-        startReadAhead(1, std::min<uint32_t>(filesCount, 1 + (uint32_t) std::max(1, params->roundSize)), 1);
+        startReadAhead(1, std::min<uint32_t>(filesCount, 1 + (uint32_t) std::max(1, params->roundSize)), 1, readBesideUpload());
     loadG0Ref(fileNames[0]);
     params->emit.enable40bitReference = params->enable40bitReference;
     if (params->lazyDecompressionSupport) refExtLoadedPosArr.emplace_back(matcher->getLoadingPosition());   // ENC.cpp:789-791

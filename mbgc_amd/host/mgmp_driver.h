@@ -106,7 +106,7 @@ protected:
     struct Ahead { std::future<void> done; uint32_t f0 = 0, f1 = 0; RoundBatch *B = nullptr; bool active = false; } ahead;
     struct ReadAhead { std::future<void> done; uint32_t f0 = 0, f1 = 0; int slot = 0; bool active = false; } readAhead;
     void readFiles(StagedFiles &S, uint32_t f0, uint32_t f1);
-    void startReadAhead(uint32_t f0, uint32_t f1, int slot);                            // files [f0, f1) into staged[slot], on a thread of its own
+    void startReadAhead(uint32_t f0, uint32_t f1, int slot, bool bothBuffers = false);                            // files [f0, f1) into staged[slot], on a thread of its own
     // read (unless read ahead) + upload + device parse, synchronous; [afterF0, afterF1) = the files to read meanwhile
     void prepareRound(uint32_t f0, uint32_t f1, RoundBatch &B, uint32_t afterF0 = 0, uint32_t afterF1 = 0);
     uint8_t *rawDev = nullptr; size_t rawCap = 0;

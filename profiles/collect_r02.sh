@@ -29,6 +29,6 @@ for c in FETCH_SIZE WRITE_SIZE tcc sq1 sq2; do python3 profiles/pmc_summary.py $
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; rm -rf $O/kt
 python3 profiles/kernel_stats.py $O | head -12
 tail -1 $O/bench_full.json | cut -c1-400
-timeout -k 10 600 python3 profiles/cpp_host_sequential.py 640 > $O/cpp_end_to_end.json 2>$O/cpp_end_to_end.err || exit 1
+timeout -k 10 600 python3 profiles/cpp_host_sequential.py 1000 > $O/cpp_end_to_end.json 2>$O/cpp_end_to_end.err || exit 1
 MBGC_BENCH_ONE_DEVICE=1 MBGC_BENCH_BACKEND=gloo timeout -k 10 500 python3 bench.py --gpus 2 --steps 6 --warmup 3 --cpu-sample 0 > $O/bench_n2_gloo.json 2>$O/bench_n2_gloo.err || exit 1
 tail -1 $O/cpp_end_to_end.json | cut -c1-300

@@ -28,7 +28,7 @@ for i, g in zip(range(n + 1), synth.genomes(base, list(range(n + 1)))):
 with open(os.path.join(d, "list.txt"), "w") as f:
     f.write("\n".join(paths) + "\n")
 out = {}
-for name, args in (("t1", ["-t1"]), ("m3", ["-m", "3"]), ("rounds_of_40", ["-R", "40"])):
+for name, args in (("rounds_of_40", ["-R", "40"]), ("t1", ["-t1"]), ("m3", ["-m", "3"])):
     t0 = time.time()
     r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c"] + args + [os.path.join(d, "list.txt"), os.path.join(d, "out")],
                        capture_output=True, text=True, env=dict(os.environ, MBGC_HIP_TIMES="2"))
