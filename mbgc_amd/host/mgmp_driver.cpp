@@ -132,7 +132,7 @@ static void validate_kseq_status(const std::string &fileName, int status) {
 
 MultipleGenomeMatchingProcessor::~MultipleGenomeMatchingProcessor() {
     if (matcher && rawDev) matcher->devFree(rawDev);
-    if (matcher && retryExt) matcher->devFree(retryExt);
+    if (matcher && extScratch) matcher->devFree(extScratch);
     if (ahead.active) ahead.done.wait();
     if (readAhead.active) readAhead.done.wait();
     for (StagedFiles &S : staged) if (fasta && S.pin) mbgc_fasta_host_free(fasta, S.pin);
@@ -468,6 +468,49 @@ void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
     for (auto &B : three) if (B.seqDev) matcher->devFree(B.seqDev);
 }
 
+// The extension strings of the targets [ta, tb) of a round (indices inside the round), :389-398: a target's contigs (and
+// reverse complements) that extend the reference, in order. A target loaded whole and without reverse complements is the
+// span of its contigs in the round's buffer; the others are put together in a grow-only scratch buffer.
+void MultipleGenomeMatchingProcessor::extensionStrings(const RoundBatch &B, const std::vector<char> &ext, const std::vector<char> &rc,
+                                                       uint32_t ta, uint32_t tb, std::vector<const uint8_t *> &extDev, std::vector<uint64_t> &extLen) {
+    const size_t ncont = B.targetOf.size();
+    const uint32_t T = tb - ta;
+    extDev.assign(T, nullptr); extLen.assign(T, 0);
+    std::vector<char> whole(T, 1), has(T, 0);
+    std::vector<uint64_t> beg(T, 0), end(T, 0);
+    size_t need = 0;
+    for (size_t c = 0; c < ncont; c++) {
+        const uint32_t t = B.targetOf[c];
+        if (t < ta || t >= tb) continue;
+        if (!has[t - ta]) { beg[t - ta] = B.offsets[c]; has[t - ta] = 1; }
+        end[t - ta] = B.offsets[c + 1];
+        if (!ext[c] || rc[c]) whole[t - ta] = 0;
+    }
+    for (size_t c = 0; c < ncont; c++) {
+        const uint32_t t = B.targetOf[c];
+        if (t >= ta && t < tb && !whole[t - ta]) need += ((ext[c] ? 1 : 0) + (rc[c] ? 1 : 0)) * (B.offsets[c + 1] - B.offsets[c]);
+    }
+    if (need > extScratchCap) {                              // grow-only: freeing device memory waits for the whole device
+        if (extScratch) matcher->devFree(extScratch);
+        extScratchCap = need + need / 2 + 64;
+        extScratch = matcher->devAlloc(extScratchCap);
+    }
+    size_t at = 0, c = 0;
+    for (uint32_t t = ta; t < tb; t++) {
+        const uint32_t k = t - ta;
+        if (!has[k]) continue;
+        if (whole[k]) { if (end[k] > beg[k]) { extDev[k] = B.seqDev + beg[k]; extLen[k] = end[k] - beg[k]; } continue; }
+        const size_t start = at;
+        for (c = 0; c < ncont; c++)
+            if (B.targetOf[c] == t) {
+                const size_t len = B.offsets[c + 1] - B.offsets[c];
+                if (ext[c]) { matcher->devCopy(extScratch + at, B.seqDev + B.offsets[c], len); at += len; }
+                if (rc[c]) { matcher->devRevComp(B.seqDev + B.offsets[c], len, extScratch + at); at += len; }    // :393-398
+            }
+        if (at > start) { extDev[k] = extScratch + start; extLen[k] = at - start; }
+    }
+}
+
 // A round whose first pass gave up a contig as dissimilar (MGMP.cpp:382-388: "discard, wait until the earlier targets
 // are loaded, retry"): the deterministic form of that wait, with blocking calls — match + emit what is pending, load
 // the targets in front of the first given-up contig, redo everything from that contig on. Locks are held by the caller.
@@ -523,49 +566,36 @@ void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B, siz
             at += n;
             stretch *= 2;
         }
-        // targets before the one holding the cut are complete: load their extensions in order (:433-468)
+        // targets before the one holding the cut are complete: load their extensions in order (:433-468), all in one call
         const uint32_t upto = cut < (int) ncont ? targetOf(cut) : r1;
-        for (uint32_t t = finalized; t < upto; t++) {
-            const size_t startPos = matcher->getLoadedRefLength();
-            size_t extLen = 0;
-            for (size_t c = 0; c < ncont; c++)
-                if (targetOf(c) == t) {
-                    const size_t len = offsets[c + 1] - offsets[c];
-                    if (params->isContigProperForRefExtension(len, unmatched[c], unmatchedFractionFactors[2 * t])) extLen += len;     // :389-392
-                    if (params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor)) extLen += len;
-                }
-            if (extLen) {
-                if (extLen > retryExtCap) {                                                     // grow-only: freeing device memory waits for the whole device
-                    if (retryExt) matcher->devFree(retryExt);
-                    retryExtCap = extLen + extLen / 4 + 64;
-                    retryExt = matcher->devAlloc(retryExtCap);
-                }
-                uint8_t *ext = retryExt;
-                size_t pos = 0;
+        if (upto > finalized) {
+            std::vector<char> ext(ncont, 0), rc(ncont, 0);
+            for (size_t c = 0; c < ncont; c++) {
+                const uint32_t t = targetOf(c);
+                if (t < finalized || t >= upto) continue;
+                const size_t len = offsets[c + 1] - offsets[c];
+                ext[c] = params->isContigProperForRefExtension(len, unmatched[c], unmatchedFractionFactors[2 * t]);                 // :389-392
+                rc[c] = params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor);
+            }
+            std::vector<const uint8_t *> extDev;
+            std::vector<uint64_t> extLen, loadedAfter, tlocks;
+            extensionStrings(B, ext, rc, finalized - r0, upto - r0, extDev, extLen);
+            for (uint32_t t = finalized; t < upto; t++) tlocks.push_back(matchingLocksPos[t]);
+            size_t startPos = matcher->getLoadedRefLength();
+            matcher->finalizeTargets(extDev, extLen, params->refRegionSeparators, REF_REGION_SEPARATOR, lazyMode(), tlocks, loadedAfter);   // :440-457
+            for (uint32_t t = finalized; t < upto; t++) {
+                // the target's streams: contig by contig, then the target separator
                 for (size_t c = 0; c < ncont; c++)
                     if (targetOf(c) == t) {
-                        const size_t len = offsets[c + 1] - offsets[c];
-                        if (params->isContigProperForRefExtension(len, unmatched[c], unmatchedFractionFactors[2 * t])) {
-                            matcher->devCopy(ext + pos, dev + offsets[c], len);
-                            pos += len;
-                        }
-                        if (params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor)) {
-                            matcher->devRevComp(dev + offsets[c], len, ext + pos);              // :393-398
-                            pos += len;
-                        }
+                        takeRoundStreams(t, emitted[c]);
+                        processAfterSequence(t);
                     }
-                matcher->loadRefDev(ext, extLen, false, params->refRegionSeparators, REF_REGION_SEPARATOR);   // :441-443
+                processAfterTarget(t);
+                appendTargetStreams(t);                                                         // ENC.cpp:543-556
+                noteTargetLoaded(t, startPos, loadedAfter[t - finalized]);                      // :557-563
+                startPos = loadedAfter[t - finalized];
+                processedTargetsCount = t + 1;
             }
-            // the target's streams: contig by contig, then the target separator
-            for (size_t c = 0; c < ncont; c++)
-                if (targetOf(c) == t) {
-                    takeRoundStreams(t, emitted[c]);
-                    processAfterSequence(t);
-                }
-            processAfterTarget(t);
-            finalizeParallelProcessingOfTarget(t, startPos);                                    // :455
-            matcher->releaseWorkerMatchingLockPos(matchingLocksPos[t]);                         // :456
-            processedTargetsCount = t + 1;
         }
         finalized = upto;
         if (cut >= (int) ncont) break;
@@ -596,7 +626,6 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
                       r + 1 < nRounds ? &slots[r + 1] : nullptr);
         }
     struct Deferred { bool valid = false; RoundBatch *B = nullptr; } prev;   // emission whose streams have not been taken yet
-    uint8_t *extTmp = nullptr; size_t extCap = 0;                           // contig + reverse complement extension strings
     int predicted = -1;                                                     // what every contig of the last round decided (-1: no prediction)
     // per-target stream merge, ENC.cpp:542-556: the views of a round's streams (page-locked memory of the emission slot)
     // are appended to the collection's strings by a thread of its own, while the next round is matched — the slot's
@@ -742,32 +771,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             allExt &= (bool) ext[c]; noneExt &= !ext[c]; anyRC |= (bool) rc[c];
         }
         if (!applied) {
-            // every target's extension string: its contigs (and reverse complements) that extend the reference, in order;
-            // a target loaded whole and without reverse complements is the span of its contigs in the round's buffer
-            size_t tmpNeed = 0;
-            std::vector<char> whole(T, 1);
-            for (size_t c = 0; c < ncont; c++) if (!ext[c] || rc[c]) whole[B.targetOf[c]] = 0;
-            for (size_t c = 0; c < ncont; c++)
-                if (!whole[B.targetOf[c]]) tmpNeed += (ext[c] ? 1 : 0) * (B.offsets[c + 1] - B.offsets[c]) + (rc[c] ? 1 : 0) * (B.offsets[c + 1] - B.offsets[c]);
-            if (tmpNeed > extCap) {
-                if (extTmp) matcher->devFree(extTmp);
-                extCap = tmpNeed + tmpNeed / 2 + 64;
-                extTmp = matcher->devAlloc(extCap);
-            }
-            size_t at = 0;
-            for (uint32_t t = 0; t < T; t++) {
-                extDev[t] = nullptr; extLen[t] = 0;
-                if (!tHas[t]) continue;
-                if (whole[t]) { if (tEnd[t] > tBeg[t]) { extDev[t] = B.seqDev + tBeg[t]; extLen[t] = tEnd[t] - tBeg[t]; } continue; }
-                const size_t start = at;
-                for (size_t c = 0; c < ncont; c++)
-                    if (B.targetOf[c] == t) {
-                        const size_t len = B.offsets[c + 1] - B.offsets[c];
-                        if (ext[c]) { matcher->devCopy(extTmp + at, B.seqDev + B.offsets[c], len); at += len; }
-                        if (rc[c]) { matcher->devRevComp(B.seqDev + B.offsets[c], len, extTmp + at); at += len; }    // :393-398
-                    }
-                if (at > start) { extDev[t] = extTmp + start; extLen[t] = at - start; }
-            }
+            extensionStrings(B, ext, rc, 0, T, extDev, extLen);
             const double tf0 = nowSeconds();
             matcher->finalizeTargets(extDev, extLen, params->refRegionSeparators, REF_REGION_SEPARATOR, lazyMode(), tlocks, loadedAfter);   // :440-457
             g_tFinalize += nowSeconds() - tf0;
@@ -793,7 +797,6 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
         for (uint32_t r = (uint32_t) params->benchWarmup; r < nRounds; r++) params->benchBases += slots[r].bytes;
     }
     for (auto &B : slots) if (B.seqDev) matcher->devFree(B.seqDev);
-    if (extTmp) matcher->devFree(extTmp);
 }
 
 

@@ -110,7 +110,9 @@ protected:
     // read (unless read ahead) + upload + device parse, synchronous; [afterF0, afterF1) = the files to read meanwhile
     void prepareRound(uint32_t f0, uint32_t f1, RoundBatch &B, uint32_t afterF0 = 0, uint32_t afterF1 = 0);
     uint8_t *rawDev = nullptr; size_t rawCap = 0;
-    uint8_t *retryExt = nullptr; size_t retryExtCap = 0;                                // extension strings of processRoundWithRetries
+    uint8_t *extScratch = nullptr; size_t extScratchCap = 0;                            // extension strings that are not a span of the round's buffer
+    void extensionStrings(const RoundBatch &B, const std::vector<char> &ext, const std::vector<char> &rc, uint32_t ta, uint32_t tb,
+                          std::vector<const uint8_t *> &extDev, std::vector<uint64_t> &extLen);
     std::vector<mbgc_fasta_record_t> records;
     void openInputStage();
     void readG0(const std::string &path, std::vector<Contig> &out, uint64_t *fileSize);
