@@ -29,6 +29,10 @@ constexpr int WN4 = SWSEM_WIN4;          // positions looked up per window (<= G
 constexpr int RING4 = 16;              // newest rows of a chain's stack mirrored in LDS
 constexpr int LEFT4 = 64;              // bytes left of the candidate covered by a visit's first load
 constexpr int LL4 = LEFT4 / 16;        // lanes holding them
+#ifndef SWSEM_VISIT_LANES
+#define SWSEM_VISIT_LANES 16
+#endif
+constexpr int NL4 = SWSEM_VISIT_LANES; // lanes whose 16 reference bytes a visit's first load fetches (the rest is fetched when the run gets there)
 #ifndef SWSEM_RESOLVE4_WAVES
 #define SWSEM_RESOLVE4_WAVES 6
 #endif
@@ -300,7 +304,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
             limR = (int32_t) (ra < (uint64_t) rbq ? (uint32_t) ra : rbq);
             dlo = c - lo;
             limL = (uint64_t) i < dlo ? i : (int32_t) dlo;
-            full = gl < (uint32_t) LL4 ? -rel <= limL : rel + 16 <= K + limR;
+            full = gl < (uint32_t) LL4 ? -rel <= limL : (gl < (uint32_t) NL4 && rel + 16 <= K + limR);
             const bool qwhole = i + rel >= 0 && (uint32_t) (i + rel) + 16u <= n;   // the query side of the chunk lies inside the contig
             if (full) xr = ld_u128(r0 + rel);
             if (qwhole) xq = ld_u128(q0 + rel);
@@ -321,9 +325,9 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
             const uint4 x = full ? xor128(xr, xq) : make_uint4(0, 0, 0, 0);
             const bool stop = !full || nz128(x);
             const uint32_t eqF = eq_low(x), eqL = eq_high(x);
-            const uint32_t stop16 = gballot(stop, gbase), full16 = gballot(full, gbase);
+            const uint32_t stop16 = gballot(stop, gbase) & ((1u << NL4) - 1u), full16 = gballot(full, gbase);
             const uint32_t fwd = stop16 >> LL4;
-            int32_t fwdlen = 16 * (GL - LL4);
+            int32_t fwdlen = 16 * (NL4 - LL4);
             bool capR = fwd == 0, capL = false;
             if (!capR) {
                 const uint32_t lf = (uint32_t) __builtin_ctz(fwd);
