@@ -229,3 +229,15 @@ def test_speculation_mostly_accepted(binding):
     st = h.batch_stats()
     nblocks = 2 * ((1_000_000 - 27 + 4095) // 4096 + 3) // 4
     assert st["replayed_blocks"] <= nblocks // 10, st
+
+
+def test_the_devices_numa_node_is_what_sysfs_says(binding):
+    """swsem_device_numa_node (the C++ host keeps its reader threads on that node): -1 or a node that exists"""
+    import ctypes
+    import os
+    L = binding.lib()
+    L.swsem_device_numa_node.argtypes = [ctypes.c_int]
+    L.swsem_device_numa_node.restype = ctypes.c_int
+    node = L.swsem_device_numa_node(0)
+    assert node == -1 or os.path.isdir("/sys/devices/system/node/node%d" % node)
+    assert L.swsem_device_numa_node(10_000) == -1
