@@ -109,7 +109,7 @@ struct Sink {
 
 struct Job { const uint8_t *src; size_t n; Coder coder; std::string packed; uint64_t compLen = 0; bool failed = false; };
 
-struct Ctx { mbgc_leaf_compress_fn leaf; void *ctx; };
+struct Ctx { mbgc_leaf_compress_fn leaf; void *ctx; int blocksScale = 1; };
 
 bool leafCompress(const Ctx &x, const mbgc_leaf_coder_t &c, const uint8_t *src, size_t n, std::string &out) {
     out.resize(n + n / 3 + 256);
@@ -162,7 +162,7 @@ bool collective(const Ctx &x, std::vector<Job> &jobs, Sink &out, int threads) {
 bool compress(const Ctx &x, Job &j, bool inBlocks) {
     if (j.coder.blocks && !inBlocks) {
         // parallelBlocksCompress, CodersLib.cpp:292-314 (+ ParallelBlocksCoderProps::prepare, CodersLib.h:163-171)
-        int nb = j.coder.blocks;
+        int nb = j.coder.blocks * (x.blocksScale > 1 ? x.blocksScale : 1);
         const int maxBlocks = (int) (j.n / (1u << 20));
         if (nb > maxBlocks) nb = maxBlocks;
         if (nb == 0) nb = 1;
@@ -217,7 +217,7 @@ int mbgc_backend_compress_streams(const mbgc_backend_params_t *p, const uint8_t 
         jobs.push_back(Job{data[st], (size_t) size[st], c});
     }
     Sink s;
-    const Ctx x{leaf, ctx};
+    const Ctx x{leaf, ctx, p->blocksScale};
     if (!collective(x, jobs, s, threads)) return fail("Error during compression.");       // (the reference exits, CodersLib.cpp:103-108)
     *out = (uint8_t *) malloc(s.s.size() ? s.s.size() : 1);
     if (!*out) return fail("out of memory");

@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     std::string transport = "rccl";
     size_t shmMb = 64;
     std::string backend;                                                        // a library with the reference's leaf coders (mbgc_leaf_compress)
-    int backendThreads = 8;
+    int backendThreads = 8, backendBlocksScale = 1;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "c") continue;
@@ -75,11 +75,12 @@ int main(int argc, char **argv) {
         else if (a == "--ref-factor" && i + 1 < argc) params.referenceFactor = atoi(argv[++i]);   // MGMP_Params.h:205 (tests: a buffer small enough to wrap)
         else if (a == "--backend" && i + 1 < argc) backend = argv[++i];
         else if (a == "--backend-threads" && i + 1 < argc) backendThreads = atoi(argv[++i]);
+        else if (a == "--backend-blocks" && i + 1 < argc) backendBlocksScale = atoi(argv[++i]);
         else pos.push_back(a);
     }
     if (pos.size() != 2) {
         fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--bench [--warmup rounds]] "
-                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T]] <sequencesListFile> <outputPrefix>\n");
+                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T] [--backend-blocks K]] <sequencesListFile> <outputPrefix>\n");
         return EXIT_FAILURE;
     }
     if (gpus < 1 || (transport != "rccl" && transport != "hostmem") || (gpus > 1 && params.sequentialMatching)) {
@@ -176,13 +177,13 @@ int main(int argc, char **argv) {
         if (!leaf) { fprintf(stderr, "cannot load the leaf coders from %s: %s\n", backend.c_str(), dlerror()); return finish(EXIT_FAILURE); }
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        const std::string section = enc.compressStreams(leaf, nullptr, backendThreads);
+        const std::string section = enc.compressStreams(leaf, nullptr, backendThreads, backendBlocksScale);
         clock_gettime(CLOCK_MONOTONIC, &t1);
         dump(pos[1], "collective", section);
         const size_t raw = enc.literals.size() + enc.rcMapOff.size() + enc.rcMapLen.size() + enc.locksPosStream.size() + enc.gapDeltas.size() +
                            enc.gapMismatchesFlags.size() + enc.mapOff.size() + enc.mapOff5thByte.size() + enc.mapLen.size() + enc.refExtSizeStream.size();
-        printf("backend: %zu stream bytes to %zu in %.0f ms (%d threads)\n", raw, section.size(),
-               (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, backendThreads);
+        printf("backend: %zu stream bytes to %zu in %.0f ms (%d threads, %d x the reference's blocks)\n", raw, section.size(),
+               (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, backendThreads, std::max(1, backendBlocksScale));
     }
     printf("exact matches total: %zu\n", enc.exactMatches());
     printf("removed matches breaking gaps total: %zu\n", enc.removedGapBreakingMatchesAll);

@@ -988,14 +988,14 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
         PgTools::SimpleSequenceMatcher::rcMatchSequence(literals, rcMapOff, rcMapLen, params->rcMatchMinLength, UINT32_MAX, device);
 }
 
-std::string MBGC_Encoder::compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads) {
+std::string MBGC_Encoder::compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale) {
     mbgc_backend_params_t bp = {};
     bp.coderMode = params->coderMode; bp.k = params->k;
     bp.enableExtensionsWithMismatches = params->emit.enableExtensionsWithMismatches;
     bp.mismatchesWithExclusion = params->emit.mismatchesWithExclusion;
     bp.sequentialMatching = params->sequentialMatching; bp.rcRedundancyRemoval = params->rcRedundancyRemoval;
     bp.frugal64bitLenEncoding = params->emit.frugal64bitLenEncoding; bp.lazyDecompressionSupport = params->lazyDecompressionSupport;
-    bp.refFinalTotalLength = refFinalTotalLength; bp.numberOfThreads = threads;
+    bp.refFinalTotalLength = refFinalTotalLength; bp.numberOfThreads = threads; bp.blocksScale = blocksScale;
     const std::string factors((const char *) unmatchedFractionFactors.data(), unmatchedFractionFactors.size());
     const std::string *src[MBGC_ST_COUNT] = {};
     src[MBGC_ST_UNMATCHED_FRACTION_FACTORS] = &factors; src[MBGC_ST_LITERALS] = &literals; src[MBGC_ST_RC_MAP_OFF] = &rcMapOff;

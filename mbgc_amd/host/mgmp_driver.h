@@ -186,7 +186,7 @@ public:
     // prepareAndCompressStreams' collective section (:641-710) for the streams this path produces — the file-name / header /
     // line-length streams belong to the part of the tool that is not rebuilt here and go in empty (eight zero bytes each) —
     // with the caller's leaf coders; what CompressionJob::writeCompressedCollectiveParallel would write for them
-    std::string compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads);
+    std::string compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale = 1);
     size_t exactMatches() const { return resCount; }
     size_t unmatchedChars() const { return unmatchedCharsAll; }
 };

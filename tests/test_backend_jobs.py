@@ -25,7 +25,7 @@ class Params(C.Structure):
     _fields_ = [("coderMode", C.c_int), ("ultraStreamsCompression", C.c_int), ("k", C.c_int), ("enableExtensionsWithMismatches", C.c_int),
                 ("mismatchesWithExclusion", C.c_int), ("sequentialMatching", C.c_int), ("rcRedundancyRemoval", C.c_int),
                 ("frugal64bitLenEncoding", C.c_int), ("lazyDecompressionSupport", C.c_int), ("refFinalTotalLength", C.c_uint64),
-                ("numberOfThreads", C.c_int)]
+                ("numberOfThreads", C.c_int), ("blocksScale", C.c_int)]
 
 
 LEAF_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Leaf), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
@@ -85,7 +85,7 @@ def synthetic_streams(seed, scale):
     return s
 
 
-def both(L, mode, flags, streams, threads=1, ref_total=1 << 31):
+def both(L, mode, flags, streams, threads=1, ref_total=1 << 31, blocks_scale=0):
     R = _refh.lib()
     data = (C.c_char_p * NST)(*[bytes(x) for x in streams])
     size = (C.c_uint64 * NST)(*[len(x) for x in streams])
@@ -98,7 +98,7 @@ def both(L, mode, flags, streams, threads=1, ref_total=1 << 31):
     p = Params(coderMode=mode, ultraStreamsCompression=flags & 1, k=32, enableExtensionsWithMismatches=1,
                mismatchesWithExclusion=0 if mode == 0 else 1, sequentialMatching=1 if flags & 4 or mode == 3 else 0,
                rcRedundancyRemoval=1 if mode == 3 else 0, frugal64bitLenEncoding=0 if mode == 0 else 1,
-               lazyDecompressionSupport=1 if flags & 2 else 0, refFinalTotalLength=ref_total, numberOfThreads=threads)
+               lazyDecompressionSupport=1 if flags & 2 else 0, refFinalTotalLength=ref_total, numberOfThreads=threads, blocksScale=blocks_scale)
     # prepareHeadersStreams appends the file separator to the (one) file's templates
     mine_streams = list(streams)
     mine_streams[2] = streams[2] + b"\xbb"
@@ -142,6 +142,28 @@ def test_fifth_byte_stream_is_enrolled_beyond_4g_and_empty_streams_are_zero_leng
     assert mine == ref
     ref2, mine2, _ = both(L, 1, 2, s, ref_total=1 << 31)
     assert mine2 == ref2 and len(ref2) < len(ref)
+
+
+def test_more_blocks_than_the_references_are_read_back_by_the_references_reader():
+    """blocksScale = 3: every split stream in three times the reference's blocks — other bytes than the reference writes, the
+    same streams out of its readCompressedCollectiveParallel"""
+    L = host()
+    streams = synthetic_streams(11, 1.0)
+    ref, mine, _ = both(L, 1, 2, streams, blocks_scale=3)
+    assert mine != ref and abs(len(mine) - len(ref)) < 0.02 * len(ref)
+    R = _refh.lib()
+    R.refbk_read_collective.restype = C.c_uint64
+    enrolled = [st for st in range(NST) if st not in (7, 8, 13)]           # -m1 below 2^32: no rc streams, no 5th byte
+    sizes = (C.c_uint64 * len(enrolled))()
+    cap = sum(len(x) for x in streams) + 64
+    buf = C.create_string_buffer(cap)
+    total = R.refbk_read_collective(mine, C.c_uint64(len(mine)), len(enrolled), sizes, buf, C.c_uint64(cap))
+    assert total <= cap
+    at = 0
+    for st, n in zip(enrolled, sizes):
+        want = streams[st] + (b"\xbb" if st == 2 else b"")
+        assert buf.raw[at: at + n] == want, st
+        at += n
 
 
 def test_job_table_query():
