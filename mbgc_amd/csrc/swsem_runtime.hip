@@ -147,6 +147,10 @@ struct swsem {
         hipEvent_t evDone = nullptr;
         bool outstanding = false, refGuarded = false;
         bool donePending = false;            // evDone has not been recorded for this emission yet (its byte automata are queued behind the speculative finalize)
+        // the byte automata of the second phase wait to be queued: at the next batch's resolve launch, gated on that kernel's
+        // start (run_phase2b), or by whoever needs this emission's results first
+        bool deferred2b = false, waitFin2b = false;
+        EmitView v2b; uint32_t grid2b = 0; int n2b = 0;
         const uint8_t *qdev = nullptr;       // query buffer the emission reads
         swsem_emit_params_t params;          // its parameters
         uint64_t emitPos1 = 0;               // loading position the emission started at
@@ -197,10 +201,13 @@ struct swsem {
     hipEvent_t evP1 = nullptr;
     hipEvent_t evFin = nullptr;            // behind the speculative finalize (see emit_begin_impl)
     bool phase2Behind = true;              // SWSEM_PHASE2_BEHIND=0: the second phase's byte automata do not wait for the finalize
+    // SWSEM_GATE2=0: the byte automata are queued with the emission, not behind the next batch's resolve launch (run_phase2b)
+    bool gate2 = true;
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 8;                       // length of a resolve block in units of RBU positions: chosen per batch (run_batch) unless SWSEM_RB fixes it
     uint32_t rbFixed = 0;
+    uint32_t slotPercent = 95;             // share of the wave slots a launch's blocks are sized for (SWSEM_SLOT_PERCENT)
     uint32_t waveSlots = 256 * 4 * RESOLVE_WAVES_PER_SIMD;   // resolve waves the device holds at once (CUs x SIMDs x waves)
     std::vector<Contig> contigs;
     std::vector<uint32_t> matchCount;
@@ -329,6 +336,42 @@ int insert_samples(swsem *h, const uint8_t *src = nullptr, uint64_t lo = 0, uint
     return SWSEM_OK;
 }
 
+int flush_copies(swsem *h);
+int download(swsem *h, void *dstPinned, const void *srcDev, size_t bytes, hipStream_t st);
+
+// The byte automata of an emission's second phase (sizes .. write), the copy of its results and its completion event, on
+// the second stream. Queued with the emission they become ready when the finalize ends — the moment the next batch's resolve
+// does — and whichever was dealt the wave slots first ran at the other's expense: the resolve took 2.8 ms instead of 2.1
+// when it lost (steps of 3.1 and 3.9 ms, the slow kind in 40 % of the steps on the 4.35e9-byte sizing). So they are kept
+// back until the next resolve kernel has been launched (run_batch; `gated`: the caller has made the second stream wait for
+// the event recorded just before that launch), or until somebody needs the emission's results.
+int run_phase2b(swsem *h, swsem::EmitSlot &E, bool gated) {
+    if (!E.deferred2b) return SWSEM_OK;
+    E.deferred2b = false;
+    if (E.waitFin2b && !gated) {                                     // behind the finalize's last kernel (everything queued so far)
+        if (!h->evFin) HIPCHK(hipEventCreateWithFlags(&h->evFin, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->evFin, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->evFin, 0));
+    }
+    const EmitView &v = E.v2b;
+    const dim3 grid2(E.grid2b);
+    const int n = E.n2b;
+    h->mark(SWSEM_K_EMIT2, true, h->stream2);
+    k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
+    k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
+    h->mark(SWSEM_K_EMIT2, false, h->stream2);
+    HIPCHK(hipGetLastError());
+    int r2;
+    if ((r2 = flush_copies(h)) || (r2 = download(h, E.pinE, E.dEOut.p, (size_t) n * sizeof(EmitOut), h->stream2)) || (r2 = flush_copies(h))) return r2;
+    HIPCHK(hipEventRecord(E.evDone, h->stream2));
+    E.donePending = false;
+    return SWSEM_OK;
+}
+
 // An emission whose second phase is still running reads reference bytes next to its matches. It never reads inside
 // its own lock window [loading position it started at, its matching-lock position): candidates there were refused
 // at match time (.cpp:212-220), pairs do not span the lock (TextMatchers.h:46-50), the right extension stops at the
@@ -349,6 +392,7 @@ int ref_write_guard(swsem *h, uint64_t firstByte, uint64_t lastByte) {
         }
         const bool appendOnly = h->laps == 0 && firstByte >= E.emitPos1;   // nothing was ever written there: nothing to read
         if (!inside && !appendOnly) {
+            if (E.deferred2b) { int d = run_phase2b(h, E, false); if (d) return d; }   // (its automata had not been queued yet)
             if (E.donePending) return SWSEM_ESPEC;                   // (only while a speculative finalize is being queued: it is given up)
             HIPCHK(hipStreamWaitEvent(h->stream, E.evDone, 0));
             E.refGuarded = true;
@@ -672,7 +716,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         }
         h->chainsPerWave = (h->simt && !h->seqResolve && h->K <= K_MAX4) ? (uint32_t) GC : 1u;
         const uint64_t waves = h->chainsPerWave > 1 ? (uint64_t) h->waveSlots / RESOLVE_WAVES_PER_SIMD * RESOLVE4_WAVES_PER_SIMD : h->waveSlots;
-        const uint64_t slots = std::max<uint64_t>(1, waves * h->chainsPerWave * 19 / 20);
+        const uint64_t slots = std::max<uint64_t>(1, waves * h->chainsPerWave * h->slotPercent / 100);
         h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(64, std::max<uint64_t>(2, (allUnits + slots - 1) / slots));   // (a small batch — one target of the sequential schedule — runs short chains: it is their length that takes the time)
     }
     for (int c = 0; c < n; c++) {
@@ -712,6 +756,8 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     if ((r = zero_dev(h, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) || (r = flush_copies(h))) return r;
     const RefView v = h->view();
     const bool wrapped = v.fpCheck == 2;                // kernels instantiated with / without the lap epochs (ht_value)
+    if (h->seqResolve || rblocks == 0)
+        for (auto &E : h->slot) if ((r = run_phase2b(h, E, false))) return r;
     if (h->seqResolve || rblocks == 0) {
         h->mark(SWSEM_K_RESOLVE, true);
         if (wrapped) k_resolve_seq<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dMatches.p, h->dMatchCount.p);
@@ -728,6 +774,15 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         if ((r = h->dKeepN.reserve(rblocks))) return r;
         if ((r = h->dDstOff.reserve(rblocks))) return r;
         if ((r = h->dPrev.reserve(rblocks))) return r;
+        // An emission whose byte automata wait to be queued (run_phase2b): they are handed to the second stream AFTER the
+        // resolve kernel has been handed to the first, behind an event recorded just before it — whatever hardware queues
+        // the two streams share, the resolve is dealt its wave slots first.
+        bool anyDeferred = false;
+        for (auto &E : h->slot) anyDeferred |= E.deferred2b;
+        if (anyDeferred) {
+            if (!h->evFin) HIPCHK(hipEventCreateWithFlags(&h->evFin, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(h->evFin, h->stream));
+        }
         h->mark(SWSEM_K_RESOLVE, true);
         if (h->chainsPerWave == (uint32_t) GC) {
             if (wrapped) k_resolve_blocks4<true><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
@@ -737,6 +792,10 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
             else k_resolve_blocks<false><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
         }
         h->mark(SWSEM_K_RESOLVE, false);
+        if (anyDeferred) {
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->evFin, 0));
+            for (auto &E : h->slot) if ((r = run_phase2b(h, E, true))) return r;
+        }
         h->mark(SWSEM_K_STITCH, true);
         k_stitch_pre<<<dim3((rblocks + 255) / 256), dim3(256), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRecs.p, h->rb, rblocks, h->dFast.p);
         if (wrapped) k_stitch<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p, h->dFast.p, h->dSegStart.p,
@@ -806,6 +865,7 @@ int end_slot(swsem *h, int si) {
     swsem::EmitSlot &E = h->slot[si];
     if (!E.outstanding) return SWSEM_OK;
     HIPCHK(hipSetDevice(h->device));
+    { int d = run_phase2b(h, E, false); if (d) return d; }            // (nobody launched a resolve since: nothing to wait for)
     HIPCHK(hipEventSynchronize(E.evDone));
     E.outstanding = false;
     const int n = E.emitN;
@@ -843,7 +903,12 @@ int swsem_device_count(void) {
 
 int swsem_device_numa_node(int device) {
     char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int) sizeof bus, device) != hipSuccess) return -1;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count ||
+        hipDeviceGetPCIBusId(bus, (int) sizeof bus, device) != hipSuccess) {
+        (void) hipGetLastError();                                      // (a failed query must not be the next launch's "last error")
+        return -1;
+    }
     for (char *c = bus; *c; c++) *c = (char) tolower((unsigned char) *c);
     char path[160];
     snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
@@ -881,7 +946,8 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
         int least = 0, greatest = 0;                        // numerically: least >= greatest
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) { h->prioLow = least; h->prioHigh = greatest; }
     }
-    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+    const bool lowPrio2 = getenv("SWSEM_STREAM2_PRIO") && !strcmp(getenv("SWSEM_STREAM2_PRIO"), "low");
+    if ((lowPrio2 ? hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, h->prioLow) : hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->slot[0].evDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->slot[1].evDone, hipEventDisableTiming) != hipSuccess ||
@@ -894,6 +960,8 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_PHASE2_BEHIND")) h->phase2Behind = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
+    if (const char *e = getenv("SWSEM_GATE2")) h->gate2 = atoi(e) != 0;
+    if (const char *e = getenv("SWSEM_SLOT_PERCENT")) { int x = atoi(e); if (x >= 10 && x <= 100) h->slotPercent = (uint32_t) x; }
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
@@ -924,6 +992,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
 void swsem_destroy(swsem_t *h) {
     if (!h) return;
     (void) hipSetDevice(h->device);
+    for (auto &E : h->slot) E.deferred2b = false;                    // (automata that were never queued: nobody wants their bytes any more)
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     if (h->stream2) (void) hipStreamSynchronize(h->stream2);
     if (h->stream3) (void) hipStreamSynchronize(h->stream3);
@@ -1390,31 +1459,12 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
-    // The byte automata (sizes .. write) are queued further down, behind the speculative finalize: with the pairing
-    // kernels and the finalize ending at about the same time (0.85 ms after pass 1 on the 4.35e9-byte sizing) it was a
-    // photo finish between k_emit_sizes and the next batch's resolve, and whichever started first was dealt the wave
-    // slots first — the resolve took 2.8 ms instead of 2.1 when it lost (steps of 3.1 and 3.9 ms alternating by the
-    // run). The automata now also wait for the finalize's last kernel: the resolve, next in that queue, starts first.
+    // The byte automata (sizes .. write) are queued later (run_phase2b): behind the speculative finalize, and — when the
+    // device can make a stream wait for a word in memory — not before the next batch's resolve kernel has started.
+    E.v2b = v; E.grid2b = chunks; E.n2b = n;
     auto phase2b = [&](bool behindFinalize) -> int {
-        if (behindFinalize) {
-            if (!h->evFin) HIPCHK(hipEventCreateWithFlags(&h->evFin, hipEventDisableTiming));
-            HIPCHK(hipEventRecord(h->evFin, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->stream2, h->evFin, 0));
-        }
-        h->mark(SWSEM_K_EMIT2, true, h->stream2);
-        k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
-        k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
-        k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
-        k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
-        k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
-        k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
-        h->mark(SWSEM_K_EMIT2, false, h->stream2);
-        HIPCHK(hipGetLastError());
-        int r2;
-        if ((r2 = download(h, E.pinE, E.dEOut.p, n * sizeof(EmitOut), h->stream2)) || (r2 = flush_copies(h))) return r2;
-        HIPCHK(hipEventRecord(E.evDone, h->stream2));
-        E.donePending = false;
-        return SWSEM_OK;
+        E.deferred2b = true; E.waitFin2b = behindFinalize;
+        return h->gate2 ? SWSEM_OK : run_phase2b(h, E, false);
     };
     E.donePending = true;
     const bool specAsked = spec && spec->ntargets > 0 && h->phase2Behind;
