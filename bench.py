@@ -467,6 +467,18 @@ def main():
             "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
             **({"step_ms": [round(t, 3) for t in step_ms]} if os.environ.get("MBGC_BENCH_STEP_MS") else {}),
         }
+        if os.environ.get("MBGC_BENCH_BLOCK_TIMES"):                  # diagnostics: how even the last launch's resolve blocks were
+            import ctypes
+            L = binding.lib()
+            L.swsem_debug_block_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+            cap = 1 << 18
+            buf = np.zeros((cap, 3), dtype=np.uint64)
+            nb = ctypes.c_uint64()
+            if L.swsem_debug_block_times(m.h, buf.ctypes.data, cap, ctypes.byref(nb)) == 0:
+                t = np.sort(buf[: min(int(nb.value), cap), 0].astype(np.float64))
+                if len(t):
+                    out["resolve_block_ticks"] = {"blocks": int(nb.value), "mean": float(t.mean()), "median": float(t[len(t) // 2]),
+                                                  "p90": float(t[int(len(t) * 0.9)]), "p99": float(t[int(len(t) * 0.99)]), "max": float(t[-1])}
         if world > 1 or forced:
             out["rccl_ranks_seen"] = dist.get_world_size()
             out["extension_allgathers_started_ahead"] = {"started": runner.pregathers[0], "used": runner.pregathers[1]}
