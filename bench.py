@@ -475,6 +475,8 @@ def main():
             buf = np.zeros((cap, 3), dtype=np.uint64)
             nb = ctypes.c_uint64()
             if L.swsem_debug_block_times(m.h, buf.ctypes.data, cap, ctypes.byref(nb)) == 0:
+                if os.environ.get("MBGC_BENCH_BLOCK_TIMES") not in ("1", ""):
+                    np.save(os.environ["MBGC_BENCH_BLOCK_TIMES"], buf[: min(int(nb.value), cap)])
                 t = np.sort(buf[: min(int(nb.value), cap), 0].astype(np.float64))
                 if len(t):
                     out["resolve_block_ticks"] = {"blocks": int(nb.value), "mean": float(t.mean()), "median": float(t[len(t) // 2]),
