@@ -200,14 +200,14 @@ struct swsem {
     hipStream_t stream2 = nullptr;
     hipEvent_t evP1 = nullptr;
     hipEvent_t evFin = nullptr;            // behind the speculative finalize (see emit_begin_impl)
-    bool phase2Behind = true;              // SWSEM_PHASE2_BEHIND=0: the second phase's byte automata do not wait for the finalize
+    bool phase2Behind = true;              // the second phase's byte automata are handed over behind the speculative finalize
     // SWSEM_GATE2=0: the byte automata are queued with the emission, not behind the next batch's resolve launch (run_phase2b)
     bool gate2 = true;
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 8;                       // length of a resolve block in units of RBU positions: chosen per batch (run_batch) unless SWSEM_RB fixes it
     uint32_t rbFixed = 0;
-    uint32_t slotPercent = 95;             // share of the wave slots a launch's blocks are sized for (SWSEM_SLOT_PERCENT)
+    uint32_t slotPercent = 95;             // share of the wave slots a launch's blocks are sized for (80 %: +5 % on the 4.35e9-byte sizing, -3 % on configs[2]'s)
     uint32_t waveSlots = 256 * 4 * RESOLVE_WAVES_PER_SIMD;   // resolve waves the device holds at once (CUs x SIMDs x waves)
     std::vector<Contig> contigs;
     std::vector<uint32_t> matchCount;
@@ -946,8 +946,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
         int least = 0, greatest = 0;                        // numerically: least >= greatest
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) { h->prioLow = least; h->prioHigh = greatest; }
     }
-    const bool lowPrio2 = getenv("SWSEM_STREAM2_PRIO") && !strcmp(getenv("SWSEM_STREAM2_PRIO"), "low");
-    if ((lowPrio2 ? hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, h->prioLow) : hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->slot[0].evDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->slot[1].evDone, hipEventDisableTiming) != hipSuccess ||
@@ -957,11 +956,9 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_ORDER")) h->orderMode = strcmp(e, "contig") == 0 ? 0 : 1;
-    if (const char *e = getenv("SWSEM_PHASE2_BEHIND")) h->phase2Behind = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_GATE2")) h->gate2 = atoi(e) != 0;
-    if (const char *e = getenv("SWSEM_SLOT_PERCENT")) { int x = atoi(e); if (x >= 10 && x <= 100) h->slotPercent = (uint32_t) x; }
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
