@@ -247,3 +247,29 @@ def test_a_missing_file_in_a_later_round_is_reported(tmp_path):
     (tmp_path / "l.txt").write_text("\n".join(paths) + "\n")
     r = subprocess.run([TOOL, "c", "-R", "2", "l.txt", "o"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "cannot open file" in r.stderr and "nowhere.fa" in r.stderr, r.stderr
+
+
+@pytest.mark.parametrize("rs", [1, 4, 7])
+def test_a_wrapping_buffer_equals_the_oracle_loop(tmp_path, rs):
+    """--ref-factor 1: a 4 MiB circular buffer for 1 Mbp genomes — it wraps every fourth target, loads are clipped at the
+    oldest lock, an emission's text is overwritten while its second phase may still be waiting to be queued (the guard hands
+    it over first) — 25 targets in rounds of 1, 4 and 7 through the pipelined host against the oracle-driven loop"""
+    base = synth.base_codes(1_000_000, 67)
+    gs = [synth.genome(base, i, 0.003) for i in range(26)]
+    paths = []
+    for i, g in enumerate(gs):
+        p = tmp_path / ("g%02d.fa" % i)
+        p.write_bytes(synth.fasta_bytes(g, i))
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    run_tool(["c", "--ref-factor", "1", "-R", str(rs), "list.txt", "out"], str(tmp_path))
+    lim = 2 * max(gs[0].size, 1 << 21)                       # initMatcher with referenceFactor = 1 (MGMP.cpp:154-158)
+    o = _orc.OracleMatcher(lim)
+    res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], rs)
+    got = {k: (tmp_path / ("out." + k)).read_bytes() for k in ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags", "locksPos", "refExtSize")}
+    assert got["literals"] == gs[0].tobytes() + b"\xa2" + res["streams"]["literals"]
+    for k in ("mapOff", "mapOff5th", "mapLen", "gapDelta", "flags"):
+        assert got[k] == res["streams"][k], k
+    assert got["locksPos"] == res["locks"] and got["refExtSize"] == res["refExtSize"]
+    assert o.loaded_ref_length() > lim                       # (it did wrap: rounds of 7 load the least, clipped at the oldest lock)
+    o.close()
