@@ -465,6 +465,7 @@ def main():
             "ms_per_step_after_wrap": round(float(np.mean(post)), 4) if post else None, "steps_after_wrap": len(post),
             "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps,
             "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
+            "round_finalizes_queued_behind_pass1": {"tried": runner.spec_local[0], "applied": runner.spec_local[1], "not_applied_at_try": runner.spec_local[2][:16]},
             **({"step_ms": [round(t, 3) for t in step_ms]} if os.environ.get("MBGC_BENCH_STEP_MS") else {}),
         }
         if os.environ.get("MBGC_BENCH_BLOCK_TIMES"):                  # diagnostics: how even the last launch's resolve blocks were

@@ -116,6 +116,7 @@ class RoundRunner:
         self._ev_tops = [None, None]                 # main-stream events: where the last round / this round began
         self._gate = self._gate_host = self._gate_ev = None     # the speculative finalize's word, several ranks (see _world_speculation)
         self.spec_rounds = [0, 0]                    # several ranks: speculative finalizes tried / applied (diagnostics)
+        self.spec_local = [0, 0, []]                 # one rank: the same, and the rounds in which it was not applied
         if self.p is not None:
             matcher.emit_set_host_copy(False)
 
@@ -391,6 +392,11 @@ class RoundRunner:
                             self.p, [lock_of[c] for c in pending], [self.policy.factor] * ncont, [self.targets_done] * ncont, tgt,
                             self.loaded, ncont, spec[0], spec[1], locks, [self._pred_ext] * ncont, [False] * ncont,
                             self.policy.factor, self.policy.rc_factor, self.lazy)
+                        self.spec_local[0] += 1
+                        if spec_applied:
+                            self.spec_local[1] += 1
+                        else:
+                            self.spec_local[2].append(self.spec_local[0])
                     else:
                         m.emit_batch_begin(self.p, None, [lock_of[c] for c in pending], [self.policy.factor] * len(pending),
                                            [self.targets_done + finalized] * len(pending), tgt, self.loaded, n=len(pending))
