@@ -416,7 +416,8 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
         if ((uint64_t) h->pos1 + tmpLength > tmpMax) tmpLength = tmpMax - (uint64_t) h->pos1;
         {
             // bytes this step writes: the copy, and the separator at the window's end when the copy reaches it
-            const uint64_t first = (uint64_t) h->pos1 < h->swEnd ? (uint64_t) h->pos1 : h->swEnd - 1;
+            // (a window that wraps has its end BELOW the loading position: only a loader that stands AT the end writes the byte before it)
+            const uint64_t first = (uint64_t) h->pos1 == h->swEnd ? h->swEnd - 1 : (uint64_t) h->pos1;
             const uint64_t last = tmpLength ? (uint64_t) h->pos1 + tmpLength - 1 : first;
             int g = ref_write_guard(h, first, last);
             if (g) return g;
@@ -462,15 +463,9 @@ namespace {
 int flush_inserts(swsem *h, const uint32_t *gate) {
     const size_t np = h->pendingPieces.size(), nc = h->pendingCopies.size(), nb = h->pendingBytes.size();
     if (!np && !nc && !nb) return SWSEM_OK;
-    {
-        uint64_t lowest = UINT64_MAX, highest = 0;
-        for (auto &c : h->pendingCopies) { lowest = std::min(lowest, c.dst); highest = std::max(highest, c.dst + c.len - 1); }
-        for (auto &b : h->pendingBytes) { lowest = std::min(lowest, b.off); highest = std::max(highest, b.off); }
-        if (lowest != UINT64_MAX) {
-            int g = ref_write_guard(h, lowest, highest);
-            if (g) return g;
-        }
-    }
+    // (every copy and byte collected here went through ref_write_guard when it was collected — load_pieces,
+    // swsem_load_separator — with the lap count of that moment; one test of the whole span would take the two halves of a
+    // round that wraps for a write across the whole buffer and give the speculative finalize up once per lap)
     constexpr uint64_t CHUNK = 256 * 16;                 // bytes per copy block
     // Insertion beside the copies: a sample whose K bytes all come out of its own piece's copy is hashed from the copy's
     // source (k_insert_multi<true>), while the copies run on a stream of their own; what is left — windows that reach into
