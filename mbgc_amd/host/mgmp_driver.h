@@ -42,8 +42,8 @@ struct MGMP_Params {                                   // matching/MGMP_Params.h
     mbgc_xchg_t *exchange = nullptr;
     int specRounds = 0;                                // rounds whose finalize ran on the ranks' device-side verdicts (diagnostics)
     int headRounds = 0;                                // rounds whose extension exchange was cut to the loadable head (diagnostics)
-    static const uint64_t MIN_BASIC_BLOCK_SIZE = 1 << 21;                 // :48
-    static const uint64_t REFERENCE_LENGTH_LIMIT = (uint64_t) UINT32_MAX << 8;   // :55
+    static constexpr uint64_t MIN_BASIC_BLOCK_SIZE = 1 << 21;             // :48
+    static constexpr uint64_t REFERENCE_LENGTH_LIMIT = (uint64_t) UINT32_MAX << 8;   // :55
     bool isContigProperForRefExtension(uint64_t len, uint64_t unmatched, int f) const { return unmatched * f > len; }      // :179-186
     bool isContigProperForRefRCExtension(uint64_t len, uint64_t unmatched, int f) const { return unmatched * f > len; }    // :188-190
 };
