@@ -273,3 +273,27 @@ def test_a_wrapping_buffer_equals_the_oracle_loop(tmp_path, rs):
     assert got["locksPos"] == res["locks"] and got["refExtSize"] == res["refExtSize"]
     assert o.loaded_ref_length() > lim                       # (it did wrap: rounds of 7 load the least, clipped at the oldest lock)
     o.close()
+
+
+def test_repeated_runs_write_the_same_bytes(tmp_path):
+    """the host's threads (file readers, the upload + parse thread, the thread that appends the streams) and the two
+    emissions in flight leave no room for timing: four runs over a buffer that wraps, with different numbers of reader
+    threads, one digest"""
+    import hashlib
+    base = synth.base_codes(1_000_000, 71)
+    paths = []
+    for i in range(31):
+        p = tmp_path / ("g%02d.fa" % i)
+        p.write_bytes(synth.fasta_bytes(synth.genome(base, i, 0.004), i))
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    digests = set()
+    for readers in ("1", "8", "3", "8"):
+        r = subprocess.run([TOOL, "c", "--ref-factor", "2", "-R", "5", "list.txt", "o"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, MBGC_HIP_READERS=readers))
+        assert r.returncode == 0, r.stderr[-1000:]
+        h = hashlib.md5()
+        for k in ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags", "locksPos", "refExtSize"):
+            h.update((tmp_path / ("o." + k)).read_bytes())
+        digests.add(h.hexdigest())
+    assert len(digests) == 1
