@@ -171,8 +171,9 @@ def test_bench_mode_reports_throughput(tmp_path):
     assert d["rounds"] == 2 and d["bases"] == 8 * 400_000 and d["value"] > 0
 
 
-def test_backend_section_is_read_back_by_the_reference(tmp_path):
-    """`--backend`: the tool's streams through the job table + container framing of include/mbgc_backend.h with the
+@pytest.mark.parametrize("blocks", [1, 2])
+def test_backend_section_is_read_back_by_the_reference(tmp_path, blocks):
+    """`--backend` (and `--backend-blocks 2`: twice the reference's block counts): the tool's streams through the job table + container framing of include/mbgc_backend.h with the
     reference's own PPMd7 / LZMA (oracle/_ref) as the leaf coders; the reference's reader
     (readCompressedCollectiveParallel, coders/CodersLib.cpp:417-478) must give back the dumps, and the section must weigh
     what the reference's archive of the same three genomes weighs (1 016 021 bytes) minus its name /
@@ -188,10 +189,10 @@ def test_backend_section_is_read_back_by_the_reference(tmp_path):
         names.append(str(tmp_path / f))
     (tmp_path / "seqlist.txt").write_text("\n".join(names) + "\n")
     out = run_tool(["c", "-t1", "--backend", os.path.join(ROOT, "oracle", "_ref", "libswsem_ref.so"), "--backend-threads", "1",
-                    "seqlist.txt", "lm"], str(tmp_path))
-    assert "backend:" in out
+                    "--backend-blocks", str(blocks), "seqlist.txt", "lm"], str(tmp_path))
+    assert "backend:" in out and ("%d x the reference's blocks" % blocks) in out
     section = (tmp_path / "lm.collective").read_bytes()
-    assert 900_000 < len(section) < 1_016_021
+    assert 900_000 < len(section) < (1_016_021 if blocks == 1 else 1_030_000)        # (models restarted twice as often: a few hundred bytes more)
     R = _refh.lib()
     order = [None, None, None, None, None, "factors", "literals", "locksPos", "gapDelta", "flags", "mapOff", "mapLen", "refExtSize"]
     sizes = (C.c_uint64 * len(order))()
