@@ -200,6 +200,8 @@ struct swsem {
     hipStream_t stream2 = nullptr;
     hipEvent_t evP1 = nullptr;
     hipEvent_t evFin = nullptr;            // behind the speculative finalize (see emit_begin_impl)
+    hipEvent_t evMeta = nullptr;           // behind the last emission's k_emit_meta_blocks
+    bool metaPending = false, metaWait = true;   // SWSEM_META_WAIT=0: the resolve does not wait for it
     bool phase2Behind = true;              // the second phase's byte automata are handed over behind the speculative finalize
     // SWSEM_GATE2=0: the byte automata are queued with the emission, not behind the next batch's resolve launch (run_phase2b)
     bool gate2 = true;
@@ -772,6 +774,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         // An emission whose byte automata wait to be queued (run_phase2b): they are handed to the second stream AFTER the
         // resolve kernel has been handed to the first, behind an event recorded just before it — whatever hardware queues
         // the two streams share, the resolve is dealt its wave slots first.
+        if (h->metaPending && h->metaWait) { HIPCHK(hipStreamWaitEvent(h->stream, h->evMeta, 0)); h->metaPending = false; }
         bool anyDeferred = false;
         for (auto &E : h->slot) anyDeferred |= E.deferred2b;
         if (anyDeferred) {
@@ -954,6 +957,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_GATE2")) h->gate2 = atoi(e) != 0;
+    if (const char *e = getenv("SWSEM_META_WAIT")) h->metaWait = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
@@ -1013,6 +1017,7 @@ void swsem_destroy(swsem_t *h) {
     if (h->evMatched) (void) hipEventDestroy(h->evMatched);
     if (h->evP1) (void) hipEventDestroy(h->evP1);
     if (h->evFin) (void) hipEventDestroy(h->evFin);
+    if (h->evMeta) (void) hipEventDestroy(h->evMeta);
     if (h->ownStream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1448,6 +1453,11 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
     h->mark(SWSEM_K_EMIT2, true, h->stream2);
     k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p);
+    // (the next batch's resolve is launched behind this kernel, run_batch: a launch of thousands of waves that is still
+    // running takes the slots the resolve's blocks are sized for, and the blocks that have to wait double its time)
+    if (!h->evMeta) HIPCHK(hipEventCreateWithFlags(&h->evMeta, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->evMeta, h->stream2));
+    h->metaPending = true;
     k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
