@@ -88,6 +88,19 @@ __global__ void k_set_bytes(uint8_t *__restrict__ ref, const BytePiece *__restri
 }
 
 
+// A table entry stores its sample's position in units of k1 (htEncodePos, .h:132), so a lookup is sent to the slot's FIRST
+// byte whatever byte the sample started at. After a wrap the loader samples at 1 + 16 n until the next call's tail is back
+// on the grid (.cpp:407-411 vs :503): such an entry sits in the bucket of the K-mer at 16 n + 1 and sends its
+// lookups to 16 n, where the reference compares bytes (memcmp, .cpp:298) — and finds them equal in a run of one letter (an
+// N run, a homopolymer), a match it then reports. The fingerprint stands for what that comparison will see, so for a sample
+// off the grid it is taken from the K-mer at the slot's first byte, not from the sample's own: a lookup whose fingerprint
+// differs from it differs from the bytes at 16 n and may be dropped; one that equals them goes on to the comparison.
+__device__ __forceinline__ uint32_t fp_at(const uint8_t *s, int nw) {
+    uint32_t f = FP_SEED;
+    for (int j = 0; j < nw; j++) f = fp_step(f, ld_u32(s + 4 * j));
+    return f;
+}
+
 // processIgnoreCollisionsRef, .cpp:146-171. Thread t < nMain inserts the main-loop sample at
 // S + t*k1 with epoch `epoch`; thread nMain + u inserts the tail sample T + u*k1 with epoch + 1
 // (the tail runs after the main loop on the CPU, so it wins collisions against it).
@@ -104,6 +117,8 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
     uint32_t h = (uint32_t) K, f = FP_SEED;
     const int nw = K / 4;
     for (int j = 0; j < nw; j++) { const uint32_t w = ld_u32(s + 4 * j); h = hash_step(h, w, (uint32_t) j); f = fp_step(f, w); }
+    const uint32_t off = (uint32_t) (p & ((1ull << k1ord) - 1));
+    if (off && p >= off) f = fp_at(s - off, nw);                   // a sample off the grid (see fp_at)
     const ht_entry key = ht_key(epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), f, fpBits);
     atomicMax(&ht[h & mask], key);
 }
@@ -145,6 +160,8 @@ __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict_
     uint32_t h = (uint32_t) K, f = FP_SEED;
     const int nw = K / 4;
     for (int j = 0; j < nw; j++) { const uint32_t w = ld_u32(s + 4 * j); h = hash_step(h, w, (uint32_t) j); f = fp_step(f, w); }
+    const uint32_t off = (uint32_t) (p & ((1ull << k1ord) - 1));
+    if (off && p >= off && (!FROM_SRC || p - off >= pc.lo)) f = fp_at(s - off, nw);   // a sample off the grid (see fp_at)
     const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), f, fpBits);
 #ifndef SWSEM_INSERT_NOREAD
     if (ht[h & mask] >= key) return;                   // (entries only grow: a stale read shows a smaller one at worst, then the atomic decides)
