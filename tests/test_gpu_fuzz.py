@@ -164,3 +164,79 @@ def test_batch_beyond_65535_contigs(binding):
         compare(streams, oe.streams())
         assert [len(oe.stream(k)) for k in range(6)] == [int(x) for x in sizes6[i]], i
     assert total == int(sizes6.sum())
+
+
+def genomes_with_runs(rng, length, nfiles):
+    """related genomes whose common base holds runs of one letter (N runs among them) and of short periods"""
+    base = synth.ACGT[rng.integers(0, 4, length)]
+    for _ in range(int(rng.integers(2, 8))):
+        a, ln = int(rng.integers(0, length - 700)), int(rng.integers(30, 600))
+        per = int(rng.choice([1, 1, 1, 2, 3, 16]))
+        unit = synth.ACGT[rng.integers(0, 4, per)] if rng.random() < 0.7 else np.full(per, ord("N"), dtype=np.uint8)
+        base[a:a + ln] = np.resize(unit, ln)
+    return [cut(rng, mutate(rng, base, 0.004 * (1 + i % 4)), int(rng.integers(1, 5))) for i in range(nfiles)]
+
+
+def _extra():
+    import os
+    return int(os.environ.get("MBGC_FUZZ_EXTRA", "24"))
+
+
+def test_fuzz_small_buffers_and_runs_of_one_letter(binding):
+    """MBGC_FUZZ_EXTRA cases (default 24; 1000 ran clean at the end of round 2): buffers of 1.5 to 20 genome lengths — most
+    wrap several times, inside rounds with retries too —, runs of one letter, both target loops of the plain API"""
+    for seed in range(5000, 5000 + _extra()):
+        rng = np.random.default_rng(seed)
+        length = int(rng.choice([30_000, 50_000, 80_000]))
+        gs = genomes_with_runs(rng, length, int(rng.integers(6, 14)))
+        lim = int(rng.choice([3, 4, 6, 9, 40]) * length // 2 + rng.integers(0, 5000))
+        rs = int(rng.integers(1, 8))
+        h, o = binding.SlidingWindowSparseEMMatcher(lim), _orc.OracleMatcher(lim)
+        a = _driver.encode_rounds(h, lambda: HipEmitter(binding, h), gs[0], gs[1:], rs)
+        b = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), gs[0], gs[1:], rs)
+        assert a["unmatched"] == b["unmatched"] and a["locks"] == b["locks"] and a["refExtSize"] == b["refExtSize"], (seed, lim, rs)
+        compare(a["streams"], b["streams"])
+        assert np.array_equal(h.ht(), o.ht()), (seed, lim, rs)
+        h.close(), o.close()
+        h, o = binding.SlidingWindowSparseEMMatcher(lim), _orc.OracleMatcher(lim)
+        he, oe = HipEmitter(binding, h), _orc.OracleEmitter(o)
+        a, b = _driver.encode_sequential(h, he, gs), _driver.encode_sequential(o, oe, gs)
+        for x, y in zip(a["matches"], b["matches"]):
+            assert np.array_equal(x, y), (seed, lim)
+        compare(he.streams(), oe.streams())
+        assert np.array_equal(h.ht(), o.ht()), (seed, lim)
+        h.close(), o.close()
+
+
+def test_fuzz_the_pipelined_round_runner(binding):
+    """the same kind of input through RoundRunner (batch calls, speculative finalize, second phase kept back behind the next
+    resolve launch), targets of several contigs"""
+    import torch
+    from mbgc_amd.rounds import RoundRunner, round_schedule
+    for seed in range(7000, 7000 + _extra()):
+        rng = np.random.default_rng(seed)
+        length = int(rng.choice([30_000, 60_000]))
+        gs = genomes_with_runs(rng, length, int(rng.integers(8, 20)))
+        lim = int(rng.choice([3, 4, 6, 9, 40]) * length // 2 + rng.integers(0, 5000))
+        rs = int(rng.integers(1, 7))
+        h = binding.SlidingWindowSparseEMMatcher(lim)
+        h.set_sliding_window_size(16)
+        h.load_ref(np.concatenate(gs[0]), load_rc=True)
+        runner = RoundRunner(h, 0, 1, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1))
+        runner.start()
+        for rnd in round_schedule(len(gs) - 1, rs, 1):
+            contigs = [c for t in rnd[0] for c in gs[1 + t]]
+            tgt = [k for k, t in enumerate(rnd[0]) for _ in gs[1 + t]]
+            buf = torch.from_numpy(np.concatenate(contigs)).to("cuda:0")
+            offs = np.zeros(len(contigs) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([c.size for c in contigs])
+            torch.cuda.synchronize()
+            runner.run_round(buf, offs, targets=tgt)
+        runner.flush()
+        o = _orc.OracleMatcher(lim)
+        res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), gs[0], gs[1:], rs)
+        for k, v in res["streams"].items():
+            assert bytes(runner.streams[k]) == v, (seed, lim, rs, k)
+        assert bytes(runner.locks_stream) == res["locks"] and bytes(runner.ref_ext_sizes) == res["refExtSize"], (seed, lim, rs)
+        assert np.array_equal(h.ht(), o.ht()), (seed, lim, rs)
+        o.close(), h.close()
