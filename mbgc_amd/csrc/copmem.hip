@@ -347,6 +347,11 @@ int mbgc_copmem_rc_matches(mbgc_copmem_t *p, const uint8_t *seq, uint64_t n, uin
     Params P;
     memset(&P, 0, sizeof P);
     int r;
+    // MBGC calls with the default (rcMatchSequence(..., rcMatchMinLength), MBGC_Encoder.cpp:636-638). A minimum BELOW the target
+    // length makes the reference report whichever of the shorter matches its sampling happens upon; random inputs with runs of
+    // one letter gave rows the device path reports and the reference does not (round 2's fuzz, 40 of 120 cases): not offered.
+    if (minMatchLength != UINT32_MAX && minMatchLength < L)
+        return fail(-3, "a minimal match length below the target length (%u < %u) is not supported on the device", minMatchLength, L);
     if ((r = derive_params(P, n, L, minMatchLength > L ? L : minMatchLength))) return r;    // CopMEMMatcher.cpp:500-502
     P.minLen = minMatchLength == UINT32_MAX ? L : minMatchLength;          // SimpleSequenceMatcher.cpp:80-81
     if (P.minLen < (uint32_t) P.K) return fail(-3, "Minimal matching length cannot be smaller than K (%u < %d)", P.minLen, P.K);   // :522-525

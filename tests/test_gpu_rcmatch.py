@@ -30,7 +30,7 @@ def test_matches_and_rewrite_equal_oracle(ssm, name):
     assert ssm.rc_match_sequence(s) == _orc.rc_match_sequence(s), name
 
 
-@pytest.mark.parametrize("target,min_len", [(55, 0xFFFFFFFF), (32, 0xFFFFFFFF), (80, 60), (120, 0xFFFFFFFF), (55, 44)])
+@pytest.mark.parametrize("target,min_len", [(55, 0xFFFFFFFF), (32, 0xFFFFFFFF), (120, 0xFFFFFFFF), (80, 0xFFFFFFFF), (55, 80)])
 def test_other_lengths_equal_oracle(ssm, target, min_len):
     s = _rcdata.literal_like(150_000, 11, copies=50, longest=1500)
     got, params = ssm.rc_matches(s, target, min_len)
@@ -39,12 +39,43 @@ def test_other_lengths_equal_oracle(ssm, target, min_len):
     assert ssm.rc_match_sequence(s, target, min_len) == _orc.rc_match_sequence(s, target, min_len)
 
 
+def test_a_minimum_below_the_target_length_is_refused(ssm):
+    """(80, 60) and (55, 44) equal the oracle on this file's data and differ from it on random inputs with runs of one letter
+    (the reference reports whichever shorter matches its sampling happens upon): MBGC never asks for it, the device says no"""
+    from mbgc_amd import binding
+    s = _rcdata.literal_like(20_000, 13)
+    for target, min_len in ((80, 60), (55, 44)):
+        with pytest.raises(binding.SwsemError):
+            ssm.rc_matches(s, target, min_len)
+
+
+def test_fuzz_default_minimum(ssm):
+    """random streams with planted, mutated and palindromic reverse-complement copies and runs of one letter, target lengths
+    55 and 32 with the default minimum: matches, rewritten stream and maps against the oracle"""
+    for seed in range(15000, 15040):
+        rng = np.random.default_rng(seed)
+        n = int(rng.choice([3_000, 40_000, 150_000, 400_000]))
+        s = _rcdata.literal_like(n, seed, copies=int(rng.integers(0, 80)), longest=int(rng.choice([200, 1500, 6000, 30000])),
+                                 mutate=float(rng.choice([0.0, 0.0, 0.005, 0.02])))
+        if rng.random() < 0.5:
+            a = int(rng.integers(0, max(1, n - 500)))
+            s[a:a + int(rng.integers(60, 400))] = _rcdata.ACGT[int(rng.integers(0, 4))]
+        if rng.random() < 0.3 and n > 5000:
+            a = int(rng.integers(0, n - 3000))
+            s[a + 700:a + 1400] = _rcdata.revcomp(s[a:a + 700].copy())
+        target = int(rng.choice([55, 32]))
+        got, params = ssm.rc_matches(s, target)
+        want, wparams, _ = _orc.rc_find_matches(s, target)
+        assert params == wparams and got.shape == want.shape and np.array_equal(got, want), seed
+        assert ssm.rc_match_sequence(s, target) == _orc.rc_match_sequence(s, target), seed
+
+
 def test_reference_error_cases(ssm):
     from mbgc_amd import binding
     s = _rcdata.literal_like(10_000, 12)
     with pytest.raises(binding.SwsemError):
         ssm.rc_matches(s, 55, 20)                                     # "Minimal matching length too short!" (CopMEMMatcher.cpp:76-79)
-    rows, params = ssm.rc_matches(s, 80, 24)                          # K follows the minimal length down ((24/4 - 1) * 4 = 20): no error
+    rows, params = ssm.rc_matches(s, 24)                              # K follows the length down ((24/4 - 1) * 4 = 20): no error
     assert params[0] == 20
     assert ssm.rc_match_sequence(s[:40]) == (s[:40].tobytes(), b"", b"", (0, 0, 0))   # shorter than the target: no matcher, empty maps
 
