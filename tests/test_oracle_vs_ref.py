@@ -297,3 +297,45 @@ def test_listeria_streams_equal_reference_cli_dumps(refh, tmp_path):
     assert res["refExtSize"] == dump[19]
     assert hashlib.md5(dump[15]).hexdigest().startswith("3731a2eb")
     assert hashlib.md5(dump[16]).hexdigest().startswith("14508a05")
+
+
+def _fuzz_genomes(seed, length=50_000, nfiles=9):
+    """tests/test_gpu_fuzz.py's generator without its GPU imports (test_fuzz_rounds, seed 1109: an N run in the piece that is
+    loaded right after a wrap, inside a round with retries)"""
+    src = open(os.path.join(os.path.dirname(__file__), "test_gpu_fuzz.py")).read()
+    code = src[src.index("_COMP ="):src.index('@pytest.mark.parametrize("seed", [1, 2, 3, 4])')]
+    code = code[:code.index("@pytest.fixture")] + code[code.index("def mutate"):]
+    from mbgc_amd import synth
+    g = {"np": np, "synth": synth}
+    exec(code, g)
+    rng = np.random.default_rng(seed)
+    base = synth.ACGT[rng.integers(0, 4, length)]
+    return [g["cut"](rng, g["mutate"](rng, base, 0.004 * (1 + i % 4)), int(rng.integers(1, 5))) for i in range(nfiles)]
+
+
+def test_the_fuzz_case_with_an_n_run_behind_a_wrap(refh):
+    """what the device path was wrong about (fingerprints of samples off the grid): the matches into the N run of
+    the piece loaded right after the wrap ARE the reference's — restatement against the reference itself"""
+    gs = _fuzz_genomes(1109)
+    lim, round_size = 350_000, 4
+    r, o = both(refh, lim)
+    ad = RefEmitAdapter(refh, r, n_targets=len(gs) - 1)
+    cnt = {"t": 0}
+
+    def make_ref():
+        class E:
+            def __init__(s): s.t = cnt["t"]; cnt["t"] += 1; s.v = ad.view(s.t)
+            def process(s, *a): return s.v.process(*a)
+            def put(s, which, data): ad.e.after_sequence(s.t) if which == 0 else ad.e.after_target(s.t)
+            def streams(s): return ad.e.streams(s.t)
+        return E()
+
+    a = _driver.encode_rounds(r, make_ref, gs[0], gs[1:], round_size)
+    b = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), gs[0], gs[1:], round_size)
+    assert a["locks"] == b["locks"] and a["refExtSize"] == b["refExtSize"] and a["unmatched"] == b["unmatched"]
+    for x, y in zip(a["matches"], b["matches"]):
+        assert np.array_equal(x, y)
+    for k in a["streams"]:
+        assert a["streams"][k] == b["streams"][k], k
+    assert_same_state(r, o)
+    assert any(len(m) and (np.asarray(m)[:, 0] == 8276).any() for m in b["matches"])      # the matches in question
