@@ -34,8 +34,8 @@ const char *mbgc_copmem_last_error(void);
  * correctDestPositionDueToRevComplMatching). seq_host: the literal stream in host memory. *matches points into a
  * handle-owned buffer valid until the next call. params (may be NULL) receives K, k1, k2, log2(hash size).
  * minMatchLength = UINT32_MAX means "the target length" (SimpleSequenceMatcher.cpp:80-81) and is what MBGC passes; a value below
- * L is refused (-3): the shorter matches the reference then reports depend on its sampling in a way the device path does not
- * reproduce on every input. Returns 0, -3 where the
+ * L is refused (-3): which of the shorter matches the reference then reports is decided by its 4-byte pre-filter, which the
+ * device path does not model (it is result-neutral for matches of at least the target length). Returns 0, -3 where the
  * reference prints a message and exits (minimal length < 24 or < K, L/K mismatch), or a negative error of its own. */
 int mbgc_copmem_rc_matches(mbgc_copmem_t *p, const uint8_t *seq_host, uint64_t n, uint32_t targetMatchLength,
                            uint32_t minMatchLength, const mbgc_copmem_match_t **matches, uint64_t *count, int params[4]);

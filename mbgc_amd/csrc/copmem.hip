@@ -348,8 +348,9 @@ int mbgc_copmem_rc_matches(mbgc_copmem_t *p, const uint8_t *seq, uint64_t n, uin
     memset(&P, 0, sizeof P);
     int r;
     // MBGC calls with the default (rcMatchSequence(..., rcMatchMinLength), MBGC_Encoder.cpp:636-638). A minimum BELOW the target
-    // length makes the reference report whichever of the shorter matches its sampling happens upon; random inputs with runs of
-    // one letter gave rows the device path reports and the reference does not (round 2's fuzz, 40 of 120 cases): not offered.
+    // length makes the reference report shorter matches too — those that pass its 4-byte pre-filter (:404), whose windows are
+    // laid out for the target length: result-neutral (and not modelled here) for matches at least that long, decisive for
+    // the shorter ones (round 2's fuzz: rows reported here and not by the reference in 40 of 120 cases). Not offered.
     if (minMatchLength != UINT32_MAX && minMatchLength < L)
         return fail(-3, "a minimal match length below the target length (%u < %u) is not supported on the device", minMatchLength, L);
     if ((r = derive_params(P, n, L, minMatchLength > L ? L : minMatchLength))) return r;    // CopMEMMatcher.cpp:500-502
