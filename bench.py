@@ -482,6 +482,8 @@ def main():
                 if len(t):
                     out["resolve_block_ticks"] = {"blocks": int(nb.value), "mean": float(t.mean()), "median": float(t[len(t) // 2]),
                                                   "p90": float(t[int(len(t) * 0.9)]), "p99": float(t[int(len(t) * 0.99)]), "max": float(t[-1])}
+        if os.environ.get("MBGC_BENCH_OCC"):                          # diagnostics: share of the table's buckets that hold an entry at the end of the run
+            out["table_occupancy"] = round(float(np.count_nonzero(m.ht())) / m.hash_size(), 5)
         if world > 1 or forced:
             out["rccl_ranks_seen"] = dist.get_world_size()
             out["extension_allgathers_started_ahead"] = {"started": runner.pregathers[0], "used": runner.pregathers[1]}
