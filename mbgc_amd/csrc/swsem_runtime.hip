@@ -1127,7 +1127,7 @@ int swsem_load_separator(swsem_t *h, int sep) {
 // loadRef of the target's extension, the lazy-mode region separator, release of its lock position.
 // loadedAfter[i] = getLoadedRefLength() after target i (what the encoder appends to refExtLoadedPosArr).
 static int finalize_impl(swsem_t *h, int n, const uint8_t *const *ext_dev, const uint64_t *ext_len, int addSep, int sep,
-                         int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter, const uint32_t *gate) {
+                         int lazySeparator, const uint64_t *lockPos, uint64_t *loadedAfter, const uint32_t *gate, bool planOnly = false) {
     HIPCHK(hipSetDevice(h->device));
     // all byte writes of the round first (copies, region separators), then every insertion phase in one
     // launch: hashing a window needs its bytes — including a separator written by a later step — in place
@@ -1141,8 +1141,10 @@ static int finalize_impl(swsem_t *h, int n, const uint8_t *const *ext_dev, const
     }
     h->deferInserts = false;
     if (r == SWSEM_ESPEC) { h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear(); return r; }
+    // planOnly (the speculative finalize): the host's bookkeeping is done and the launches are listed; the caller queues them
+    // (flush_inserts) once every replica's verdict has been reduced into the gate — and knows by now whether THIS replica can
+    if (planOnly) return r;
     const int r2 = flush_inserts(h, gate);
-    if (r2 == SWSEM_ESPEC) { h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear(); }
     return r ? r : r2;
 }
 
@@ -1487,22 +1489,33 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     // round trip. The host comes to the same verdict from the values pass 1 hands back and keeps or undoes its
     // bookkeeping accordingly; when the prediction fails nothing on the device has changed.
     struct { int64_t pos1, sepEndPos; int laps, sepEndLaps, sepEndVal; uint64_t samplingPos, swEnd; uint32_t epoch, eCur, ePrev; bool pristine; std::deque<uint64_t> locks; } snap;
-    bool queued = false;
+    bool queued = false, exchanged = false;
     if (spec && spec->ntargets > 0) {
         snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch; snap.eCur = h->eCur; snap.ePrev = h->ePrev; snap.sepEndPos = h->sepEndPos; snap.sepEndLaps = h->sepEndLaps; snap.sepEndVal = h->sepEndVal;
         snap.pristine = h->pristine; snap.locks = h->locks;
         uint32_t *gate = spec->gate_dev ? spec->gate_dev : h->dGate.p;
         k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, gate);
-        if (spec->veto) HIPCHK(hipMemsetAsync(gate, 0, sizeof(uint32_t), h->stream));
-        // several replicas: the word becomes the minimum over all of them before anything gated by it is queued
-        if (spec->exchange && spec->exchange(spec->exchange_ctx, 0, gate, (void *) h->stream)) return fail(SWSEM_EHIP, "speculative finalize: the exchange between the replicas failed");
+        // The host's half first (lock window, piece schedule, separators: load_pieces and its callees, nothing launched): it can
+        // find that this finalize cannot be queued behind a gate at all (SWSEM_ESPEC: a write that would have to wait for an older
+        // emission, a separator over an already hashed byte). With several replicas that has to be known BEFORE the verdicts are
+        // reduced: a replica that cannot apply the round must say so in the reduction, or the others apply it without it.
         h->specMode = true;
         r = finalize_impl(h, spec->ntargets, spec->ext_dev, spec->ext_len, spec->addSep, spec->sep, spec->lazySeparator, spec->lockPos,
-                          spec->loadedAfter, gate);
+                          spec->loadedAfter, gate, true);
         h->specMode = false;
-        if (r == SWSEM_ESPEC) r = SWSEM_OK;                         // not possible this time: nothing was queued
+        const bool planned = r == SWSEM_OK;
+        if (r == SWSEM_ESPEC) r = SWSEM_OK;                         // not possible this time: nothing will be queued
         else if (r) return r;
-        else queued = true;
+        if (spec->veto || !planned) HIPCHK(hipMemsetAsync(gate, 0, sizeof(uint32_t), h->stream));
+        // several replicas: the word becomes the minimum over all of them before anything gated by it is queued
+        if (spec->exchange) {
+            if (spec->exchange(spec->exchange_ctx, 0, gate, (void *) h->stream)) return fail(SWSEM_EHIP, "speculative finalize: the exchange between the replicas failed");
+            exchanged = true;
+        }
+        if (planned) {
+            if ((r = flush_inserts(h, gate))) return r;
+            queued = true;
+        }
         if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
                        h->pristine = snap.pristine; h->locks = snap.locks; }
     }
@@ -1517,11 +1530,12 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
             ok = un != UINT64_MAX && (un * (uint64_t) spec->factor > len) == (spec->predExt[k] != 0) &&
                  (un * (uint64_t) spec->rcFactor > len) == (spec->predRC[k] != 0);
         }
-        if (spec->exchange) ok = spec->exchange(spec->exchange_ctx, 1, nullptr, (void *) h->stream) == 1 && ok;   // ... and every other replica's
+        if (exchanged) ok = spec->exchange(spec->exchange_ctx, 1, nullptr, (void *) h->stream) == 1 && ok;   // ... and every other replica's
         if (ok) { if (applied) *applied = 1; }
         else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
                h->pristine = snap.pristine; h->locks = snap.locks; }
-    }
+    } else if (exchanged)
+        (void) spec->exchange(spec->exchange_ctx, 1, nullptr, (void *) h->stream);   // (this replica said no in the reduction: the word is 0 everywhere; taken so that the exchange's state is the same on every rank)
     return SWSEM_OK;
 }
 

@@ -68,6 +68,8 @@ int main(int argc, char **argv) {
         else if (a == "-L") params.lazyDecompressionSupport = false;             // disable lazy decompression support
         else if (a == "-U") params.uppercaseDNA = true;                          // MBGC_Params.h: converts bases to uppercase
         else if (a == "--bench") params.benchMode = true;                        // rounds timed with every contig resident in HBM (no streams written)
+        else if (a == "--verify-every" && i + 1 < argc) { params.verifyEmissions = true; params.verifyEvery = atoi(argv[++i]); }
+        else if (a == "--verify") params.verifyEmissions = true;                  // every emission decoded again on the device before the reference moves on
         else if (a == "--warmup" && i + 1 < argc) params.benchWarmup = atoi(argv[++i]);
         else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (a == "--exchange" && i + 1 < argc) transport = argv[++i];
@@ -79,7 +81,7 @@ int main(int argc, char **argv) {
         else pos.push_back(a);
     }
     if (pos.size() != 2) {
-        fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--bench [--warmup rounds]] "
+        fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--verify | --verify-every K] [--ref-factor F] [--bench [--warmup rounds]] "
                         "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T] [--backend-blocks K]] <sequencesListFile> <outputPrefix>\n");
         return EXIT_FAILURE;
     }
@@ -185,6 +187,8 @@ int main(int argc, char **argv) {
         printf("backend: %zu stream bytes to %zu in %.0f ms (%d threads, %d x the reference's blocks)\n", raw, section.size(),
                (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, backendThreads, std::max(1, backendBlocksScale));
     }
+    if (params.verifyEmissions) printf("verified on the device: %llu contigs, %llu bases decoded back to their bytes\n",
+                                       (unsigned long long) params.verifiedContigs, (unsigned long long) params.verifiedBases);
     printf("exact matches total: %zu\n", enc.exactMatches());
     printf("removed matches breaking gaps total: %zu\n", enc.removedGapBreakingMatchesAll);
     printf("swsMEM unmatched chars: %zu\n", enc.unmatchedChars());

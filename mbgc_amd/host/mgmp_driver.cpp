@@ -419,6 +419,18 @@ void MultipleGenomeMatchingProcessor::loadG0Ref(const std::string &refName) {
 // before it, so the contigs run one after the other — but only up to what the next one needs: a contig's match-finding
 // and processMatches' first pass (its return value decides the loadRef), then the loadRef; the stream bytes of contig c
 // are produced beside contig c + 1 (two emissions in flight) and appended, in order, one contig later.
+void MultipleGenomeMatchingProcessor::verifyEmission(size_t contigs, size_t bases) {
+    int firstBad = -1;
+    uint64_t firstDiff = 0;
+    const int nbad = matcher->emitVerify(&firstBad, &firstDiff);
+    if (nbad) {
+        fprintf(stderr, "verify: %d of %zu contigs do not decode back to their bytes (first: contig %d of the batch, byte %llu; %llu contigs verified before)\n",
+                nbad, contigs, firstBad, (unsigned long long) firstDiff, (unsigned long long) params->verifiedContigs);
+        exit(EXIT_FAILURE);
+    }
+    params->verifiedContigs += contigs; params->verifiedBases += bases;
+}
+
 void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
     RoundBatch three[3];                   // the file being matched, the file arriving, the file whose last contig's emission still reads its bytes
     struct { bool valid = false; int fileSeps = 0; uint32_t buf = 0; } prev;                   // the contig whose streams are still to be taken
@@ -450,6 +462,7 @@ void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
                                     nullptr, un, counts);                                        // :276 (targetIdx 0 in this mode, ENC.cpp:202)
             resCount += counts[0];
             totalDestLenAll += bSize;
+            if (params->verifyEmissions && i % (uint32_t) std::max(1, params->verifyEvery) == 0) verifyEmission(1, bSize);
             collectPrev(true);
             const size_t currentUnmatched = un[0];
             const bool loadContigToRef = params->isContigProperForRefExtension(bSize, currentUnmatched, params->currentUnmatchedFractionFactor);
@@ -550,6 +563,7 @@ void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B, siz
             matcher->matchRound(dev + offsets[at], offs, params->k, locks, counts);            // :379
             std::vector<EmittedStreams> out;
             matcher->emitRound(emitParams(), locks, factors, processed, tidx, loadedPositions(), out);   // :381
+            if (params->verifyEmissions) verifyEmission(n, offs[n]);
             for (size_t k = 0; k < n; k++) {
                 const int c = (int) (at + k);
                 if (out[k].unmatchedChars == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) {   // :382-388
@@ -728,7 +742,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
         std::vector<uint64_t> extLen(T, 0), loadedAfter(T, 0);
         std::vector<uint8_t> predExt(ncont, predicted == 1), predRC(ncont, 0);
         swsem_spec_finalize_t spec = {};
-        const bool useSpec = predicted >= 0;
+        const bool useSpec = predicted >= 0 && !params->verifyEmissions;       // (verifying: the round's loads wait for the check)
         if (useSpec) {
             if (predicted == 1)
                 for (uint32_t t = 0; t < T; t++)
@@ -760,6 +774,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             continue;
         }
         for (size_t c = 0; c < ncont; c++) resCount += counts[c];
+        if (params->verifyEmissions && (B.t0 / std::max<uint32_t>(1, T)) % (uint32_t) std::max(1, params->verifyEvery) == 0) verifyEmission(ncont, B.offsets[ncont] - B.offsets[0]);
         // extension policy, :389-398
         std::vector<char> ext(ncont), rc(ncont);
         bool allExt = true, noneExt = true, anyRC = false;

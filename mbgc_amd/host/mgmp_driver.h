@@ -36,6 +36,11 @@ struct MGMP_Params {                                   // matching/MGMP_Params.h
     // mbgc-hip c --bench: every round's contigs are put into HBM first, the rounds after `benchWarmup` are timed and the
     // emitted streams stay packed in HBM (what bench.py measures, from the C++ host)
     bool benchMode = false;
+    // mbgc-hip c --verify: every emission is decoded again on the device (SlidingWindowSparseEMMatcher::emitVerify) before the
+    // reference moves on, and the run fails on the first contig that does not come back; rounds then load on the host's decision
+    bool verifyEmissions = false;
+    int verifyEvery = 1;                               // --verify-every K: only the emissions of every K-th target file (sequential schedule) / round
+    uint64_t verifiedContigs = 0, verifiedBases = 0;
     int benchWarmup = 0;
     double benchSeconds = 0; uint64_t benchBases = 0; int benchRounds = 0;   // filled by processTargetsRounds
     // several GPUs: this process is one rank of `exchange`; a round then holds roundSize targets PER RANK
@@ -90,6 +95,7 @@ protected:
     void performMatching();                                                             // :568-606
     void processTargetsWithParallelIO();                                                // :232-313  (-t1)
     void processTargetsRounds();                                                        // :340-468 as deterministic rounds
+    void verifyEmission(size_t contigs, size_t bases);                                  // --verify: the selected emission through the device decoder, exit on a contig that does not come back
     void processRoundWithRetries(RoundBatch &B, size_t expectTaken = SIZE_MAX);                                        // a round holding a dissimilar contig (:382-388), blocking calls
     void processTargetsRoundsSharded();                                                 // the rounds with their targets sharded over the ranks of params->exchange (mgmp_sharded.cpp)
     // input stage (MGMP.cpp:7-35,349-372 on the device parser)

@@ -159,6 +159,11 @@ void SlidingWindowSparseEMMatcher::emitCounters(std::vector<uint64_t> &out, int 
 void SlidingWindowSparseEMMatcher::emitView(int k, swsem_streams_t &view) { check(swsem_emit_result(h, k, &view), "processMatches"); }
 
 void SlidingWindowSparseEMMatcher::emitEnd() { check(swsem_emit_batch_end(h), "processMatches"); }
+int SlidingWindowSparseEMMatcher::emitVerify(int *firstBad, uint64_t *firstDiff) {
+    int nbad = 0;
+    check(swsem_emit_verify(h, &nbad, firstBad, firstDiff), "decodeSequence");
+    return nbad;
+}
 
 void SlidingWindowSparseEMMatcher::finalizeTargets(const std::vector<const uint8_t *> &extDev, const std::vector<uint64_t> &extLen,
                                                    bool addSep, char sep, bool lazySeparator, const std::vector<uint64_t> &lockPos,

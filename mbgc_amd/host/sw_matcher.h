@@ -91,6 +91,9 @@ public:
     uint64_t emitPack(uint8_t *dstDev, uint64_t cap, std::vector<uint64_t> *sizes, int n);
     void emitCounters(std::vector<uint64_t> &out, int n);
     void emitEnd();
+    // the selected emission decoded again on the device by the decoder's automaton (MBGC_Decoder.cpp:319-523; include/mbgc_swsem.h:
+    // swsem_emit_verify) and compared with the contigs it was emitted for: contigs that fail, the first of them, its first differing byte
+    int emitVerify(int *firstBad = nullptr, uint64_t *firstDiff = nullptr);
     void finalizeTargets(const std::vector<const uint8_t *> &extDev, const std::vector<uint64_t> &extLen, bool addSep, char sep,
                          bool lazySeparator, const std::vector<uint64_t> &lockPos, std::vector<uint64_t> &loadedAfter);
     void synchronize();

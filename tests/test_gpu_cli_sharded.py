@@ -66,6 +66,24 @@ def test_ranks_on_one_gpu_equal_the_single_gpu_rounds(tmp_path, gpus, r, n, div,
         assert spec == 0
 
 
+@pytest.mark.parametrize("gpus,r,empty", [(2, 1, (4, 9)), (2, 1, (3, 5, 7)), (3, 1, (6,)), (2, 2, (5, 6))])
+def test_a_rank_whose_file_holds_no_record(tmp_path, gpus, r, empty):
+    """files without a record among the targets (an empty file: kseq reports end of file at once, MGMP.cpp:16-35) with rounds of
+    one or two targets per rank: in such a round one rank has nothing to match or emit, and in the next its emission slots stand
+    differently from the other ranks' — the speculative finalize must come out the same on every rank (a rank that cannot
+    queue it says so in the reduction of the verdicts), the streams must equal the single-GPU rounds'"""
+    write_collection(tmp_path, 14, 70_000, 0.003, 1)
+    for i in empty:
+        (tmp_path / ("g%02d.fa" % i)).write_bytes(b"")
+    one = run_tool(["c", "-R", str(gpus * r), "list.txt", "one"], str(tmp_path))
+    many = run_tool(["c", "--gpus", str(gpus), "--exchange", "hostmem", "--shm-mb", "1", "-R", str(r), "list.txt", "many"], str(tmp_path))
+    a, b = dumps(tmp_path, "one"), dumps(tmp_path, "many")
+    for k in STREAMS:
+        assert a[k] == b[k], k
+    for line in ("exact matches total", "final unmatched chars"):
+        assert [x for x in one.splitlines() if x.startswith(line)] == [x for x in many.splitlines() if x.startswith(line)], line
+
+
 def test_rccl_with_one_rank_equals_the_plain_loop(tmp_path):
     """the RCCL transport on the hardware at hand: one rank — communicators, the two collectives' streams, the on-stream
     reduction inside the speculative finalize, the gather — against the loop without an exchange"""
