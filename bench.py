@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark: input Gbases/s of the MI355X match-finding path (BASELINE.json `metric`).
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1000 synthetic 5 Mbp genomes at
-99 % identity per GPU, matched against the growing circular reference `mbgc c` sizes for that collection (G0 +
-reverse complement preloaded; 2.56e9 bytes and a 2^28-entry table for 1001 files, MGMP.cpp:130-168). A *step* is
-one round: every GPU matches `--round` targets (default: 1000 / (steps + warmup) = 40 under the driver's
-`--steps 20 --warmup 5`) against its frozen replica — matchTexts + processMatches, six streams — then every replica
-loads the round's extensions in target order (loadRef, hash insertion included). The run goes THROUGH the wrap of
-the circular buffer (near target 510); step times before and after it are reported separately. With N > 1 the
-targets are sharded file-per-GPU (N x 1000 genomes, per-GPU work fixed: weak scaling), the extension bytes are
-all-gathered over RCCL and the streams gathered to rank 0. Inputs are resident in HBM before the timed region.
-One JSON line is printed by rank 0.
+Workload (BASELINE.json configs[2] on one GPU, configs[3] on several: the SAME collection at every N): 1000 synthetic
+5 Mbp genomes at 99 % identity, matched against the growing circular reference `mbgc c` sizes for that collection (G0 +
+reverse complement preloaded; 2.56e9 bytes and a 2^28-entry table for 1001 files, MGMP.cpp:130-168 — at every N). A
+*step* is one round: the round's targets hold their lock positions together, so a round is as large as the reference's
+own rules let targets be in flight — what they load must fit the sliding window (1/16 of the buffer = 160 MB = 31
+targets; SlidingWindowSparseEMMatcher.cpp:361-378,412-417,433: what goes beyond the window is dropped) and at most 64
+(MGMP.cpp:374-375,532) — and NO extension byte is dropped (`extension_bytes_dropped_per_step` must be 0, or the line says
+INVALID). Every GPU matches its share of the round (31 // N targets, file-per-GPU) against its frozen replica —
+matchTexts + processMatches, six streams — then every replica loads the round's extensions in target order (loadRef,
+hash insertion included). The run goes THROUGH the wrap of the circular buffer (near target 510); step times before and
+after it are reported separately. With N > 1 the total work per step is fixed (strong scaling: the in-flight bound is
+the collection's, not a GPU's), the extension bytes are exchanged over RCCL and the streams gathered to rank 0. Inputs are
+resident in HBM before the timed region. One JSON line is printed by rank 0.
 
 `python bench.py --gpus N` starts its own N ranks (children, before anything in this process touches a GPU);
 under `python -m torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
@@ -34,7 +37,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GENOME_LEN = 5_000_000
-COLLECTION = 1000                    # targets per GPU of configs[2]
+COLLECTION = 1000                    # targets of configs[2] / configs[3]
+SW_FACTOR = 16                       # DEFAULT_REFERENCE_SLIDING_WINDOW_FACTOR, MGMP_Params.h:36
+MAX_IN_FLIGHT = 64                   # matcherWorkingThreads x allowedTargetsOutrunFactor, MGMP.cpp:532, MGMP_Params.h:16,57
+
+
+def targets_in_flight(max_ref, target_bytes):
+    """targets that may hold their lock positions together: what they load (target + region separator each) fits the
+    sliding window, and the reference never lets more than 64 run ahead of its finalizer"""
+    return max(1, min(MAX_IN_FLIGHT, (max_ref // SW_FACTOR) // (target_bytes + 1)))
 
 
 def ref_length_limit(files_count, basic_len):
@@ -242,7 +253,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--round", type=int, default=0, help="targets per GPU per step (default: 1000 / (steps + warmup), at most 40)")
+    ap.add_argument("--round", type=int, default=0, help="targets per GPU per step (default: what fits the sliding window, at most 64, divided by the GPUs)")
     ap.add_argument("--length", type=int, default=GENOME_LEN)
     ap.add_argument("--cpu-sample", type=int, default=128, help="targets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--check", action="store_true", help="compare the first step's matches with the oracle")
@@ -264,7 +275,11 @@ def main():
     from mbgc_amd import synth
     from mbgc_amd.rounds import round_schedule
     steps, warm = args.steps, args.warmup
-    R = args.round if args.round > 0 else max(1, min(40, COLLECTION // (steps + warm)))
+    # the buffer `mbgc c` gives the collection of configs[2] / configs[3] (1000 targets + G0) at every N
+    coll = COLLECTION
+    max_ref = int(float(os.environ["MBGC_BENCH_MAX_REF"])) if "MBGC_BENCH_MAX_REF" in os.environ else ref_length_limit(1 + coll, args.length)
+    cap = targets_in_flight(max_ref, args.length)
+    R = args.round if args.round > 0 else max(1, min(cap, COLLECTION // (steps + warm)) // world)
     n_targets = (steps + warm) * R * world
     # synthetic collection (SURVEY.md §8d recipe), generated by forked workers BEFORE this process touches the GPU:
     # this rank's targets of every round, one host array per round
@@ -314,9 +329,6 @@ def main():
     from mbgc_amd import binding
     from mbgc_amd.rounds import RoundRunner
 
-    # the buffer `mbgc c` gives the whole collection of configs[2] (N x 1000 targets + G0), whatever part of it this run matches
-    coll = max(COLLECTION * world, n_targets)
-    max_ref = int(float(os.environ["MBGC_BENCH_MAX_REF"])) if "MBGC_BENCH_MAX_REF" in os.environ else ref_length_limit(1 + coll, args.length)
     bit40 = max_ref > 0xFFFFFFFF
     m = binding.SlidingWindowSparseEMMatcher(max_ref, device=local_rank)
     stream = torch.cuda.current_stream()
@@ -362,6 +374,7 @@ def main():
             check_against_oracle(runner, base, sched[0][0], args.length, emit, max_ref)
         runner.keep_streams = False
     m.profile_enable(True)
+    dropped0 = m.dropped_bytes()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # step boundaries on the main stream
     laps_at = []                                                                   # laps of the circular buffer after each step
     barrier()
@@ -395,6 +408,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = m.profile_get()
     m.profile_enable(False)
+    dropped = m.dropped_bytes() - dropped0
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if os.environ.get("MBGC_BENCH_BLOCK_STATS"):          # diagnostics of the last round's resolve blocks, to stderr
         import ctypes as C
@@ -442,16 +456,16 @@ def main():
                        "input Gbases/s (compress path, SlidingWindowSparseEMMatcher only)") +
                       (" [queries cross PCIe inside the timed region]" if args.from_host else ""),
             "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": warm,
-            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[2]: %d synthetic 5 Mbp genomes @99%% identity%s, %.4g-byte circular reference "
+            "config": {"workload": ("configs[%d]: %d synthetic 5 Mbp genomes @99%% identity%s, %.4g-byte circular reference "
                                     "(the buffer `mbgc c` gives %d files); step = matchTexts%s + loadRef of one round of %d "
-                                    "targets/GPU; timed: targets %d..%d of the collection, through the buffer's wrap") %
-                                   (n_targets, " (%d per GPU, file-per-GPU)" % (n_targets // world) if world > 1 else "", float(max_ref),
+                                    "targets%s (the sliding window holds %d); timed: targets %d..%d of the collection, through the buffer's wrap") %
+                                   (3 if world > 1 else 2, n_targets, " sharded file-per-GPU over %d GPUs" % world if world > 1 else "", float(max_ref),
                                     1 + coll, " + processMatches (six streams, %s)" %
                                     ("gathered to rank 0 over RCCL" if world > 1 else "left packed in HBM for the host backend") if emit else "",
-                                    R, first_coll, n_targets),
-                       "genome_len": args.length, "targets_per_step": R * world, "max_ref_len": max_ref,
+                                    R * world, " (%d per GPU)" % R if world > 1 else "", cap, first_coll, n_targets),
+                       "genome_len": args.length, "targets_per_step": R * world, "targets_in_flight_cap": cap, "max_ref_len": max_ref,
                        "hash_entries": m.hash_size(), "offsets_40bit": bit40,
                        "sharding": "file-per-GPU, all-gather of extensions" if world > 1 else "one GPU"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
@@ -459,6 +473,14 @@ def main():
                          "traffic_GBs": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms else None,
                          "alg_bytes_per_base": round(alg[dom], 3), "avg_launch_ms": round(dom_ms, 4),
                          "whole_step_frac": round(ALG_BYTES_PER_BASE * value / world / HBM_PEAK_GBS, 5)},
+            # reference extension bytes loadRef gave up at the window's end inside the timed region (.cpp:433): a round that fits drops none
+            "extension_bytes_dropped_per_step": dropped / steps,
+            # per step, this rank: the sharded part (match-finding + stitch + processMatches' first pass), the part every replica
+            # repeats (loadRef: copies with the table insertion beside them), and the host's time in the exchange (N > 1, MBGC_ROUNDS_TRACE=1)
+            "sharded_ms": round(per_launch_ms["resolve"] + per_launch_ms["stitch"] + per_launch_ms["emit"], 4),
+            "replicated_ms": round(max(per_launch_ms["insert"], per_launch_ms["load"]), 4),
+            "exchange_ms": (round(sum(v for k, v in runner.trace.items() if k == "top" or k.startswith("flush")) * 1e3 / (steps + warm), 4)
+                            if runner.trace is not None and (world > 1 or forced) else None),
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch_ms.items() if k != "probe"},
             "kernel_ms_total": {k: round(prof[k][0], 3) for k in prof if k != "probe"}, "dominant_kernel": dom,
             "ms_per_step_before_wrap": round(float(np.mean(pre)), 4) if pre else None, "steps_before_wrap": len(pre),
@@ -494,6 +516,11 @@ def main():
             out["host_ms_per_round"] = {k: round(v * 1e3 / (steps + warm), 3) for k, v in runner.trace.items()}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit, max_ref)
+        if dropped and not os.environ.get("MBGC_BENCH_ALLOW_DROPS"):
+            # a round larger than the window discards part of its reference extensions: less replicated work, a worse ratio —
+            # not the workload. Such a line is marked, never the headline.
+            out["metric"] = "INVALID (reference extension bytes dropped at the sliding window's end): " + out["metric"]
+            out["value"] = None
         print(json.dumps(out), flush=True)
     if world > 1 or forced:
         dist.destroy_process_group()

@@ -62,6 +62,12 @@ uint64_t swsem_get_ref_length(const swsem_t *h);                  /* getRefLengt
 uint64_t swsem_get_loading_position(const swsem_t *h);            /* getLoadingPosition, .h:107 */
 uint64_t swsem_get_loaded_ref_length(const swsem_t *h);           /* getLoadedRefLength, .h:108 */
 uint64_t swsem_get_max_ref_length(const swsem_t *h);              /* getMaxRefLength, .h:105 */
+/* swSize (.h:47,97; 0: no window — sequential matching or a buffer that is not circular): what the targets that hold their
+ * lock positions together may load between them once the buffer has wrapped; the caller sizes its rounds by it */
+uint64_t swsem_get_sliding_window_size(const swsem_t *h);
+/* extension bytes loadRef has given up so far because the loader reached the oldest outstanding lock position
+ * (.cpp:412-417,433: `seqLength = pos1 == tmpEnd ? 0 : ...`) — 0 for rounds that fit the window */
+uint64_t swsem_get_dropped_bytes(const swsem_t *h);
 void swsem_set_position(swsem_t *h, uint64_t refPos, int reachedRefLengthCount);  /* setPosition, .h:110-113 */
 uint64_t swsem_acquire_lock(swsem_t *h);                          /* acquireWorkerMatchingLockPos, .cpp:361-378 */
 int swsem_release_lock(swsem_t *h, uint64_t lockValue);           /* releaseWorkerMatchingLockPos, .cpp:380-400 */

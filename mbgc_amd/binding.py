@@ -18,7 +18,7 @@ KERNEL_FAMILIES = ("load", "insert", "probe", "emit2", "resolve", "stitch", "emi
 
 EXPORTS = """swsem_last_error swsem_device_count swsem_device_numa_node swsem_create swsem_destroy swsem_set_stream swsem_synchronize
 swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circular_buffer swsem_get_ref_length
-swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_set_position
+swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_get_sliding_window_size swsem_get_dropped_bytes swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
 swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_emit_pack_dev_on swsem_emit_counters swsem_debug_copy_ref swsem_debug_write_ref swsem_debug_copy_ht
@@ -90,7 +90,7 @@ def lib():
         L.swsem_set_sliding_window_size.argtypes = [vp, ci]
         L.swsem_set_sliding_window_size.restype = None
         for n in ("swsem_get_ref_length", "swsem_get_loading_position", "swsem_get_loaded_ref_length",
-                  "swsem_get_max_ref_length", "swsem_acquire_lock"):
+                  "swsem_get_max_ref_length", "swsem_get_sliding_window_size", "swsem_get_dropped_bytes", "swsem_acquire_lock"):
             getattr(L, n).restype = u64
             getattr(L, n).argtypes = [vp]
         L.swsem_set_position.argtypes = [vp, u64, ci]
@@ -178,6 +178,8 @@ class SlidingWindowSparseEMMatcher:
     def loading_position(self): return lib().swsem_get_loading_position(self.h)
     def loaded_ref_length(self): return lib().swsem_get_loaded_ref_length(self.h)
     def max_ref_length(self): return lib().swsem_get_max_ref_length(self.h)
+    def sliding_window_size(self): return lib().swsem_get_sliding_window_size(self.h)
+    def dropped_bytes(self): return lib().swsem_get_dropped_bytes(self.h)
     def set_position(self, pos, laps): lib().swsem_set_position(self.h, pos, laps)
     def acquire_lock(self): return lib().swsem_acquire_lock(self.h)
     def release_lock(self, v): _chk(lib().swsem_release_lock(self.h, v)); return 0

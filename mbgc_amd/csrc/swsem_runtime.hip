@@ -88,6 +88,7 @@ struct swsem {
     void sep_end_set(int64_t at, int sep) { sepEndPos = at; sepEndLaps = laps; sepEndVal = sep; }
     bool pristine = true;                  // the loader has only moved forward (wraps included: told by epochs); false after swsem_set_position
     int fpBits = 0;                        // fingerprint bits of a table entry
+    uint64_t droppedBytes = 0;             // extension bytes loadRef gave up at the window's end (.cpp:433: the rest of a text is dropped when the loader reaches swEnd)
     uint64_t hostProbes = 0;               // query positions of the batch
     bool deferInserts = false;             // collect the insertion phases of a finalize call into one launch
     bool specMode = false;                 // a speculative finalize is being queued: nothing may be written outside its gated launches
@@ -449,6 +450,7 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
         int r = viaTable ? insert_samples(h, text, copiedTo, copiedTo + tmpLength) : insert_samples(h);
         if (r) return r;
         text += rc ? 0 : tmpLength;
+        if ((uint64_t) h->pos1 == tmpEnd) h->droppedBytes += len - tmpLength;
         len = (uint64_t) h->pos1 == tmpEnd ? 0 : len - tmpLength;
     }
     HIPCHK(hipGetLastError());
@@ -1040,6 +1042,8 @@ uint64_t swsem_get_loaded_ref_length(const swsem_t *h) {
     return (uint64_t) h->laps * (h->maxRefLength - REF_SHIFT) + ((uint64_t) h->pos1 - REF_SHIFT);
 }
 uint64_t swsem_get_max_ref_length(const swsem_t *h) { return h->maxRefLength; }
+uint64_t swsem_get_dropped_bytes(const swsem_t *h) { return h->droppedBytes; }
+uint64_t swsem_get_sliding_window_size(const swsem_t *h) { return h->circular ? h->swSize : 0; }
 void swsem_set_position(swsem_t *h, uint64_t p, int laps) { h->pos1 = (int64_t) p; h->laps = laps; h->pristine = false; }
 int swsem_get_K(const swsem_t *h) { return h->K; }
 uint32_t swsem_get_hash_size(const swsem_t *h) { return h->hash_size; }
@@ -1488,11 +1492,11 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     // prediction — so the copies and the table insertion start the moment pass 1 ends instead of after the host's
     // round trip. The host comes to the same verdict from the values pass 1 hands back and keeps or undoes its
     // bookkeeping accordingly; when the prediction fails nothing on the device has changed.
-    struct { int64_t pos1, sepEndPos; int laps, sepEndLaps, sepEndVal; uint64_t samplingPos, swEnd; uint32_t epoch, eCur, ePrev; bool pristine; std::deque<uint64_t> locks; } snap;
+    struct { int64_t pos1, sepEndPos; int laps, sepEndLaps, sepEndVal; uint64_t samplingPos, swEnd; uint32_t epoch, eCur, ePrev; bool pristine; std::deque<uint64_t> locks; uint64_t dropped; } snap;
     bool queued = false, exchanged = false;
     if (spec && spec->ntargets > 0) {
         snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch; snap.eCur = h->eCur; snap.ePrev = h->ePrev; snap.sepEndPos = h->sepEndPos; snap.sepEndLaps = h->sepEndLaps; snap.sepEndVal = h->sepEndVal;
-        snap.pristine = h->pristine; snap.locks = h->locks;
+        snap.pristine = h->pristine; snap.locks = h->locks; snap.dropped = h->droppedBytes;
         uint32_t *gate = spec->gate_dev ? spec->gate_dev : h->dGate.p;
         k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, gate);
         // The host's half first (lock window, piece schedule, separators: load_pieces and its callees, nothing launched): it can
@@ -1517,7 +1521,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
             queued = true;
         }
         if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
-                       h->pristine = snap.pristine; h->locks = snap.locks; }
+                       h->pristine = snap.pristine; h->locks = snap.locks; h->droppedBytes = snap.dropped; }
     }
     if (specAsked) { if ((r = phase2b(queued))) return r; }
     HIPCHK(hipEventSynchronize(h->evP1));                           // pass 1 and its copies to the host (not what was queued after them)
@@ -1533,7 +1537,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (exchanged) ok = spec->exchange(spec->exchange_ctx, 1, nullptr, (void *) h->stream) == 1 && ok;   // ... and every other replica's
         if (ok) { if (applied) *applied = 1; }
         else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
-               h->pristine = snap.pristine; h->locks = snap.locks; }
+               h->pristine = snap.pristine; h->locks = snap.locks; h->droppedBytes = snap.dropped; }
     } else if (exchanged)
         (void) spec->exchange(spec->exchange_ctx, 1, nullptr, (void *) h->stream);   // (this replica said no in the reduction: the word is 0 everywhere; taken so that the exchange's state is the same on every rank)
     return SWSEM_OK;

@@ -189,6 +189,9 @@ int main(int argc, char **argv) {
     }
     if (params.verifyEmissions) printf("verified on the device: %llu contigs, %llu bases decoded back to their bytes\n",
                                        (unsigned long long) params.verifiedContigs, (unsigned long long) params.verifiedBases);
+    if (!params.sequentialMatching)
+        printf("rounds of %d targets%s; reference extension bytes dropped at the sliding window's end: %zu\n", params.roundSize,
+               gpus > 1 ? " per GPU" : "", enc.droppedExtensionBytes());
     printf("exact matches total: %zu\n", enc.exactMatches());
     printf("removed matches breaking gaps total: %zu\n", enc.removedGapBreakingMatchesAll);
     printf("swsMEM unmatched chars: %zu\n", enc.unmatchedChars());

@@ -375,14 +375,39 @@ void MultipleGenomeMatchingProcessor::prepareRound(uint32_t f0, uint32_t f1, Rou
 
 // ---------------------------------------------------------------- MultipleGenomeMatchingProcessor
 
-void MultipleGenomeMatchingProcessor::initMatcher(const char *refStr, size_t refStrSize, size_t basicRefLength) {
+size_t MultipleGenomeMatchingProcessor::refLengthLimitFor(size_t basicRefLength, bool *bit40) const {
     size_t refLengthLimit = (size_t) params->referenceFactor * basicRefLength;                 // MGMP.cpp:154
     refLengthLimit *= 2;                                                                       // :157-158 (RC kept in the same buffer)
-    if (refLengthLimit <= UINT32_MAX) params->enable40bitReference = false;                    // :159-160
-    else if (!params->enable40bitReference) refLengthLimit = UINT32_MAX;
+    bool b40 = params->enable40bitReference;
+    if (refLengthLimit <= UINT32_MAX) b40 = false;                                             // :159-160
+    else if (!b40) refLengthLimit = UINT32_MAX;
     else if (refLengthLimit > MGMP_Params::REFERENCE_LENGTH_LIMIT) refLengthLimit = MGMP_Params::REFERENCE_LENGTH_LIMIT;
     if (refLengthLimit > UINT32_MAX)
         refLengthLimit = UINT32_MAX + (refLengthLimit - UINT32_MAX) / params->bigReferenceCompressorRatio;   // :165-166
+    if (bit40) *bit40 = b40;
+    return refLengthLimit;
+}
+
+// MGMP_Params::roundSize == 0: the targets that may hold their lock positions together. Sized by the largest target file (an
+// upper bound of the bytes a target adds to the reference without its reverse complement; a gzip file is taken for five times
+// its size) — a round whose extensions outgrow the window anyway (reverse complements of dissimilar contigs) loses the excess
+// as the reference's workers would, and the tool reports the bytes.
+uint32_t MultipleGenomeMatchingProcessor::windowRoundSize(uint64_t window, int gpus) const {
+    uint64_t largest = 0;
+    for (uint32_t f = 1; f < filesCount; f++) {
+        struct stat st;
+        if (stat(fileNames[f].c_str(), &st) != 0) continue;
+        const std::string &n = fileNames[f];
+        const bool gz = n.size() > 3 && n.compare(n.size() - 3, 3, ".gz") == 0;
+        largest = std::max<uint64_t>(largest, (uint64_t) st.st_size * (gz ? 5 : 1));
+    }
+    uint64_t inFlight = MGMP_Params::MAX_TARGETS_IN_FLIGHT;
+    if (window && largest) inFlight = std::min<uint64_t>(inFlight, std::max<uint64_t>(1, window / (largest + 1)));
+    return (uint32_t) std::max<uint64_t>(1, inFlight / (uint64_t) std::max(1, gpus));
+}
+
+void MultipleGenomeMatchingProcessor::initMatcher(const char *refStr, size_t refStrSize, size_t basicRefLength) {
+    size_t refLengthLimit = refLengthLimitFor(basicRefLength, &params->enable40bitReference);
     if (refLengthLimit < refStrSize) refLengthLimit = refStrSize;
     matcher = new SlidingWindowSparseEMMatcher(refLengthLimit, params->k, params->k1, params->k2, params->skipMargin, device);
     if (params->sequentialMatching) matcher->disableSlidingWindow();                           // :177-180
@@ -992,9 +1017,25 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
     params->emit.lazyDecompressionSupport = params->lazyDecompressionSupport;
     // the first round's files are read (and their page-locked buffer allocated) while the reference file is parsed and the
     // matcher's reference buffer and table are set up
+    const int gpus = params->exchange ? mbgc_xchg_world(params->exchange) : 1;
+    const bool autoRound = params->roundSize <= 0 && !params->sequentialMatching;
+    if (autoRound) {                                                                            // a first guess from the file's size (the sequence is a little shorter): what the read-ahead starts with
+        struct stat st;
+        const uint64_t g0 = stat(fileNames[0].c_str(), &st) == 0 ? (uint64_t) st.st_size : 0;
+        MBGC_Params guessParams = *params;
+        if (guessParams.referenceFactor < 1) {
+            int tmp = 15 - (__builtin_clz((unsigned) filesCount) / 3);
+            guessParams.referenceFactor = 1 << (tmp < 5 ? 5 : (tmp > 12 ? 12 : tmp));
+        }
+        MBGC_Params *keep = params; params = &guessParams;
+        const size_t lim = refLengthLimitFor(std::max<size_t>(g0, MGMP_Params::MIN_BASIC_BLOCK_SIZE), nullptr);
+        params = keep;
+        params->roundSize = (int) windowRoundSize(params->circularReference ? lim / (size_t) params->referenceSlidingWindowFactor : 0, gpus);
+    }
     if (!params->sequentialMatching && !params->exchange)
         startReadAhead(1, std::min<uint32_t>(filesCount, 1 + (uint32_t) std::max(1, params->roundSize)), 1, readBesideUpload());
     loadG0Ref(fileNames[0]);
+    if (autoRound) params->roundSize = (int) windowRoundSize(matcher->getSlidingWindowSize(), gpus);   // (the window as the matcher has it)
     params->emit.enable40bitReference = params->enable40bitReference;
     if (params->lazyDecompressionSupport) refExtLoadedPosArr.emplace_back(matcher->getLoadingPosition());   // ENC.cpp:789-791
     performMatching();

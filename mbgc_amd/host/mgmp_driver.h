@@ -31,7 +31,13 @@ struct MGMP_Params {                                   // matching/MGMP_Params.h
     int unmatchedFractionRCFactor = 8;                 // :73 (128 in -m2/-m3)
     bool rcInReference = true;                         // !isRCinReferenceDisabled(), :82-84
     bool sequentialMatching = false;                   // :218
-    int roundSize = 8;                                 // targets per round (the deterministic stand-in for matcherWorkingThreads, :22)
+    // Targets per round and GPU: the targets of a round hold their lock positions together (the deterministic stand-in for the
+    // reference's worker threads, :16-22). 0 = as many as the reference's own rules let be in flight: what they load must fit the
+    // sliding window once the buffer has wrapped (their shared lock stands one window ahead of the loading position and loadRef
+    // drops what goes beyond it, SlidingWindowSparseEMMatcher.cpp:361-378,412-417,433), and at most matcherWorkingThreads x
+    // allowedTargetsOutrunFactor = 64 targets run ahead of the finalizer (MGMP.cpp:374-375,532, :16,:57) — divided by the GPUs.
+    int roundSize = 0;
+    static constexpr int MAX_TARGETS_IN_FLIGHT = 64;
     bool uppercaseDNA = false;                         // :196 (-U)
     // mbgc-hip c --bench: every round's contigs are put into HBM first, the rounds after `benchWarmup` are timed and the
     // emitted streams stay packed in HBM (what bench.py measures, from the C++ host)
@@ -92,6 +98,8 @@ protected:
 
     void loadG0Ref(const std::string &refName);                                        // MGMP.cpp:66-150
     void initMatcher(const char *refStr, size_t refStrSize, size_t basicRefLength);     // :152-192
+    size_t refLengthLimitFor(size_t basicRefLength, bool *bit40) const;                 // :154-168
+    uint32_t windowRoundSize(uint64_t window, int gpus) const;                          // MGMP_Params::roundSize == 0
     void performMatching();                                                             // :568-606
     void processTargetsWithParallelIO();                                                // :232-313  (-t1)
     void processTargetsRounds();                                                        // :340-468 as deterministic rounds
@@ -194,5 +202,6 @@ public:
     // with the caller's leaf coders; what CompressionJob::writeCompressedCollectiveParallel would write for them
     std::string compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale = 1);
     size_t exactMatches() const { return resCount; }
+    size_t droppedExtensionBytes() const { return matcher ? matcher->getDroppedBytes() : 0; }
     size_t unmatchedChars() const { return unmatchedCharsAll; }
 };

@@ -22,6 +22,8 @@ void SlidingWindowSparseEMMatcher::disableSlidingWindow() { swsem_disable_slidin
 void SlidingWindowSparseEMMatcher::disableCircularBuffer() { swsem_disable_circular_buffer(h); }
 void SlidingWindowSparseEMMatcher::setSlidingWindowSize(uint8_t factor) { swsem_set_sliding_window_size(h, factor); }
 size_t SlidingWindowSparseEMMatcher::getMaxRefLength() const { return swsem_get_max_ref_length(h); }
+size_t SlidingWindowSparseEMMatcher::getSlidingWindowSize() const { return swsem_get_sliding_window_size(h); }
+size_t SlidingWindowSparseEMMatcher::getDroppedBytes() const { return swsem_get_dropped_bytes(h); }
 size_t SlidingWindowSparseEMMatcher::getRefLength() const { return swsem_get_ref_length(h); }
 size_t SlidingWindowSparseEMMatcher::getLoadingPosition() const { return swsem_get_loading_position(h); }
 size_t SlidingWindowSparseEMMatcher::getLoadedRefLength() const { return swsem_get_loaded_ref_length(h); }

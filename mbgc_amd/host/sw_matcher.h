@@ -15,6 +15,7 @@
 
 #include "../../include/mbgc_swsem.h"
 
+#ifndef MBGC_HIP_USE_REFERENCE_TEXTMATCH   // (a build inside the reference's tree brings its own matching/TextMatchers.h: oracle/dropin)
 namespace PgTools {
 
 struct TextMatch {                      // TextMatchers.h:9-16
@@ -27,6 +28,7 @@ struct TextMatch {                      // TextMatchers.h:9-16
 };
 
 }  // namespace PgTools
+#endif
 
 struct EmittedStreams {                 // the six byte streams of one processMatches call + its counters
     std::string s[SWSEM_NSTREAMS];
@@ -49,6 +51,8 @@ public:
     void loadRef(const char *refText, size_t refLength, bool loadRCRef, bool addRegionSeparators, char regionSeparator);   // .h:99
     void loadSeparator(char regionSeparator);                               // .h:102
     size_t getMaxRefLength() const;                                         // .h:105
+    size_t getSlidingWindowSize() const;                                    // swSize, .h:47 (0: no window)
+    size_t getDroppedBytes() const;                                         // extension bytes given up at the window's end so far (.cpp:433)
     size_t getRefLength() const;                                            // .h:106
     size_t getLoadingPosition() const;                                      // .h:107
     size_t getLoadedRefLength() const;                                      // .h:108

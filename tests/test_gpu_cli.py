@@ -276,6 +276,35 @@ def test_a_wrapping_buffer_equals_the_oracle_loop(tmp_path, rs):
     o.close()
 
 
+def test_rounds_sized_by_the_sliding_window_drop_nothing(tmp_path):
+    """without -R the host sizes its rounds by the reference's own rules for targets in flight (the sliding window, at most 64:
+    MGMP_Params::roundSize): 200 kbp genomes against a 16 MiB buffer (--ref-factor 4, window 1 MiB) make rounds of 5, the
+    buffer wraps, no extension byte is dropped and the streams equal the oracle-driven loop with that round size; rounds of 8
+    lose bytes at the window's end (SlidingWindowSparseEMMatcher.cpp:412-417,433) and the tool says how many"""
+    base = synth.base_codes(200_000, 73)
+    gs = [synth.genome(base, i, 0.004) for i in range(100)]
+    paths = []
+    for i, g in enumerate(gs):
+        p = tmp_path / ("g%03d.fa" % i)
+        p.write_bytes(synth.fasta_bytes(g, i))
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    out = run_tool(["c", "--ref-factor", "4", "list.txt", "out"], str(tmp_path))
+    assert "rounds of 5 targets; reference extension bytes dropped at the sliding window's end: 0" in out, out
+    lim = 4 * 2 * (1 << 21)
+    o = _orc.OracleMatcher(lim)
+    res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], 5)
+    assert o.loaded_ref_length() > lim                       # (it wrapped)
+    got = {k: (tmp_path / ("out." + k)).read_bytes() for k in ("literals", "mapOff", "mapLen", "gapDelta", "flags", "locksPos", "refExtSize")}
+    assert got["literals"] == gs[0].tobytes() + b"\xa2" + res["streams"]["literals"]
+    for k in ("mapOff", "mapLen", "gapDelta", "flags"):
+        assert got[k] == res["streams"][k], k
+    assert got["locksPos"] == res["locks"] and got["refExtSize"] == res["refExtSize"]
+    out8 = run_tool(["c", "--ref-factor", "4", "-R", "8", "list.txt", "out8"], str(tmp_path))
+    dropped = int([x for x in out8.splitlines() if x.startswith("rounds of 8 targets")][0].rsplit(":", 1)[1])
+    assert dropped > 1_000_000, out8
+
+
 def test_repeated_runs_write_the_same_bytes(tmp_path):
     """the host's threads (file readers, the upload + parse thread, the thread that appends the streams) and the two
     emissions in flight leave no room for timing: four runs over a buffer that wraps, with different numbers of reader

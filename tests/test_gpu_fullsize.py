@@ -75,17 +75,17 @@ def test_configs1_all_rounds_equal_oracle():
 
 
 def test_configs2_all_rounds_through_the_wrap_equal_oracle():
-    """BASELINE.json configs[2] as bench.py runs it: 1000 synthetic 5 Mbp genomes in 25 rounds of 40 against the
-    2.56e9-byte circular reference and 2^28-bucket table `mbgc c` derives for 1001 files (MGMP.cpp:130-168), THROUGH the
-    buffer's wrap near target 510 (SlidingWindowSparseEMMatcher.cpp:402-437: laps, the samplingPos = 1 restart, stale
-    table entries told by epochs, extensions clipped at the sliding window's end once 40 x 5 MB exceed its 160 MB).
+    """BASELINE.json configs[2] as bench.py runs it: 1000 synthetic 5 Mbp genomes in rounds of 31 — what the sliding window
+    (160 MB) lets be in flight, so that no extension byte is dropped — against the 2.56e9-byte circular reference and
+    2^28-bucket table `mbgc c` derives for 1001 files (MGMP.cpp:130-168), THROUGH the buffer's wrap near target 510
+    (SlidingWindowSparseEMMatcher.cpp:402-437: laps, the samplingPos = 1 restart, stale table entries told by epochs).
     Every byte of the six streams, the lock and refExtSize streams, the loading position and the final hash-table
     image against the oracle driven through the reference's target loop with the same round schedule."""
     import os
     import torch
     from mbgc_amd import binding
     from mbgc_amd.rounds import RoundRunner
-    NT, RR, MAXREF = 1000, 40, 2_560_000_000
+    NT, RR, MAXREF = 1000, 31, 2_560_000_000
     assert _driver.ref_length_limit(NT + 1, L) == (MAXREF, False)
     base = synth.base_codes(L)
     gs = synth.genomes(base, range(NT + 1), fork=False)
@@ -114,7 +114,8 @@ def test_configs2_all_rounds_through_the_wrap_equal_oracle():
         if wrapped_at is None and h.ref_length() == MAXREF:
             wrapped_at = i
     runner.flush()
-    assert wrapped_at is not None and 10 <= wrapped_at <= 14         # target ~510 of 1000: rounds on both sides of the wrap
+    assert wrapped_at is not None and 14 <= wrapped_at <= 18         # target ~510 of 1000: rounds on both sides of the wrap
+    assert h.dropped_bytes() == 0                                    # rounds of 31 x 5 000 001 bytes fit the 160 000 000-byte window
     bad = [i for i, (a, b) in enumerate(zip(got_counts, exp["matches"])) if a != b]
     assert not bad, "match counts differ first at target %d (round %d): %s" % (bad[0] + 1, bad[0] // RR, [(got_counts[i], exp["matches"][i]) for i in bad[:5]])
     for k, v in exp["streams"].items():
