@@ -192,6 +192,7 @@ int main(int argc, char **argv) {
     if (!params.sequentialMatching)
         printf("rounds of %d targets%s; reference extension bytes dropped at the sliding window's end: %zu\n", params.roundSize,
                gpus > 1 ? " per GPU" : "", enc.droppedExtensionBytes());
+    printf("final reference length: %zu\n", enc.finalReferenceLength());
     printf("exact matches total: %zu\n", enc.exactMatches());
     printf("removed matches breaking gaps total: %zu\n", enc.removedGapBreakingMatchesAll);
     printf("swsMEM unmatched chars: %zu\n", enc.unmatchedChars());

@@ -202,6 +202,7 @@ public:
     // with the caller's leaf coders; what CompressionJob::writeCompressedCollectiveParallel would write for them
     std::string compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale = 1);
     size_t exactMatches() const { return resCount; }
+    size_t finalReferenceLength() const { return refFinalTotalLength; }          // writeStats' refFinalTotalLength, ENC.cpp:734-743
     size_t droppedExtensionBytes() const { return matcher ? matcher->getDroppedBytes() : 0; }
     size_t unmatchedChars() const { return unmatchedCharsAll; }
 };
