@@ -75,19 +75,33 @@ KERNEL_OF = {"resolve": "k_resolve_blocks4", "stitch": "k_stitch_pre + k_stitch 
              "insert": "k_insert_multi", "emit": "k_emit_* (13 launches)"}
 # HBM-side bytes per launch of each kernel, from the PMC passes over THIS command (profiles/pmc_summary.py writes the
 # file from rocprofv3's FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes); absent = null
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+def kernel_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for n in ("swsem_resolve4.hip", "swsem_kernels.hip", "swsem_device.h"):
+        h.update(open(os.path.join(ROOT, "mbgc_amd", "csrc", n), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(kernel_prefix, targets_per_launch):
+    """(bytes per launch, where the figure comes from): the PMC passes are a rocprofv3 run of their own over this command, so
+    the line says which commit's kernels they saw and whether the kernel sources have changed since (then: re-take them)"""
     try:
         with open(TRAFFIC_FILE) as f:
             t = json.load(f)
         k = t["kernels"][kernel_prefix]
+        src = {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "commit": t.get("collected_at_commit"),
+               "kernel_sources_changed_since": t.get("kernel_source_sha16") != kernel_source_sha()}
+        if src["kernel_sources_changed_since"]:
+            print("bench.py: %s was taken from other kernel sources than the ones built now: roofline.traffic is stale" % src["file"], file=sys.stderr)
         if t.get("targets_per_launch") != targets_per_launch:
-            return None
-        return int(k["bytes_per_launch"])
+            return None, src
+        return int(k["bytes_per_launch"]), src
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_model():
@@ -447,7 +461,7 @@ def main():
         launch_bases = R * args.length                     # bases one launch of a family processes (this rank's round)
         alg = dict(ALG_BYTES)
         ach = alg[dom] * launch_bases / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
-        traffic = measured_traffic(KERNEL_OF[dom].split()[0], R)
+        traffic, traffic_source = measured_traffic(KERNEL_OF[dom].split()[0], R * world)
         pre = [t for t, w in zip(step_ms, laps_at) if not w]
         post = [t for t, w in zip(step_ms, laps_at) if w]
         first_coll = 1 + warm * R * world
@@ -469,7 +483,7 @@ def main():
                        "hash_entries": m.hash_size(), "offsets_40bit": bit40,
                        "sharding": "file-per-GPU, all-gather of extensions" if world > 1 else "one GPU"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_GBs": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms else None,
                          "alg_bytes_per_base": round(alg[dom], 3), "avg_launch_ms": round(dom_ms, 4),
                          "whole_step_frac": round(ALG_BYTES_PER_BASE * value / world / HBM_PEAK_GBS, 5)},

@@ -4,12 +4,19 @@
 // utils/helper.h:256-272) and ContextAwareMismatchesCoder::code2mismatch (coders/ContextAwareMismatchesCoder.cpp:8-17,72-77).
 //
 // The six streams of a contig are consumed in lock-step and carry no synchronisation points (how many flag bytes an
-// extension reads depends on the flags themselves), so a contig is one sequential chain: one wave per contig, the chain's
-// values wave-uniform, the lanes sharing what can be shared — the search for the next match mark (64 literal bytes per
-// step) and every copy (plain literals, the match bytes out of the reference buffer). The contigs of a round are
-// independent (each stands against the reference as its lock position froze it) and are decoded side by side. Used as the
-// device-side check of an emission (swsem_emit_verify: what was just emitted must decode to the query, with no encoder
-// logic in the loop) and as the building block of an accelerated `mbgc d`.
+// extension reads depends on the flags themselves), so WHERE every match's bytes lie in the six streams and in the contig
+// is one sequential chain per contig — but only that: which bytes they are depends on nothing the chain computes. Two passes:
+//   k_decode_plan   one wave per contig walks the automaton without producing a byte: marks, lengths, offsets, the pairing
+//                   ring, the score automaton over the flags — every stream read through a register window (64 bytes or 64
+//                   dwords per load instead of one dependent load per byte; flags and marks as ballot masks) — and leaves one
+//                   record per match: its place in every stream and in the contig, the parameters of its two extensions;
+//   k_decode_fill   one thread per record produces the bytes: the plain literals, the left extension (written backwards), the
+//                   match copied out of the reference buffer, the right extension — dec_left_write / dec_extend_right, the
+//                   same functions the one-wave form runs, now thousands at a time;
+//   k_decode_check  (verification) the contig against the bytes it was encoded from.
+// The contigs of a round are independent (each stands against the reference as its lock position froze it) and are decoded
+// side by side. Used as the device-side check of an emission (swsem_emit_verify: what was just emitted must decode to the
+// query, with no encoder logic in the loop) and as the building block of an accelerated `mbgc d`.
 #include "swsem_device.h"
 #include "../../include/mbgc_swsem.h"
 
@@ -39,6 +46,7 @@ struct Dec {
     uint64_t destLen, destCap;
     int bad;
     int initialScore, penalty, bonus, threshold;
+    bool solo;                                            // one THREAD runs this automaton (k_decode_fill): every lane stores its own bytes
 };
 
 __device__ __forceinline__ int dec_sym5(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1; }
@@ -59,7 +67,7 @@ __device__ __forceinline__ uint8_t dec_flag_at(Dec &d, uint64_t i) { if (i >= d.
 __device__ __forceinline__ uint8_t dec_ref_at(Dec &d, int64_t i) { if (i < 0) { d.bad = 1; return 0; } return d.ref[i]; }
 __device__ __forceinline__ void dec_push(Dec &d, uint8_t c) {
     if (d.destLen >= d.destCap) { d.bad = 1; return; }
-    if ((threadIdx.x & (WAVE - 1)) == 0) d.dest[d.destLen] = c;
+    if (d.solo || (threadIdx.x & (WAVE - 1)) == 0) d.dest[d.destLen] = c;
     d.destLen++;
 }
 // all lanes copy; source and destination never overlap (the reference buffer / the literal stream -> the contig)
@@ -103,7 +111,7 @@ __device__ uint64_t dec_extend_right(Dec &d, int64_t offsetDelta, bool isGap, bo
 // plain literals that follow its codes in the literal stream; here its length and the number of literal codes it will take
 // are found first (the same walk, nothing consumed or written), which fixes its place in the contig, then the same walk
 // writes every byte to dest[at + len - 1 - k].
-struct LeftExt { int64_t srcMatch, srcGuard; uint64_t len, codes; };
+struct LeftExt { int64_t srcMatch, srcGuard; uint64_t len, codes; };   // (codes = literal bytes the extension takes)
 __device__ LeftExt dec_left_measure(Dec &d, uint64_t *matchSrcPos, bool skipOffset, uint64_t refLockPos, uint64_t markPos) {
     LeftExt e; e.len = 0; e.codes = 0;
     int64_t srcMatch = (int64_t) *matchSrcPos;
@@ -153,7 +161,7 @@ __device__ LeftExt dec_left_measure(Dec &d, uint64_t *matchSrcPos, bool skipOffs
 }
 __device__ void dec_left_write(Dec &d, const LeftExt &e, uint64_t at, uint64_t markPos) {
     if (at + e.len > d.destCap) { d.bad = 1; return; }
-    const bool l0 = (threadIdx.x & (WAVE - 1)) == 0;
+    const bool l0 = d.solo || (threadIdx.x & (WAVE - 1)) == 0;
     uint64_t k = 0;
     int64_t src = e.srcMatch - 1;
     {
@@ -193,23 +201,184 @@ __device__ uint32_t dec_next_len(Dec &d, bool frugal) {
     return lo;
 }
 
-// decodeSequenceAndReturnUnmatchedChars, :319-432: one wave per contig
-__global__ void __launch_bounds__(WAVE) k_decode_contigs(const uint8_t *__restrict__ ref, swsem_emit_params_t p, const DecodeJob *__restrict__ jobs,
-                                                         DecodeOut *__restrict__ outs) {
+// ------------------------------------------------------------------------------------------------------------------
+// pass 1: the plan — decodeSequenceAndReturnUnmatchedChars (:319-432) with extendMatchLeft / extendMatchRight walked for
+// their lengths only. One wave per contig, every value wave-uniform.
+// ------------------------------------------------------------------------------------------------------------------
+struct DecRec {                                           // one match as the plan leaves it: where, in every stream and in the contig
+    uint64_t litFrom;                                     // literal stream at the top of the iteration: the left extension's codes, then the plain literals
+    uint64_t mark;                                        // the match's mark (the tail record: the end of the stream)
+    uint64_t destAt;                                      // contig position at the top of the iteration
+    uint64_t src;                                         // matchSrcPos (after the left extension's adjustment, :462-523)
+    int64_t leftSrcMatch, leftSrcGuard;                   // the left extension's walk (dec_left_write)
+    uint64_t flLeft, flRight;                             // flag stream: where the two extensions' walks start
+    int64_t offsetDelta;                                  // the right extension's source relative to the contig position (:434-460)
+    uint64_t guardLit;                                    // ... and the literal position it must not pass
+    uint32_t len, leftLen, leftCodes, rightLen;
+    uint32_t flags, pad;
+};
+enum { REC_GAP = 1, REC_GAP_START = 2, REC_GAP_MIDDLE = 4, REC_GAP_END = 8, REC_TAIL = 16, REC_RIGHT = 32 };
+struct DecPlanOut { uint64_t nrec, destLen; int64_t unmatched; uint64_t pad; };    // unmatched -1: malformed streams
+
+// 64 bytes of a stream from `base` on, as the ballot mask of one property (a match mark / a set flag); bytes past the end: clear
+struct ByteWin { const uint8_t *p; uint64_t n, base; unsigned long long mask; };
+template <bool MARKS>
+__device__ __forceinline__ void bw_load(ByteWin &w, uint64_t pos) {
+    const uint64_t i = pos + (threadIdx.x & (WAVE - 1));
+    const uint8_t b = i < w.n ? w.p[i] : (uint8_t) 0;
+    w.base = pos;
+    w.mask = __ballot(MARKS ? b == DEC_MATCH_MARK : b != 0);
+}
+// 256 bytes of a stream from `base` on, a dword per lane
+struct DwWin { const uint8_t *p; uint64_t n, base; uint32_t v; };
+__device__ __forceinline__ void dw_load(DwWin &w, uint64_t pos) {
+    const uint64_t o = pos + 4ull * (threadIdx.x & (WAVE - 1));
+    uint32_t x = 0;
+    if (o + 4 <= w.n) x = ld_u32(w.p + o);
+    else
+        for (int k = 0; k < 4; k++) if (o + k < w.n) x |= (uint32_t) w.p[o + k] << (8 * k);
+    w.v = x;
+    w.base = pos;
+}
+// `width` (1, 2 or 4) bytes at pos, little endian; the caller has checked pos + width <= n
+__device__ __forceinline__ uint32_t dw_get(DwWin &w, uint64_t pos, uint32_t width) {
+    if (pos < w.base || pos + width > w.base + 4 * WAVE) dw_load(w, pos);
+    const uint32_t rel = (uint32_t) (pos - w.base), q = rel >> 2, r = rel & 3u;
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) w.v, __builtin_amdgcn_readfirstlane((int) q));
+    const uint32_t hi = q + 1 < (uint32_t) WAVE ? (uint32_t) __builtin_amdgcn_readlane((int) w.v, __builtin_amdgcn_readfirstlane((int) (q + 1))) : 0u;
+    const uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, r);
+    return width == 4 ? x : (width == 2 ? x & 0xFFFFu : x & 0xFFu);
+}
+
+struct Plan {
+    ByteWin lit, fl;
+    DwWin len, off, off5, gap;
+    uint64_t nLit, nOff, nOff5, nLen, nGap, nFlags;
+    uint64_t litPos, offPos, off5Pos, lenPos, gapPos, flPos;
+    uint64_t destLen, destCap;
+    int bad;
+    int initialScore, penalty, bonus, threshold;
+};
+__device__ __forceinline__ bool plan_flag_at(Plan &d, uint64_t i) {
+    if (i >= d.nFlags) { d.bad = 1; return false; }
+    if (i - d.fl.base >= (uint64_t) WAVE) bw_load<false>(d.fl, i);
+    return (d.fl.mask >> (i - d.fl.base)) & 1ull;
+}
+__device__ __forceinline__ void plan_lit_skip(Plan &d) { if (d.litPos >= d.nLit) d.bad = 1; else d.litPos++; }
+__device__ __forceinline__ void plan_grow(Plan &d, uint64_t n) { if (d.destLen + n > d.destCap) d.bad = 1; else d.destLen += n; }
+__device__ uint64_t plan_find_mark(Plan &d, uint64_t from) {
+    while (from < d.nLit) {
+        if (from - d.lit.base >= (uint64_t) WAVE) bw_load<true>(d.lit, from);
+        const unsigned long long m = d.lit.mask >> (from - d.lit.base);
+        if (m) return from + (uint64_t) __builtin_ctzll(m);
+        from = d.lit.base + WAVE;
+    }
+    return DEC_NPOS;
+}
+// extendMatchRight, :434-460, for its length
+__device__ uint64_t plan_extend_right(Plan &d, bool isGap, bool gapStart, bool gapMiddle, bool gapEnd, uint64_t guardLitPos) {
+    if (d.litPos == guardLitPos && !gapMiddle) return 0;
+    uint64_t n = 0;
+    if (gapStart || !isGap) { plan_lit_skip(d); n++; }
+    int score = d.initialScore;
+    while (!d.bad && (!gapEnd || d.litPos != guardLitPos) && (isGap || score < d.threshold)) {
+        const bool mismatch = plan_flag_at(d, d.flPos++);
+        if (mismatch && d.litPos == guardLitPos) break;
+        if (mismatch) { score += d.penalty; plan_lit_skip(d); }
+        else { score -= d.bonus; if (score < 0) score = 0; }
+        n++;
+    }
+    plan_grow(d, n);
+    return n;
+}
+// extendMatchLeft, :462-523, for its length, the literal codes it takes and the flag position behind it (dec_left_measure with
+// the flags read through the window)
+__device__ LeftExt plan_left_measure(Plan &d, uint64_t *matchSrcPos, bool skipOffset, uint64_t refLockPos, uint64_t markPos, uint64_t *flEnd) {
+    LeftExt e; e.len = 0; e.codes = 0;
+    *flEnd = d.flPos;
+    int64_t srcMatch = (int64_t) *matchSrcPos;
+    int64_t srcGuard = srcMatch - DEC_MAX_EXT_LEFT;
+    if (!skipOffset) {
+        if (srcGuard < 1) srcGuard = 1;                                       // REF_SHIFT
+        const int64_t srcLock = (int64_t) refLockPos;                         // SIZE_MAX: one before the buffer, as there
+        if (srcGuard < srcLock && srcLock <= srcMatch) srcGuard = srcLock;
+    }
+    e.srcMatch = srcMatch; e.srcGuard = srcGuard;
+    if (srcGuard == srcMatch) return e;
+    if (skipOffset) {                                                         // the match position was given relative to the extension's end
+        int64_t src = srcMatch - 1;
+        uint64_t length = 0, mismatches = 0;
+        bool known = true;
+        int score = d.initialScore;
+        while (--src > srcGuard && score < d.threshold) {
+            const bool mismatch = plan_flag_at(d, d.flPos + length++);
+            if (d.bad) return e;
+            if (mismatch && d.litPos + ++mismatches == markPos) { known = false; break; }
+            if (mismatch) score += d.penalty;
+            else { score -= d.bonus; if (score < 0) score = 0; }
+        }
+        if (src == srcGuard && known) { mismatches++; length++; }
+        const uint64_t matchingChars = length - mismatches;
+        *matchSrcPos += matchingChars;
+        srcGuard += (int64_t) matchingChars;
+        srcMatch += (int64_t) matchingChars;
+        e.srcMatch = srcMatch; e.srcGuard = srcGuard;
+    }
+    if (d.litPos >= d.nLit) { d.bad = 1; return e; }
+    uint64_t len = 1, codes = 1;                                              // the first byte is always a coded mismatch
+    int64_t src = srcMatch - 1;
+    uint64_t lp = d.litPos + 1, fp = d.flPos;
+    int score = d.initialScore;
+    while (--src >= srcGuard && score < d.threshold) {
+        if ((int64_t) len >= DEC_MAX_EXT_LEFT) { d.bad = 1; return e; }
+        const bool mismatch = plan_flag_at(d, fp++);
+        if (d.bad) return e;
+        if (mismatch && lp == markPos) break;
+        if (mismatch) { score += d.penalty; if (lp >= d.nLit) { d.bad = 1; return e; } lp++; codes++; }
+        else { score -= d.bonus; if (score < 0) score = 0; }
+        len++;
+    }
+    e.len = len; e.codes = codes;
+    *flEnd = fp;
+    return e;
+}
+// one entry of the mapLen stream, decodeMapLenStream :966-986
+__device__ uint32_t plan_next_len(Plan &d, bool frugal) {
+    if (!frugal) {
+        if (d.lenPos + 4 > d.nLen) { d.bad = 1; return 0; }
+        const uint32_t v = dw_get(d.len, d.lenPos, 4); d.lenPos += 4;
+        return v;
+    }
+    if (d.lenPos + 2 > d.nLen) { d.bad = 1; return 0; }
+    const uint32_t y16 = dw_get(d.len, d.lenPos, 2); d.lenPos += 2;
+    if (y16 < 0xFFFFu) return y16;
+    if (d.lenPos + 4 > d.nLen) { d.bad = 1; return 0; }
+    const uint32_t y32 = dw_get(d.len, d.lenPos, 4); d.lenPos += 4;
+    if (y32 < 0xFFFFFFFFu) return y32;
+    if (d.lenPos + 8 > d.nLen) { d.bad = 1; return 0; }
+    const uint32_t lo = dw_get(d.len, d.lenPos, 4); d.lenPos += 8;            // readUInt64Frugal<uint32_t>: the low word
+    return lo;
+}
+
+__global__ void __launch_bounds__(WAVE) k_decode_plan(swsem_emit_params_t p, const DecodeJob *__restrict__ jobs, DecRec *__restrict__ recs,
+                                                      const uint64_t *__restrict__ recBase, DecPlanOut *__restrict__ outs) {
     __shared__ int64_t paired[DEC_MAX_GAP_DEPTH];
     const DecodeJob jb = jobs[blockIdx.x];
-    Dec d;
-    d.ref = ref;
-    d.lit = jb.stream[SWSEM_LIT]; d.nLit = jb.size[SWSEM_LIT];
-    d.off = jb.stream[SWSEM_OFF]; d.nOff = jb.size[SWSEM_OFF];
-    d.off5 = jb.stream[SWSEM_OFF5]; d.nOff5 = jb.size[SWSEM_OFF5];
-    d.len = jb.stream[SWSEM_LEN]; d.nLen = jb.size[SWSEM_LEN];
-    d.gap = jb.stream[SWSEM_GAP]; d.nGap = jb.size[SWSEM_GAP];
-    d.flags = jb.stream[SWSEM_FLAGS]; d.nFlags = jb.size[SWSEM_FLAGS];
+    DecRec *out = recs + recBase[blockIdx.x];
+    const uint64_t recCap = recBase[blockIdx.x + 1] - recBase[blockIdx.x];
+    Plan d;
+    d.lit.p = jb.stream[SWSEM_LIT]; d.lit.n = d.nLit = jb.size[SWSEM_LIT];
+    d.fl.p = jb.stream[SWSEM_FLAGS]; d.fl.n = d.nFlags = jb.size[SWSEM_FLAGS];
+    d.off.p = jb.stream[SWSEM_OFF]; d.off.n = d.nOff = jb.size[SWSEM_OFF];
+    d.off5.p = jb.stream[SWSEM_OFF5]; d.off5.n = d.nOff5 = jb.size[SWSEM_OFF5];
+    d.len.p = jb.stream[SWSEM_LEN]; d.len.n = d.nLen = jb.size[SWSEM_LEN];
+    d.gap.p = jb.stream[SWSEM_GAP]; d.gap.n = d.nGap = jb.size[SWSEM_GAP];
     d.litPos = d.offPos = d.off5Pos = d.lenPos = d.gapPos = d.flPos = 0;
-    d.dest = jb.dest; d.destLen = 0; d.destCap = jb.destCap;
+    d.destLen = 0; d.destCap = jb.destCap;
     d.bad = 0;
     d.initialScore = p.mmsMismatchesInitialScore; d.penalty = p.mmsMismatchPenalty; d.bonus = p.mmsMatchBonus; d.threshold = p.mmsMismatchesScoreThreshold;
+    bw_load<true>(d.lit, 0); bw_load<false>(d.fl, 0);
+    dw_load(d.len, 0); dw_load(d.off, 0); dw_load(d.off5, 0); dw_load(d.gap, 0);
     for (int i = threadIdx.x; i < DEC_MAX_GAP_DEPTH; i += WAVE) paired[i] = INT64_MAX;
     __builtin_amdgcn_s_waitcnt(0);
     const bool l0 = threadIdx.x == 0;
@@ -222,8 +391,12 @@ __global__ void __launch_bounds__(WAVE) k_decode_contigs(const uint8_t *__restri
     uint64_t extLeftLen = 0, extRightLen = 0;
     bool isGap = false;
     int64_t j = 0;
-    uint64_t markPos = dec_find_mark(d, d.litPos);
+    uint64_t markPos = plan_find_mark(d, d.litPos);
     while (!d.bad && markPos != DEC_NPOS && markPos < seqEnd) {
+        if ((uint64_t) j + 1 >= recCap) { d.bad = 1; break; }                 // (more marks than mapLen entries: malformed)
+        DecRec rec;
+        rec.litFrom = d.litPos; rec.mark = markPos; rec.destAt = d.destLen; rec.flLeft = d.flPos;
+        rec.leftLen = 0; rec.leftCodes = 0; rec.leftSrcMatch = 0; rec.leftSrcGuard = 0; rec.pad = 0;
         const uint64_t literalsLeft = markPos - d.litPos;
         matchSrcPos = 0;
         const int64_t pv = paired[gapCurIdx];
@@ -233,18 +406,21 @@ __global__ void __launch_bounds__(WAVE) k_decode_contigs(const uint8_t *__restri
             if (l0) paired[gapCurIdx] = INT64_MAX;
         } else {
             if (d.offPos + 4 > d.nOff) { d.bad = 1; break; }
-            matchSrcPos = ld_u32(d.off + d.offPos); d.offPos += 4;
+            matchSrcPos = dw_get(d.off, d.offPos, 4); d.offPos += 4;
             if (p.enable40bitReference) {                                     // :356-359
                 if (d.off5Pos >= d.nOff5) { d.bad = 1; break; }
-                matchSrcPos += (uint64_t) d.off5[d.off5Pos++] << 32;
+                matchSrcPos += (uint64_t) dw_get(d.off5, d.off5Pos, 1) << 32; d.off5Pos++;
             }
         }
         extLeftLen = 0;
         if (p.enableExtensionsWithMismatches) {
             if (!isGap && literalsLeft) {
-                const LeftExt e = dec_left_measure(d, &matchSrcPos, skipOffset, jb.refLockPos, markPos);
+                uint64_t flEnd = d.flPos;
+                const LeftExt e = plan_left_measure(d, &matchSrcPos, skipOffset, jb.refLockPos, markPos, &flEnd);
                 if (!d.bad && e.len) {
-                    dec_left_write(d, e, d.destLen + (literalsLeft - e.codes), markPos);    // behind the plain literals its codes leave over
+                    if (e.codes > literalsLeft) { d.bad = 1; break; }
+                    rec.leftLen = (uint32_t) e.len; rec.leftCodes = (uint32_t) e.codes; rec.leftSrcMatch = e.srcMatch; rec.leftSrcGuard = e.srcGuard;
+                    d.litPos += e.codes; d.flPos = flEnd;                     // what dec_left_write consumes
                     extLeftLen = e.len;
                 }
             }
@@ -252,20 +428,22 @@ __global__ void __launch_bounds__(WAVE) k_decode_contigs(const uint8_t *__restri
         }
         if (d.bad) break;
         const uint64_t literalLen = markPos - d.litPos + extLeftLen + extRightLen;
-        dec_append(d, d.lit + d.litPos, markPos - d.litPos);                  // the plain literals ...
-        if (d.destLen + extLeftLen > d.destCap) { d.bad = 1; break; }
-        d.destLen += extLeftLen;                                              // ... and, already in place behind them, the left extension
+        plan_grow(d, markPos - d.litPos);                                     // the plain literals ...
+        plan_grow(d, extLeftLen);                                             // ... and, behind them, the left extension
+        if (d.bad) break;
         unmatchedChars += (uint32_t) literalLen;
         d.litPos = markPos + 1;
-        const uint32_t matchLength = dec_next_len(d, p.frugal64bitLenEncoding != 0);
+        const uint32_t matchLength = plan_next_len(d, p.frugal64bitLenEncoding != 0);
         if (d.bad) break;
         prevMatchDestPos = d.destLen;
-        dec_append(d, ref + matchSrcPos, matchLength);
-        markPos = dec_find_mark(d, d.litPos);
+        plan_grow(d, matchLength);
+        if (d.bad) break;
+        rec.src = matchSrcPos; rec.len = matchLength;
+        markPos = plan_find_mark(d, d.litPos);
         uint32_t gapDelta = 0;
         if (p.gapDepthOffsetEncoding && markPos != DEC_NPOS && markPos < seqEnd) {
             if (d.gapPos >= d.nGap) { d.bad = 1; break; }
-            gapDelta = d.gap[d.gapPos++];
+            gapDelta = dw_get(d.gap, d.gapPos, 1); d.gapPos++;
         }
         if (gapDelta) {
             int gapIdx = gapCurIdx;
@@ -294,36 +472,94 @@ __global__ void __launch_bounds__(WAVE) k_decode_contigs(const uint8_t *__restri
         const bool gapMiddle = gapStartIdx < j && j + 1 < gapEndIdx;
         isGap = gapStart || gapMiddle || gapEnd;
         extRightLen = 0;
+        rec.flags = (isGap ? REC_GAP : 0) | (gapStart ? REC_GAP_START : 0) | (gapMiddle ? REC_GAP_MIDDLE : 0) | (gapEnd ? REC_GAP_END : 0);
+        rec.flRight = d.flPos; rec.offsetDelta = 0; rec.guardLit = 0; rec.rightLen = 0;
         if (p.enableExtensionsWithMismatches) {
             if (!isGap || gapStart) offsetDelta = (int64_t) matchSrcPos + (int64_t) matchLength - (int64_t) d.destLen;
-            extRightLen = dec_extend_right(d, offsetDelta, isGap, gapStart, gapMiddle, gapEnd,
-                                           markPos != DEC_NPOS && markPos < seqEnd ? markPos : seqEnd);
+            const uint64_t guardLit = markPos != DEC_NPOS && markPos < seqEnd ? markPos : seqEnd;
+            rec.flags |= REC_RIGHT; rec.offsetDelta = offsetDelta; rec.guardLit = guardLit;
+            extRightLen = plan_extend_right(d, isGap, gapStart, gapMiddle, gapEnd, guardLit);
+            rec.rightLen = (uint32_t) extRightLen;
         }
+        if (l0) out[j] = rec;
         j++;
     }
-    if (!d.bad) {
+    if (!d.bad) {                                                             // the literals behind the last match
         const uint64_t literalLen = seqEnd - d.litPos + extRightLen;
-        dec_append(d, d.lit + d.litPos, seqEnd - d.litPos);
+        DecRec rec = {};
+        rec.litFrom = d.litPos; rec.mark = seqEnd; rec.destAt = d.destLen; rec.flags = REC_TAIL;
+        plan_grow(d, seqEnd - d.litPos);
         unmatchedChars += (uint32_t) literalLen;
         d.litPos = seqEnd;
+        if (l0 && !d.bad) out[j] = rec;
+        j++;
     }
     if (!d.bad && (d.offPos != d.nOff || d.off5Pos != d.nOff5 || d.lenPos != d.nLen || d.gapPos != d.nGap || d.flPos != d.nFlags)) d.bad = 1;
-    // the device-side check: the contig the streams gave back against the one that was encoded
-    uint64_t firstDiff = DEC_NPOS;
-    if (jb.expect && !d.bad) {
-        __builtin_amdgcn_s_waitcnt(0);
-        const uint64_t lane = threadIdx.x;
-        for (uint64_t base = 0; base < d.destLen; base += WAVE) {
-            const uint64_t i = base + lane;
-            const unsigned long long m = __ballot(i < d.destLen && d.dest[i] != jb.expect[i]);
-            if (m) { firstDiff = base + (uint64_t) __builtin_ctzll(m); break; }
-        }
-    }
     if (l0) {
-        DecodeOut o;
-        o.destLen = d.destLen; o.unmatched = d.bad ? -1 : (int64_t) unmatchedChars; o.firstDiff = firstDiff;
+        DecPlanOut o;
+        o.nrec = d.bad ? 0 : (uint64_t) j; o.destLen = d.destLen; o.unmatched = d.bad ? -1 : (int64_t) unmatchedChars; o.pad = 0;
         outs[blockIdx.x] = o;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pass 2: the bytes — one thread per record
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_decode_fill(const uint8_t *__restrict__ ref, swsem_emit_params_t p, const DecodeJob *__restrict__ jobs,
+                                                     const DecRec *__restrict__ recs, const uint64_t *__restrict__ recBase,
+                                                     const DecPlanOut *__restrict__ plans, uint32_t *__restrict__ badFlags) {
+    const uint32_t c = blockIdx.y;
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (plans[c].unmatched < 0 || i >= plans[c].nrec) return;
+    const DecRec r = recs[recBase[c] + i];
+    const DecodeJob &jb = jobs[c];
+    Dec d;
+    d.ref = ref; d.solo = true;
+    d.lit = jb.stream[SWSEM_LIT]; d.nLit = jb.size[SWSEM_LIT];
+    d.flags = jb.stream[SWSEM_FLAGS]; d.nFlags = jb.size[SWSEM_FLAGS];
+    d.off = nullptr; d.off5 = nullptr; d.len = nullptr; d.gap = nullptr; d.nOff = d.nOff5 = d.nLen = d.nGap = 0;
+    d.litPos = r.litFrom; d.flPos = r.flLeft; d.offPos = d.off5Pos = d.lenPos = d.gapPos = 0;
+    d.dest = jb.dest; d.destLen = r.destAt; d.destCap = jb.destCap;
+    d.bad = 0;
+    d.initialScore = p.mmsMismatchesInitialScore; d.penalty = p.mmsMismatchPenalty; d.bonus = p.mmsMatchBonus; d.threshold = p.mmsMismatchesScoreThreshold;
+    const uint64_t plain = (r.mark - r.litFrom) - r.leftCodes;
+    if (r.leftLen) {                                                          // (its codes come first in the literal stream, its bytes behind the plain literals)
+        LeftExt e; e.srcMatch = r.leftSrcMatch; e.srcGuard = r.leftSrcGuard; e.len = r.leftLen; e.codes = r.leftCodes;
+        dec_left_write(d, e, r.destAt + plain, r.mark);
+    }
+    {
+        const uint8_t *s = d.lit + r.litFrom + r.leftCodes;
+        uint8_t *t = d.dest + r.destAt;
+        for (uint64_t k = 0; k < plain; k++) t[k] = s[k];
+    }
+    if (!(r.flags & REC_TAIL)) {
+        const uint64_t at = r.destAt + plain + r.leftLen;
+        const uint8_t *s = ref + r.src;
+        uint8_t *t = d.dest + at;
+        uint64_t k = 0;
+        for (; k + 16 <= r.len; k += 16) { const uint4 x = ld_u128(s + k); __builtin_memcpy(t + k, &x, 16); }
+        for (; k < r.len; k++) t[k] = s[k];
+        if (r.flags & REC_RIGHT) {
+            d.litPos = r.mark + 1; d.flPos = r.flRight; d.destLen = at + r.len;
+            const uint64_t n = dec_extend_right(d, r.offsetDelta, (r.flags & REC_GAP) != 0, (r.flags & REC_GAP_START) != 0, (r.flags & REC_GAP_MIDDLE) != 0,
+                                                (r.flags & REC_GAP_END) != 0, r.guardLit);
+            if (n != r.rightLen) d.bad = 1;
+        }
+    }
+    if (d.bad) atomicOr(&badFlags[c], 1u);
+}
+
+// the contig the streams gave back against the one that was encoded: first differing byte per contig (DEC_NPOS: equal)
+__global__ void __launch_bounds__(256) k_decode_check(const DecodeJob *__restrict__ jobs, const DecPlanOut *__restrict__ plans, unsigned long long *__restrict__ firstDiff) {
+    const uint32_t c = blockIdx.y;
+    const DecodeJob &jb = jobs[c];
+    if (!jb.expect || plans[c].unmatched < 0) return;
+    const uint64_t n = plans[c].destLen;
+    const uint64_t i0 = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i0 >= n) return;
+    const uint64_t i1 = i0 + 16 < n ? i0 + 16 : n;
+    for (uint64_t i = i0; i < i1; i++)
+        if (jb.dest[i] != jb.expect[i]) { atomicMin(&firstDiff[c], (unsigned long long) i); break; }
 }
 
 }  // namespace swk
