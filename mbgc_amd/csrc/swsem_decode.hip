@@ -47,6 +47,7 @@ struct Dec {
     int bad;
     int initialScore, penalty, bonus, threshold;
     bool solo;                                            // one THREAD runs this automaton (k_decode_fill): every lane stores its own bytes
+    uint64_t refBytes;                                    // size of the reference buffer: no stream, however malformed, sends a read beyond it
 };
 
 __device__ __forceinline__ int dec_sym5(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1; }
@@ -64,30 +65,12 @@ __device__ uint8_t dec_code2mismatch(Dec &d, uint8_t actual, uint8_t code) {
 }
 __device__ __forceinline__ uint8_t dec_lit_next(Dec &d) { if (d.litPos >= d.nLit) { d.bad = 1; return 0; } return d.lit[d.litPos++]; }
 __device__ __forceinline__ uint8_t dec_flag_at(Dec &d, uint64_t i) { if (i >= d.nFlags) { d.bad = 1; return 0; } return d.flags[i]; }
-__device__ __forceinline__ uint8_t dec_ref_at(Dec &d, int64_t i) { if (i < 0) { d.bad = 1; return 0; } return d.ref[i]; }
+__device__ __forceinline__ uint8_t dec_ref_at(Dec &d, int64_t i) { if (i < 0 || (uint64_t) i >= d.refBytes) { d.bad = 1; return 0; } return d.ref[i]; }
 __device__ __forceinline__ void dec_push(Dec &d, uint8_t c) {
     if (d.destLen >= d.destCap) { d.bad = 1; return; }
     if (d.solo || (threadIdx.x & (WAVE - 1)) == 0) d.dest[d.destLen] = c;
     d.destLen++;
 }
-// all lanes copy; source and destination never overlap (the reference buffer / the literal stream -> the contig)
-__device__ void dec_append(Dec &d, const uint8_t *s, uint64_t n) {
-    if (d.destLen + n > d.destCap) { d.bad = 1; return; }
-    uint8_t *t = d.dest + d.destLen;
-    for (uint64_t i = threadIdx.x & (WAVE - 1); i < n; i += WAVE) t[i] = s[i];
-    d.destLen += n;
-}
-// memchr(lit + from, MATCH_MARK, nLit - from), 64 bytes per step
-__device__ uint64_t dec_find_mark(const Dec &d, uint64_t from) {
-    const uint64_t lane = threadIdx.x & (WAVE - 1);
-    for (uint64_t base = from; base < d.nLit; base += WAVE) {
-        const uint64_t i = base + lane;
-        const unsigned long long m = __ballot(i < d.nLit && d.lit[i] == DEC_MATCH_MARK);
-        if (m) return base + (uint64_t) __builtin_ctzll(m);
-    }
-    return DEC_NPOS;
-}
-
 // extendMatchRight, :434-460
 __device__ uint64_t dec_extend_right(Dec &d, int64_t offsetDelta, bool isGap, bool gapStart, bool gapMiddle, bool gapEnd, uint64_t guardLitPos) {
     if (d.litPos == guardLitPos && !gapMiddle) return 0;
@@ -109,56 +92,9 @@ __device__ uint64_t dec_extend_right(Dec &d, int64_t offsetDelta, bool isGap, bo
 
 // extendMatchLeft, :462-523. The reference writes the extension backwards into a scratch buffer and appends it behind the
 // plain literals that follow its codes in the literal stream; here its length and the number of literal codes it will take
-// are found first (the same walk, nothing consumed or written), which fixes its place in the contig, then the same walk
-// writes every byte to dest[at + len - 1 - k].
+// are found first (plan_left_measure: the same walk, nothing written), which fixes its place in the contig, then the same
+// walk writes every byte to dest[at + len - 1 - k].
 struct LeftExt { int64_t srcMatch, srcGuard; uint64_t len, codes; };   // (codes = literal bytes the extension takes)
-__device__ LeftExt dec_left_measure(Dec &d, uint64_t *matchSrcPos, bool skipOffset, uint64_t refLockPos, uint64_t markPos) {
-    LeftExt e; e.len = 0; e.codes = 0;
-    int64_t srcMatch = (int64_t) *matchSrcPos;
-    int64_t srcGuard = srcMatch - DEC_MAX_EXT_LEFT;
-    if (!skipOffset) {
-        if (srcGuard < 1) srcGuard = 1;                                       // REF_SHIFT
-        const int64_t srcLock = (int64_t) refLockPos;                         // SIZE_MAX: one before the buffer, as there
-        if (srcGuard < srcLock && srcLock <= srcMatch) srcGuard = srcLock;
-    }
-    e.srcMatch = srcMatch; e.srcGuard = srcGuard;
-    if (srcGuard == srcMatch) return e;
-    if (skipOffset) {                                                         // the match position was given relative to the extension's end
-        int64_t src = srcMatch - 1;
-        uint64_t length = 0, mismatches = 0;
-        bool known = true;
-        int score = d.initialScore;
-        while (--src > srcGuard && score < d.threshold) {
-            const bool mismatch = dec_flag_at(d, d.flPos + length++) != 0;
-            if (d.bad) return e;
-            if (mismatch && d.litPos + ++mismatches == markPos) { known = false; break; }
-            if (mismatch) score += d.penalty;
-            else { score -= d.bonus; if (score < 0) score = 0; }
-        }
-        if (src == srcGuard && known) { mismatches++; length++; }
-        const uint64_t matchingChars = length - mismatches;
-        *matchSrcPos += matchingChars;
-        srcGuard += (int64_t) matchingChars;
-        srcMatch += (int64_t) matchingChars;
-        e.srcMatch = srcMatch; e.srcGuard = srcGuard;
-    }
-    if (d.litPos >= d.nLit) { d.bad = 1; return e; }
-    uint64_t len = 1, codes = 1;                                              // the first byte is always a coded mismatch
-    int64_t src = srcMatch - 1;
-    uint64_t lp = d.litPos + 1, fp = d.flPos;
-    int score = d.initialScore;
-    while (--src >= srcGuard && score < d.threshold) {
-        if ((int64_t) len >= DEC_MAX_EXT_LEFT) { d.bad = 1; return e; }
-        if (fp >= d.nFlags) { d.bad = 1; return e; }
-        const bool mismatch = d.flags[fp++] != 0;
-        if (mismatch && lp == markPos) break;
-        if (mismatch) { score += d.penalty; if (lp >= d.nLit) { d.bad = 1; return e; } lp++; codes++; }
-        else { score -= d.bonus; if (score < 0) score = 0; }
-        len++;
-    }
-    e.len = len; e.codes = codes;
-    return e;
-}
 __device__ void dec_left_write(Dec &d, const LeftExt &e, uint64_t at, uint64_t markPos) {
     if (at + e.len > d.destCap) { d.bad = 1; return; }
     const bool l0 = d.solo || (threadIdx.x & (WAVE - 1)) == 0;
@@ -183,24 +119,6 @@ __device__ void dec_left_write(Dec &d, const LeftExt &e, uint64_t at, uint64_t m
     if (k != e.len) d.bad = 1;
 }
 
-// one entry of the mapLen stream, decodeMapLenStream :966-986
-__device__ uint32_t dec_next_len(Dec &d, bool frugal) {
-    if (!frugal) {
-        if (d.lenPos + 4 > d.nLen) { d.bad = 1; return 0; }
-        const uint32_t v = ld_u32(d.len + d.lenPos); d.lenPos += 4;
-        return v;
-    }
-    if (d.lenPos + 2 > d.nLen) { d.bad = 1; return 0; }
-    const uint32_t y16 = (uint32_t) d.len[d.lenPos] | ((uint32_t) d.len[d.lenPos + 1] << 8); d.lenPos += 2;
-    if (y16 < 0xFFFFu) return y16;
-    if (d.lenPos + 4 > d.nLen) { d.bad = 1; return 0; }
-    const uint32_t y32 = ld_u32(d.len + d.lenPos); d.lenPos += 4;
-    if (y32 < 0xFFFFFFFFu) return y32;
-    if (d.lenPos + 8 > d.nLen) { d.bad = 1; return 0; }
-    const uint32_t lo = ld_u32(d.len + d.lenPos); d.lenPos += 8;             // readUInt64Frugal<uint32_t>: the low word
-    return lo;
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // pass 1: the plan — decodeSequenceAndReturnUnmatchedChars (:319-432) with extendMatchLeft / extendMatchRight walked for
 // their lengths only. One wave per contig, every value wave-uniform.
@@ -221,17 +139,17 @@ enum { REC_GAP = 1, REC_GAP_START = 2, REC_GAP_MIDDLE = 4, REC_GAP_END = 8, REC_
 struct DecPlanOut { uint64_t nrec, destLen; int64_t unmatched; uint64_t pad; };    // unmatched -1: malformed streams
 
 // 64 bytes of a stream from `base` on, as the ballot mask of one property (a match mark / a set flag); bytes past the end: clear
-struct ByteWin { const uint8_t *p; uint64_t n, base; unsigned long long mask; };
+struct DecByteWin { const uint8_t *p; uint64_t n, base; unsigned long long mask; };
 template <bool MARKS>
-__device__ __forceinline__ void bw_load(ByteWin &w, uint64_t pos) {
+__device__ __forceinline__ void bw_load(DecByteWin &w, uint64_t pos) {
     const uint64_t i = pos + (threadIdx.x & (WAVE - 1));
     const uint8_t b = i < w.n ? w.p[i] : (uint8_t) 0;
     w.base = pos;
     w.mask = __ballot(MARKS ? b == DEC_MATCH_MARK : b != 0);
 }
 // 256 bytes of a stream from `base` on, a dword per lane
-struct DwWin { const uint8_t *p; uint64_t n, base; uint32_t v; };
-__device__ __forceinline__ void dw_load(DwWin &w, uint64_t pos) {
+struct DecDwWin { const uint8_t *p; uint64_t n, base; uint32_t v; };
+__device__ __forceinline__ void dw_load(DecDwWin &w, uint64_t pos) {
     const uint64_t o = pos + 4ull * (threadIdx.x & (WAVE - 1));
     uint32_t x = 0;
     if (o + 4 <= w.n) x = ld_u32(w.p + o);
@@ -241,7 +159,7 @@ __device__ __forceinline__ void dw_load(DwWin &w, uint64_t pos) {
     w.base = pos;
 }
 // `width` (1, 2 or 4) bytes at pos, little endian; the caller has checked pos + width <= n
-__device__ __forceinline__ uint32_t dw_get(DwWin &w, uint64_t pos, uint32_t width) {
+__device__ __forceinline__ uint32_t dw_get(DecDwWin &w, uint64_t pos, uint32_t width) {
     if (pos < w.base || pos + width > w.base + 4 * WAVE) dw_load(w, pos);
     const uint32_t rel = (uint32_t) (pos - w.base), q = rel >> 2, r = rel & 3u;
     const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) w.v, __builtin_amdgcn_readfirstlane((int) q));
@@ -251,8 +169,8 @@ __device__ __forceinline__ uint32_t dw_get(DwWin &w, uint64_t pos, uint32_t widt
 }
 
 struct Plan {
-    ByteWin lit, fl;
-    DwWin len, off, off5, gap;
+    DecByteWin lit, fl;
+    DecDwWin len, off, off5, gap;
     uint64_t nLit, nOff, nOff5, nLen, nGap, nFlags;
     uint64_t litPos, offPos, off5Pos, lenPos, gapPos, flPos;
     uint64_t destLen, destCap;
@@ -361,7 +279,7 @@ __device__ uint32_t plan_next_len(Plan &d, bool frugal) {
 }
 
 __global__ void __launch_bounds__(WAVE) k_decode_plan(swsem_emit_params_t p, const DecodeJob *__restrict__ jobs, DecRec *__restrict__ recs,
-                                                      const uint64_t *__restrict__ recBase, DecPlanOut *__restrict__ outs) {
+                                                      const uint64_t *__restrict__ recBase, DecPlanOut *__restrict__ outs, uint64_t refBytes) {
     __shared__ int64_t paired[DEC_MAX_GAP_DEPTH];
     const DecodeJob jb = jobs[blockIdx.x];
     DecRec *out = recs + recBase[blockIdx.x];
@@ -437,6 +355,7 @@ __global__ void __launch_bounds__(WAVE) k_decode_plan(swsem_emit_params_t p, con
         if (d.bad) break;
         prevMatchDestPos = d.destLen;
         plan_grow(d, matchLength);
+        if (matchSrcPos > refBytes || matchLength > refBytes - matchSrcPos) d.bad = 1;   // (a match outside the reference buffer: malformed)
         if (d.bad) break;
         rec.src = matchSrcPos; rec.len = matchLength;
         markPos = plan_find_mark(d, d.litPos);
@@ -507,14 +426,14 @@ __global__ void __launch_bounds__(WAVE) k_decode_plan(swsem_emit_params_t p, con
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_decode_fill(const uint8_t *__restrict__ ref, swsem_emit_params_t p, const DecodeJob *__restrict__ jobs,
                                                      const DecRec *__restrict__ recs, const uint64_t *__restrict__ recBase,
-                                                     const DecPlanOut *__restrict__ plans, uint32_t *__restrict__ badFlags) {
+                                                     const DecPlanOut *__restrict__ plans, uint32_t *__restrict__ badFlags, uint64_t refBytes) {
     const uint32_t c = blockIdx.y;
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (plans[c].unmatched < 0 || i >= plans[c].nrec) return;
     const DecRec r = recs[recBase[c] + i];
     const DecodeJob &jb = jobs[c];
     Dec d;
-    d.ref = ref; d.solo = true;
+    d.ref = ref; d.solo = true; d.refBytes = refBytes;
     d.lit = jb.stream[SWSEM_LIT]; d.nLit = jb.size[SWSEM_LIT];
     d.flags = jb.stream[SWSEM_FLAGS]; d.nFlags = jb.size[SWSEM_FLAGS];
     d.off = nullptr; d.off5 = nullptr; d.len = nullptr; d.gap = nullptr; d.nOff = d.nOff5 = d.nLen = d.nGap = 0;

@@ -127,7 +127,9 @@ struct swsem {
     DevBuf<unsigned long long> dStats;
     DevBuf<uint8_t> dDecode;                 // contigs given back by the device decoder (swsem_emit_verify)
     DevBuf<DecodeJob> dJobs;
-    DevBuf<DecodeOut> dDecOut;
+    DevBuf<DecRec> dDecRecs;                 // the plan pass's records, contig after contig (swsem_decode.hip)
+    DevBuf<DecPlanOut> dDecPlan;
+    DevBuf<uint64_t> dDecAux;                // per contig: record base (n + 1), first differing byte (n), malformed flag (n, as u32 pairs)
     // --- emission: two slots, so that the second phase of one batch can still be running while the next is begun
     struct EmitSlot {
         DevBuf<EmitContig> dECg;
@@ -1002,7 +1004,7 @@ void swsem_destroy(swsem_t *h) {
     h->stage.release(); h->dContigs.release(); 
     h->dMatchCount.release(); h->dMatches.release(); h->dStats.release();
     h->dRegions.release(); h->dReplay.release(); h->dRecs.release(); h->dFast.release(); h->dSegStart.release(); h->dKeepN.release(); h->dDstOff.release();
-    h->dPrev.release(); h->dRbContig.release(); h->dRbOrder.release(); h->dDecode.release(); h->dJobs.release(); h->dDecOut.release();
+    h->dPrev.release(); h->dRbContig.release(); h->dRbOrder.release(); h->dDecode.release(); h->dJobs.release(); h->dDecRecs.release(); h->dDecPlan.release(); h->dDecAux.release();
     for (auto &E : h->slot) E.release();
     h->dTables.release(); h->dGate.release(); h->dPred.release();
     if (h->pin) { (void) hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
@@ -1652,13 +1654,42 @@ int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
 // ---- the decoder's automaton on the device (swsem_decode.hip)
 static int decode_jobs(swsem_t *h, const swsem_emit_params_t *p, int n, const std::vector<DecodeJob> &jobs, std::vector<DecodeOut> &outs) {
     int r;
-    if ((r = h->dJobs.reserve(n)) || (r = h->dDecOut.reserve(n))) return r;
+    // records a contig can need: one per mapLen entry (two bytes at least, four without the frugal encoding) + the tail
+    std::vector<uint64_t> aux(3 * (size_t) n + 1, 0);
+    uint64_t *recBase = aux.data(), *firstDiff = recBase + n + 1;
+    uint32_t *badFlags = (uint32_t *) (firstDiff + n);
+    for (int k = 0; k < n; k++) {
+        recBase[k + 1] = recBase[k] + jobs[k].size[SWSEM_LEN] / (p->frugal64bitLenEncoding ? 2 : 4) + 2;
+        firstDiff[k] = UINT64_MAX;
+    }
+    if ((r = h->dJobs.reserve(n)) || (r = h->dDecPlan.reserve(n)) || (r = h->dDecAux.reserve(aux.size())) || (r = h->dDecRecs.reserve(recBase[n]))) return r;
     HIPCHK(hipMemcpyAsync(h->dJobs.p, jobs.data(), (size_t) n * sizeof(DecodeJob), hipMemcpyHostToDevice, h->stream));
-    k_decode_contigs<<<dim3(n), dim3(WAVE), 0, h->stream>>>(h->ref, *p, h->dJobs.p, h->dDecOut.p);
+    HIPCHK(hipMemcpyAsync(h->dDecAux.p, aux.data(), aux.size() * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    const uint64_t *dRecBase = h->dDecAux.p;
+    unsigned long long *dFirstDiff = (unsigned long long *) (h->dDecAux.p + n + 1);
+    uint32_t *dBad = (uint32_t *) (h->dDecAux.p + 2 * (size_t) n + 1);
+    k_decode_plan<<<dim3(n), dim3(WAVE), 0, h->stream>>>(*p, h->dJobs.p, h->dDecRecs.p, dRecBase, h->dDecPlan.p, h->maxRefLength + REF_SLACK);
     HIPCHK(hipGetLastError());
-    outs.resize(n);
-    HIPCHK(hipMemcpyAsync(outs.data(), h->dDecOut.p, (size_t) n * sizeof(DecodeOut), hipMemcpyDeviceToHost, h->stream));
+    std::vector<DecPlanOut> plans(n);
+    HIPCHK(hipMemcpyAsync(plans.data(), h->dDecPlan.p, (size_t) n * sizeof(DecPlanOut), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    uint64_t maxRec = 0, maxLen = 0;
+    bool anyExpect = false;
+    for (int k = 0; k < n; k++) {
+        if (plans[k].unmatched < 0) continue;
+        maxRec = std::max(maxRec, plans[k].nrec); maxLen = std::max(maxLen, plans[k].destLen);
+        anyExpect |= jobs[k].expect != nullptr;
+    }
+    if (maxRec) k_decode_fill<<<dim3((unsigned) ((maxRec + 255) / 256), (unsigned) n), dim3(256), 0, h->stream>>>(h->ref, *p, h->dJobs.p, h->dDecRecs.p, dRecBase, h->dDecPlan.p, dBad, h->maxRefLength + REF_SLACK);
+    if (anyExpect && maxLen) k_decode_check<<<dim3((unsigned) ((maxLen + 4095) / 4096), (unsigned) n), dim3(256), 0, h->stream>>>(h->dJobs.p, h->dDecPlan.p, dFirstDiff);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(aux.data(), h->dDecAux.p, aux.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    outs.resize(n);
+    for (int k = 0; k < n; k++) {
+        const bool bad = plans[k].unmatched < 0 || badFlags[k] != 0;
+        outs[k].destLen = plans[k].destLen; outs[k].unmatched = bad ? -1 : plans[k].unmatched; outs[k].firstDiff = bad ? UINT64_MAX : firstDiff[k];
+    }
     return SWSEM_OK;
 }
 

@@ -126,3 +126,35 @@ def test_rounds_at_full_genome_size_verify_on_the_device(binding):
         done += R
         torch.cuda.synchronize()
     h.close()
+
+
+def test_many_contigs_decode_side_by_side(binding):
+    """the plan pass is one sequential chain per contig (a wave each): a batch of many contigs is what fills the device — 256
+    contigs of 500 kbp in one emission, decoded and compared on the device (the figure printed is DESIGN's "decoder throughput")"""
+    import time
+    import torch
+    L, R = 500_000, 256
+    base = synth.base_codes(L, 17)
+    h = binding.SlidingWindowSparseEMMatcher(400_000_000)
+    h.set_sliding_window_size(16)
+    g0 = torch.from_numpy(synth.genome(base, 0)).to("cuda:0")
+    torch.cuda.synchronize()
+    h.load_ref_dev(g0.data_ptr(), g0.numel(), True, True, 0)
+    for t in range(1, 9):                                              # a few genomes in the reference: matches as in a collection
+        g = torch.from_numpy(synth.genome(base, t)).to("cuda:0")
+        torch.cuda.synchronize()
+        h.load_ref_dev(g.data_ptr(), g.numel(), False, True, 0)
+    gs = synth.genomes(base, [9 + t for t in range(R)], fork=False)
+    buf = torch.from_numpy(np.concatenate(gs)).to("cuda:0")
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    torch.cuda.synchronize()
+    locks = [h.acquire_lock() for _ in range(R)]
+    h.match_batch_dev(buf.data_ptr(), offs, 32, locks)
+    h.emit_set_host_copy(False)
+    h.emit_batch(binding.emit_params(1), None, locks, [128] * R, list(range(R)), list(range(R)), [h.loaded_ref_length()], n=R)
+    assert h.emit_verify() == (0, -1, 2 ** 64 - 1)                     # (first call: the scratch buffers)
+    t0 = time.perf_counter()
+    assert h.emit_verify() == (0, -1, 2 ** 64 - 1)
+    dt = time.perf_counter() - t0
+    print("device decode + compare of %d x %d bases: %.1f ms = %.2f Gbases/s" % (R, L, dt * 1e3, R * L / dt / 1e9))
+    h.close()
