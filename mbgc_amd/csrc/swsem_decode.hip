@@ -182,6 +182,16 @@ __device__ __forceinline__ bool plan_flag_at(Plan &d, uint64_t i) {
     if (i - d.fl.base >= (uint64_t) WAVE) bw_load<false>(d.fl, i);
     return (d.fl.mask >> (i - d.fl.base)) & 1ull;
 }
+// clear flags from position i on, as far as the window and the stream reach (0: the flag at i is set, or the stream ends there).
+// The score automaton of an extension only falls over them and none of its other conditions moves: they are taken in one step.
+__device__ __forceinline__ uint64_t plan_zero_run(Plan &d, uint64_t i) {
+    if (i >= d.nFlags) return 0;
+    if (i - d.fl.base >= (uint64_t) WAVE) bw_load<false>(d.fl, i);
+    const uint64_t rel = i - d.fl.base;
+    const unsigned long long m = d.fl.mask >> rel;
+    const uint64_t z = m ? (uint64_t) __builtin_ctzll(m) : (uint64_t) WAVE - rel;
+    return z < d.nFlags - i ? z : d.nFlags - i;
+}
 __device__ __forceinline__ void plan_lit_skip(Plan &d) { if (d.litPos >= d.nLit) d.bad = 1; else d.litPos++; }
 __device__ __forceinline__ void plan_grow(Plan &d, uint64_t n) { if (d.destLen + n > d.destCap) d.bad = 1; else d.destLen += n; }
 __device__ uint64_t plan_find_mark(Plan &d, uint64_t from) {
@@ -200,7 +210,14 @@ __device__ uint64_t plan_extend_right(Plan &d, bool isGap, bool gapStart, bool g
     if (gapStart || !isGap) { plan_lit_skip(d); n++; }
     int score = d.initialScore;
     while (!d.bad && (!gapEnd || d.litPos != guardLitPos) && (isGap || score < d.threshold)) {
-        const bool mismatch = plan_flag_at(d, d.flPos++);
+        const uint64_t z = plan_zero_run(d, d.flPos);
+        if (z) {                                                              // z matching positions: the score falls, nothing else moves
+            const int64_t sc = (int64_t) score - (int64_t) d.bonus * (int64_t) z;
+            score = sc < 0 ? 0 : (int) sc;
+            n += z; d.flPos += z;
+            continue;
+        }
+        const bool mismatch = plan_flag_at(d, d.flPos++);                     // (set, or past the end of the stream: malformed)
         if (mismatch && d.litPos == guardLitPos) break;
         if (mismatch) { score += d.penalty; plan_lit_skip(d); }
         else { score -= d.bonus; if (score < 0) score = 0; }
@@ -249,6 +266,18 @@ __device__ LeftExt plan_left_measure(Plan &d, uint64_t *matchSrcPos, bool skipOf
     int score = d.initialScore;
     while (--src >= srcGuard && score < d.threshold) {
         if ((int64_t) len >= DEC_MAX_EXT_LEFT) { d.bad = 1; return e; }
+        {   // matching positions ahead, as far as the guard and the length limit allow: one step (this iteration and z - 1 more)
+            uint64_t z = plan_zero_run(d, fp);
+            const uint64_t room = (uint64_t) (src - srcGuard) + 1, cap = (uint64_t) (DEC_MAX_EXT_LEFT - (int64_t) len);
+            if (z > room) z = room;
+            if (z > cap) z = cap;
+            if (z) {
+                const int64_t sc = (int64_t) score - (int64_t) d.bonus * (int64_t) z;
+                score = sc < 0 ? 0 : (int) sc;
+                len += z; fp += z; src -= (int64_t) z - 1;
+                continue;
+            }
+        }
         const bool mismatch = plan_flag_at(d, fp++);
         if (d.bad) return e;
         if (mismatch && lp == markPos) break;
