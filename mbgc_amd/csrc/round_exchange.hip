@@ -58,7 +58,9 @@ struct mbgc_xchg {
     Shared *sh = nullptr; uint8_t *area = nullptr; uint64_t areaBytes = 0;
 
     int barrier() {
-        // sense-reversing barrier over the shared header; gives up (all ranks) after two minutes or when a rank failed
+        // sense-reversing barrier over the shared header; gives up (all ranks) when a rank failed, or after MBGC_XCHG_BARRIER_SECONDS
+        // (default 120; 0 = never: a rank reading from cold storage is slow, not dead)
+        static const double limit = getenv("MBGC_XCHG_BARRIER_SECONDS") ? atof(getenv("MBGC_XCHG_BARRIER_SECONDS")) : 120.0;
         const uint32_t g = sh->generation.load();
         if (sh->arrived.fetch_add(1) + 1 == (uint32_t) world) { sh->arrived.store(0); sh->generation.fetch_add(1); return 0; }
         const double t0 = now();
@@ -66,7 +68,7 @@ struct mbgc_xchg {
             if (sh->failed.load()) return fail("exchange: another rank failed");
             if ((spin & 1023) == 1023) {
                 sched_yield();
-                if (now() - t0 > 120) { sh->failed.store(1); return fail("exchange: a rank did not arrive within 120 s"); }
+                if (limit > 0 && now() - t0 > limit) { sh->failed.store(1); return fail("exchange: a rank did not arrive within %.0f s", limit); }
             }
         }
         return 0;
@@ -104,14 +106,15 @@ int mbgc_xchg_create_rccl(mbgc_xchg_t **out, const uint8_t ids[2 * MBGC_XCHG_ID_
     ncclUniqueId id[2];
     memcpy(&id[0], ids, sizeof(ncclUniqueId));
     memcpy(&id[1], ids + MBGC_XCHG_ID_BYTES, sizeof(ncclUniqueId));
+    // (on any failure what has been created so far is given back: mbgc_xchg_destroy takes a half-built object)
     if (ncclCommInitRank(&x->bulk, world, id[0], rank) != ncclSuccess || ncclCommInitRank(&x->ctl, world, id[1], rank) != ncclSuccess) {
-        delete x;
+        mbgc_xchg_destroy(x);
         return fail("ncclCommInitRank failed (rank %d of %d on device %d)", rank, world, device);
     }
     if (hipStreamCreateWithFlags(&x->sBulk, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&x->sCtl, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&x->evBytes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x->evWord, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&x->hWord, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
-        delete x;
+        mbgc_xchg_destroy(x);
         return fail("exchange: stream creation failed");
     }
     *out = x;

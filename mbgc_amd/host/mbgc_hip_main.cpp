@@ -38,9 +38,22 @@ struct Bootstrap {
 static Bootstrap *g_boot = nullptr;
 static std::atomic<bool> g_done{false};
 static void raiseFailure() { if (g_boot && !g_done.load()) g_boot->failed.store(1); }
-static void watchOtherRanks() {
-    std::thread([] {
-        while (!g_boot->failed.load()) usleep(50000);
+// Cooperative only as far as it goes: a rank killed by a signal (a fault, the OOM killer) raises nothing. Rank 0 therefore polls
+// its children (waitpid WNOHANG) and raises the flag for any that ended abnormally; the children watch their parent.
+static void watchOtherRanks(const std::vector<pid_t> *children, pid_t parent) {
+    std::thread([children, parent] {
+        while (!g_boot->failed.load()) {
+            usleep(50000);
+            if (children)
+                for (pid_t pid : *children) {
+                    siginfo_t info;
+                    info.si_pid = 0;                                             // (peek: finish() still reaps the child)
+                    if (waitid(P_PID, (id_t) pid, &info, WEXITED | WNOHANG | WNOWAIT) == 0 && info.si_pid == pid &&
+                        !(info.si_code == CLD_EXITED && info.si_status == 0) && !g_done.load())
+                        g_boot->failed.store(1);
+                }
+            else if (parent && getppid() != parent) g_boot->failed.store(1);       // (rank 0 is gone)
+        }
         if (!g_done.load()) { fprintf(stderr, "mbgc-hip: another rank failed\n"); _exit(EXIT_FAILURE); }
     }).detach();
 }
@@ -57,7 +70,7 @@ int main(int argc, char **argv) {
     std::string transport = "rccl";
     size_t shmMb = 64;
     std::string backend;                                                        // a library with the reference's leaf coders (mbgc_leaf_compress)
-    int backendThreads = 8, backendBlocksScale = 1;
+    int backendThreads = 8, backendBlocksScale = 1, coderThreads = 0;           // coderThreads: the reference's -t as the coders see it (0: the pool's size)
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "c") continue;
@@ -78,11 +91,14 @@ int main(int argc, char **argv) {
         else if (a == "--backend" && i + 1 < argc) backend = argv[++i];
         else if (a == "--backend-threads" && i + 1 < argc) backendThreads = atoi(argv[++i]);
         else if (a == "--backend-blocks" && i + 1 < argc) backendBlocksScale = atoi(argv[++i]);
+        else if (a == "--coder-threads" && i + 1 < argc) coderThreads = atoi(argv[++i]);
         else pos.push_back(a);
     }
     if (pos.size() != 2) {
         fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--verify | --verify-every K] [--ref-factor F] [--bench [--warmup rounds]] "
-                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T] [--backend-blocks K]] <sequencesListFile> <outputPrefix>\n");
+                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T] [--backend-blocks K] [--coder-threads t]] <sequencesListFile> <outputPrefix>\n"
+                        "  --backend writes <outputPrefix>.collective: the collective section of the matcher-side streams (the header-side streams are the CLI's and\n"
+                        "  go in empty); --coder-threads = the reference's -t as its coders see it (LZMA runs two threads when it is > 1)\n");
         return EXIT_FAILURE;
     }
     if (gpus < 1 || (transport != "rccl" && transport != "hostmem") || (gpus > 1 && params.sequentialMatching)) {
@@ -113,13 +129,16 @@ int main(int argc, char **argv) {
         boot = g_boot = (Bootstrap *) m;
         atexit(raiseFailure);
         fflush(stdout); fflush(stderr);
+        const pid_t parent = getpid();
         for (int r = 1; r < gpus; r++) {
             const pid_t pid = fork();
             if (pid < 0) { perror("fork"); return EXIT_FAILURE; }
             if (pid == 0) { rank = r; children.clear(); break; }
             children.push_back(pid);
         }
-        watchOtherRanks();
+        static std::vector<pid_t> watched;                                      // (outlives main's frame for the detached watcher)
+        watched = children;
+        watchOtherRanks(rank == 0 ? &watched : nullptr, rank == 0 ? 0 : parent);
         if (transport == "rccl") {
             params.device = rank;                                                // one rank per GPU
             if (rank == 0) {
@@ -179,7 +198,7 @@ int main(int argc, char **argv) {
         if (!leaf) { fprintf(stderr, "cannot load the leaf coders from %s: %s\n", backend.c_str(), dlerror()); return finish(EXIT_FAILURE); }
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        const std::string section = enc.compressStreams(leaf, nullptr, backendThreads, backendBlocksScale);
+        const std::string section = enc.compressStreams(leaf, nullptr, backendThreads, backendBlocksScale, coderThreads);
         clock_gettime(CLOCK_MONOTONIC, &t1);
         dump(pos[1], "collective", section);
         const size_t raw = enc.literals.size() + enc.rcMapOff.size() + enc.rcMapLen.size() + enc.locksPosStream.size() + enc.gapDeltas.size() +

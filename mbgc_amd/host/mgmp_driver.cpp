@@ -1044,14 +1044,15 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
         PgTools::SimpleSequenceMatcher::rcMatchSequence(literals, rcMapOff, rcMapLen, params->rcMatchMinLength, UINT32_MAX, device);
 }
 
-std::string MBGC_Encoder::compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale) {
+std::string MBGC_Encoder::compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale, int numberOfThreads) {
     mbgc_backend_params_t bp = {};
     bp.coderMode = params->coderMode; bp.k = params->k;
     bp.enableExtensionsWithMismatches = params->emit.enableExtensionsWithMismatches;
     bp.mismatchesWithExclusion = params->emit.mismatchesWithExclusion;
     bp.sequentialMatching = params->sequentialMatching; bp.rcRedundancyRemoval = params->rcRedundancyRemoval;
     bp.frugal64bitLenEncoding = params->emit.frugal64bitLenEncoding; bp.lazyDecompressionSupport = params->lazyDecompressionSupport;
-    bp.refFinalTotalLength = refFinalTotalLength; bp.numberOfThreads = threads; bp.blocksScale = blocksScale;
+    bp.refFinalTotalLength = refFinalTotalLength; bp.blocksScale = blocksScale;
+    bp.numberOfThreads = numberOfThreads > 0 ? numberOfThreads : threads;       // PgHelpers::numberOfThreads (the reference's -t): > 1 gives LZMA two threads, PropsLibrary.cpp:9
     const std::string factors((const char *) unmatchedFractionFactors.data(), unmatchedFractionFactors.size());
     const std::string *src[MBGC_ST_COUNT] = {};
     src[MBGC_ST_UNMATCHED_FRACTION_FACTORS] = &factors; src[MBGC_ST_LITERALS] = &literals; src[MBGC_ST_RC_MAP_OFF] = &rcMapOff;

@@ -200,7 +200,10 @@ public:
     // prepareAndCompressStreams' collective section (:641-710) for the streams this path produces — the file-name / header /
     // line-length streams belong to the part of the tool that is not rebuilt here and go in empty (eight zero bytes each) —
     // with the caller's leaf coders; what CompressionJob::writeCompressedCollectiveParallel would write for them
-    std::string compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale = 1);
+    // threads: the job pool of this call; numberOfThreads: what the reference's -t would be (it only decides LZMA's numThreads; 0: = threads).
+    // The header-side streams (names, sequence counts, header templates, headers, line lengths) are the CLI's and go in empty:
+    // the section is what the reference's reader takes for the matcher-side streams, not a complete archive.
+    std::string compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale = 1, int numberOfThreads = 0);
     size_t exactMatches() const { return resCount; }
     size_t finalReferenceLength() const { return refFinalTotalLength; }          // writeStats' refFinalTotalLength, ENC.cpp:734-743
     size_t droppedExtensionBytes() const { return matcher ? matcher->getDroppedBytes() : 0; }

@@ -243,7 +243,10 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
                     wanted += need[r]; all += rankBytes[r];
                 }
             }
-            if (all && wanted < all) {
+            // MBGC_HIP_GATHER_ALL=1 (diagnostics): every round's extensions travel whole — the A/B for the head-only exchange,
+            // whose safety rests on `cap` covering exactly what loadRef's clipping lets through
+            static const bool gatherAll = getenv("MBGC_HIP_GATHER_ALL") != nullptr && atoi(getenv("MBGC_HIP_GATHER_ALL")) != 0;
+            if (all && wanted < all && !gatherAll) {
                 xc(mbgc_xchg_bcast_heads_begin(X, src, need.data(), mx, ext.p));
                 params->headRounds++;
             } else

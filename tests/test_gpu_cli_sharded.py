@@ -116,3 +116,10 @@ def test_a_wrapping_buffer_and_the_head_of_the_round(tmp_path):
         assert a[k] == b[k], k
     heads = int([x for x in many.splitlines() if x.startswith("rounds whose extension exchange carried only the loadable head")][0].split(":")[1])
     assert heads >= 2, many
+    # the A/B for the head-only exchange: every round's extensions gathered whole (MBGC_HIP_GATHER_ALL=1) — the same bytes
+    whole = run_tool(["c", "--ref-factor", "1", "--gpus", "2", "--exchange", "hostmem", "--shm-mb", "1", "-R", "2", "list.txt", "whole"], str(tmp_path),
+                     env={"MBGC_HIP_GATHER_ALL": "1"})
+    c = dumps(tmp_path, "whole")
+    for k in STREAMS:
+        assert a[k] == c[k], k
+    assert "rounds whose extension exchange carried only the loadable head: 0" in whole
