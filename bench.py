@@ -220,6 +220,22 @@ def cpu_all_cores(sample_targets, length):
                    whole_run_value=round(sample_targets * length / wall / 1e9, 5), cpu_model=cpu_model(), nproc=hw, cpu_quota=quota)
         if ratio:
             out["archive_bytes"] = int(ratio.group(2))
+        # the same files through this repo's full encode: `mbgc-hip c --backend` (rounds sized by the window, the backend's job table
+        # of include/mbgc_backend.h around the reference's own PPMd7 / LZMA leaf coders) — seconds and bytes beside the reference's
+        hip, coders = os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), os.path.join(ROOT, "oracle", "_ref", "libmbgc_coders.so")
+        if os.access(hip, os.X_OK) and os.path.exists(coders):
+            t0 = time.perf_counter()
+            q = subprocess.run([hip, "c", "--backend", coders, "--backend-threads", str(cores), lst, os.path.join(d, "hip")],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            wall_hip = time.perf_counter() - t0
+            mb = re.search(r"backend: (\d+) stream bytes to (\d+) in (\d+) ms", q.stdout)
+            mm = re.search(r"matching finished - (\d+) \[ms\]", q.stderr)
+            if q.returncode == 0 and mb:
+                out["full_encode"] = dict(files=sample_targets + 1, command="mbgc-hip c --backend oracle/_ref/libmbgc_coders.so --backend-threads %d" % cores,
+                                          seconds=round(wall_hip, 2), matching_ms=int(mm.group(1)) if mm else None, backend_ms=int(mb.group(3)),
+                                          collective_section_bytes=int(mb.group(2)), reference_seconds=round(wall, 2),
+                                          reference_archive_bytes=out.get("archive_bytes"),
+                                          section_over_reference_archive=round(int(mb.group(2)) / out["archive_bytes"], 4) if out.get("archive_bytes") else None)
         return out
     except Exception:
         return None

@@ -256,7 +256,7 @@ int refbk_archive(const char *path, int mode, int flags, int threads, uint64_t r
 }
 
 // the leaf callback of include/mbgc_backend.h served by the reference's coders: what a maintainer's build passes to
-// mbgc_backend_compress_streams, and what `mbgc-hip c --backend oracle/_ref/libswsem_ref.so` loads in the tests
+// mbgc_backend_compress_streams, (the tool itself is given oracle/_ref/libmbgc_coders.so: the coders alone, ref_coders.cpp)
 struct RefLeafCoder { int coder, level, lc, lp, pb, fb, algo, numThreads; uint32_t dictSize, memSize; int order; };
 int mbgc_leaf_compress(void *ctx, const RefLeafCoder *c, const unsigned char *src, uint64_t n, unsigned char *dest, uint64_t cap, uint64_t *destLen) {
     return refbk_leaf(c->coder, c->level, c->dictSize, c->lc, c->lp, c->pb, c->fb, c->algo, c->numThreads, c->memSize, c->order, src, n, dest, cap, destLen);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Compression-ratio parity on synthetic 5 Mbp genomes (BASELINE.json's second clause): the reference's own `mbgc c -m1`
-(oracle/_ref/mbgc, all hardware threads: its parallel schedule) against `mbgc-hip c -R 40 --backend`, i.e. this repo's
+(oracle/_ref/mbgc, all hardware threads: its parallel schedule) against `mbgc-hip c --backend` (rounds sized by the sliding window), i.e. this repo's
 streams through the job table + container of include/mbgc_backend.h with the reference's unchanged PPMd / LZMA as the leaf
 coders. The two archives come from different (both admissible) schedules of the same encoder, so their sizes agree to a
 fraction of a percent rather than byte for byte; byte identity is checked at the stream level by the tests.
@@ -40,13 +40,13 @@ out["reference"] = dict(command="mbgc c -m1 (all hardware threads)", rc=r.return
                         bases_per_byte=round(bases / size, 2) if size else None)
 for key, blocks, th in (("this_repo", "1", threads), ("this_repo_8x_blocks", "8", "64")):
     t0 = time.time()
-    r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c", "-R", "40", "--backend", os.path.join(REF, "libswsem_ref.so"), "--backend-threads", th,
+    r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c", "--backend", os.path.join(REF, "libmbgc_coders.so"), "--backend-threads", th,
                         "--backend-blocks", blocks, os.path.join(d, "list.txt"), os.path.join(d, "hip")], capture_output=True, text=True)
     wall = time.time() - t0
     m = re.search(r"backend: (\d+) stream bytes to (\d+) in (\d+) ms", r.stdout)
     mm = re.search(r"matching finished - (\d+) \[ms\]", r.stderr)
     sec = int(m.group(2)) if m else None
-    out[key] = dict(command="mbgc-hip c -R 40 --backend <reference coders> --backend-threads %s --backend-blocks %s" % (th, blocks), rc=r.returncode,
+    out[key] = dict(command="mbgc-hip c --backend <the reference's leaf coders, oracle/_ref/libmbgc_coders.so> --backend-threads %s --backend-blocks %s" % (th, blocks), rc=r.returncode,
                     wall_s=round(wall, 2), matching_ms=int(mm.group(1)) if mm else None, stream_bytes=int(m.group(1)) if m else None,
                     collective_section_bytes=sec, backend_ms=int(m.group(3)) if m else None, bases_per_byte=round(bases / sec, 2) if sec else None,
                     section_over_reference_archive=round(sec / size, 4) if size and sec else None)

@@ -61,7 +61,7 @@ rows = []
 for R in (0, 1, 8, 32, 40, 64, 320):
     t0 = time.time()
     args = [os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c", "--ref-factor", str(1 << order)] + (["-R", str(R)] if R else []) + \
-           ["--backend", os.path.join(REF, "libswsem_ref.so"), "--backend-threads", threads, lst, os.path.join(d, "hip%d" % R)]
+           ["--backend", os.path.join(REF, "libmbgc_coders.so"), "--backend-threads", threads, lst, os.path.join(d, "hip%d" % R)]
     r = subprocess.run(args, capture_output=True, text=True)
     wall = time.time() - t0
     m = re.search(r"backend: (\d+) stream bytes to (\d+) in (\d+) ms", r.stdout)

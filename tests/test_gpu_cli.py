@@ -188,7 +188,7 @@ def test_backend_section_is_read_back_by_the_reference(tmp_path, blocks):
         (tmp_path / f).write_bytes(lzma.open(os.path.join(LIST, f + ".xz")).read())
         names.append(str(tmp_path / f))
     (tmp_path / "seqlist.txt").write_text("\n".join(names) + "\n")
-    out = run_tool(["c", "-t1", "--backend", os.path.join(ROOT, "oracle", "_ref", "libswsem_ref.so"), "--backend-threads", "1",
+    out = run_tool(["c", "-t1", "--backend", os.path.join(ROOT, "oracle", "_ref", "libmbgc_coders.so"), "--backend-threads", "1",
                     "--backend-blocks", str(blocks), "seqlist.txt", "lm"], str(tmp_path))
     assert "backend:" in out and ("%d x the reference's blocks" % blocks) in out
     section = (tmp_path / "lm.collective").read_bytes()
