@@ -21,7 +21,7 @@ under `python -m torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
 Diagnostics (never the headline): --no-emit (matcher only), --from-host (queries cross PCIe inside the timed region),
 --check (first round against the oracle); environment: MBGC_BENCH_MAX_REF (another buffer size), MBGC_BENCH_BLOCK_STATS
 / MBGC_BENCH_BLOCK_DUMP (per-block clocks of the last resolve launch), MBGC_BENCH_ONE_DEVICE + MBGC_BENCH_BACKEND=gloo
-(several ranks on one GPU, a rehearsal of the N > 1 protocol), and the library's own switches (SWSEM_CHAINS, SWSEM_ORDER,
+(several ranks on one GPU, a rehearsal of the N > 1 protocol), and the library's own switches (SWSEM_CHAINS,
 SWSEM_RB, SWSEM_RESOLVE, SWSEM_PROF_FAMS; see mbgc_amd/csrc/swsem_runtime.hip: swsem_create)."""
 import argparse
 import json

@@ -112,7 +112,6 @@ struct swsem {
     DevBuf<Contig> dContigs;
     DevBuf<uint32_t> dMatchCount, dRbContig, dRbOrder;
     std::vector<uint32_t> rbOrderHost, rbOrderKey;   // the table on the device is kept while the batches keep their shape (rbOrderKey)
-    int orderMode = 1;                     // launch order of the resolve blocks: 0 contig-major, 1 offset-major on one XCD (SWSEM_ORDER)
     bool simt = true;                      // four chains per wave (k_resolve_blocks4); SWSEM_CHAINS=1: one chain per wave (k_resolve_blocks)
     uint32_t chainsPerWave = 1;            // of the last batch
     hipStream_t stream3 = nullptr;         // device-to-host copies of emitted streams (end_slot)
@@ -204,10 +203,8 @@ struct swsem {
     hipEvent_t evP1 = nullptr;
     hipEvent_t evFin = nullptr;            // behind the speculative finalize (see emit_begin_impl)
     hipEvent_t evMeta = nullptr;           // behind the last emission's k_emit_meta_blocks
-    bool metaPending = false, metaWait = true;   // SWSEM_META_WAIT=0: the resolve does not wait for it
+    bool metaPending = false;
     bool phase2Behind = true;              // the second phase's byte automata are handed over behind the speculative finalize
-    // SWSEM_GATE2=0: the byte automata are queued with the emission, not behind the next batch's resolve launch (run_phase2b)
-    bool gate2 = true;
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
     uint32_t rb = 8;                       // length of a resolve block in units of RBU positions: chosen per batch (run_batch) unless SWSEM_RB fixes it
@@ -650,17 +647,12 @@ int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
 bool build_resolve_order(swsem *h, uint32_t rblocks, uint32_t per) {
     std::vector<uint32_t> key;
     key.reserve(h->contigs.size() + 3);
-    key.push_back((uint32_t) h->orderMode); key.push_back(rblocks); key.push_back(per);
+    key.push_back(rblocks); key.push_back(per);
     for (auto &cg : h->contigs) key.push_back(cg.nrb);
     if (key == h->rbOrderKey && !h->rbOrderHost.empty()) return false;       // same shape as the last batch: the device table stands
     h->rbOrderKey.swap(key);
     std::vector<uint32_t> &order = h->rbOrderHost;
     order.clear();
-    if (h->orderMode == 0) {                                                 // contig-major: blocks in their canonical order
-        order.assign((size_t) ((rblocks + per - 1) / per) * per, 0xFFFFFFFFu);
-        for (uint32_t g = 0; g < rblocks; g++) order[g] = g;
-        return true;
-    }
     uint32_t maxNrb = 0;
     for (auto &cg : h->contigs) maxNrb = std::max(maxNrb, cg.nrb);
     // contigs by descending block count: the contigs that still have a block at offset b are a prefix
@@ -778,7 +770,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         // An emission whose byte automata wait to be queued (run_phase2b): they are handed to the second stream AFTER the
         // resolve kernel has been handed to the first, behind an event recorded just before it — whatever hardware queues
         // the two streams share, the resolve is dealt its wave slots first.
-        if (h->metaPending && h->metaWait) { HIPCHK(hipStreamWaitEvent(h->stream, h->evMeta, 0)); h->metaPending = false; }
+        if (h->metaPending) { HIPCHK(hipStreamWaitEvent(h->stream, h->evMeta, 0)); h->metaPending = false; }
         bool anyDeferred = false;
         for (auto &E : h->slot) anyDeferred |= E.deferred2b;
         if (anyDeferred) {
@@ -957,11 +949,8 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
-    if (const char *e = getenv("SWSEM_ORDER")) h->orderMode = strcmp(e, "contig") == 0 ? 0 : 1;
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
-    if (const char *e = getenv("SWSEM_GATE2")) h->gate2 = atoi(e) != 0;
-    if (const char *e = getenv("SWSEM_META_WAIT")) h->metaWait = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
@@ -1474,7 +1463,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     E.v2b = v; E.grid2b = chunks; E.n2b = n;
     auto phase2b = [&](bool behindFinalize) -> int {
         E.deferred2b = true; E.waitFin2b = behindFinalize;
-        return h->gate2 ? SWSEM_OK : run_phase2b(h, E, false);
+        return SWSEM_OK;
     };
     E.donePending = true;
     const bool specAsked = spec && spec->ntargets > 0 && h->phase2Behind;

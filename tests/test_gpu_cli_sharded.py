@@ -84,6 +84,19 @@ def test_a_rank_whose_file_holds_no_record(tmp_path, gpus, r, empty):
         assert [x for x in one.splitlines() if x.startswith(line)] == [x for x in many.splitlines() if x.startswith(line)], line
 
 
+def test_window_sized_rounds_are_divided_among_the_ranks(tmp_path):
+    """without -R a round is what the reference's rules let be in flight — min(64, window / largest target) — whatever the number of
+    GPUs: two ranks take half of it each and write the bytes the single GPU writes (a 16 MiB buffer: window 1 MiB, 200 kbp genomes,
+    rounds of 5 on one GPU, 2 per rank on two = rounds of 4: the single-GPU run is given that size to compare)"""
+    write_collection(tmp_path, 40, 200_000, 0.003, 1)
+    many = run_tool(["c", "--ref-factor", "4", "--gpus", "2", "--exchange", "hostmem", "--shm-mb", "2", "list.txt", "many"], str(tmp_path))
+    assert "rounds of 2 targets per GPU; reference extension bytes dropped at the sliding window's end: 0" in many, many
+    run_tool(["c", "--ref-factor", "4", "-R", "4", "list.txt", "one"], str(tmp_path))
+    a, b = dumps(tmp_path, "one"), dumps(tmp_path, "many")
+    for k in STREAMS:
+        assert a[k] == b[k], k
+
+
 def test_rccl_with_one_rank_equals_the_plain_loop(tmp_path):
     """the RCCL transport on the hardware at hand: one rank — communicators, the two collectives' streams, the on-stream
     reduction inside the speculative finalize, the gather — against the loop without an exchange"""

@@ -198,7 +198,7 @@ def test_batch_round_on_device(binding):
 
 @pytest.mark.parametrize("env", [{"SWSEM_RESOLVE": "seq"}, {"SWSEM_RB": "1"}, {"SWSEM_RB": "2"}, {"SWSEM_RB": "16"}, {"SWSEM_RB": "64"},
                                  {"SWSEM_CHAINS": "1"}, {"SWSEM_CHAINS": "1", "SWSEM_RB": "1"}, {"SWSEM_CHAINS": "1", "SWSEM_RB": "5"},
-                                 {"SWSEM_ORDER": "contig"}, {"SWSEM_ORDER": "contig", "SWSEM_RB": "3"}])
+                                 {"SWSEM_RB": "3"}])
 def test_resolve_variants_agree_with_oracle(binding, env, monkeypatch):
     """one wave replaying a whole contig, block-parallel speculation at several block lengths (units of 1024 positions),
     four chains per wave (default) and one chain per wave, both launch orders: same rows"""
