@@ -217,10 +217,7 @@ constexpr int RING = 64;
 __device__ __forceinline__ uint32_t rl32(uint32_t x, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) x, lane); }
 __device__ __forceinline__ uint32_t rfl32(uint32_t x) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) x); }
 __device__ __forceinline__ uint64_t rfl64(uint64_t x) { return ((uint64_t) rfl32((uint32_t) (x >> 32)) << 32) | rfl32((uint32_t) x); }
-#ifndef SWSEM_OVERLAP
-#define SWSEM_OVERLAP 1024
-#endif
-constexpr int OVERLAP = SWSEM_OVERLAP;          // warm-up positions of a speculative block chain (<= a block: RBU)
+constexpr int OVERLAP_MAX = RBU;       // warm-up positions of a speculative block chain: at most a block's unit; the launch says how many (run_batch adapts it)
 constexpr int SNAP = 4;                // stack elements snapshotted at a block boundary / end
 
 // A row of a block chain's stack: the match plus the scan position the chain had right after emitting it.
@@ -721,7 +718,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
                                                          const uint32_t *__restrict__ rbContig,
                                                          const uint32_t *__restrict__ order,
                                                          Row *__restrict__ regions, uint32_t cap, uint32_t rb,
-                                                         BlockRec *__restrict__ recs) {
+                                                         BlockRec *__restrict__ recs, uint32_t overlap) {
     __shared__ uint2 ring[RING];
     // launch slot -> block (run_batch: blocks that scan the same offsets of different contigs sit in slots that are
     // equal mod 8, i.e. on one XCD, next to each other; 0xFFFFFFFF pads the lists of the eight XCDs to one length)
@@ -733,7 +730,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     const int32_t w0 = (int32_t) (b * rb * RBU);
     const int32_t w1 = w0 + (int32_t) (rb * RBU) < npos ? w0 + (int32_t) (rb * RBU) : npos;
     Chain ch;
-    ch.scan = b ? w0 - OVERLAP : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
+    ch.scan = b ? w0 - (int32_t) overlap : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
 #ifdef SWSEM_DIAG_PHASES
     ch.tRefill = ch.tVisit = ch.tLcp = 0; ch.nRefill = ch.nLcp = 0;
 #endif
@@ -744,7 +741,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     ArrayStack<Row> stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
-    if (b) chain_run<LAPS>(v, cg, q, w0 - OVERLAP, w0, stk, ch);   // warm-up on the previous block's tail
+    if (b) chain_run<LAPS>(v, cg, q, w0 - (int32_t) overlap, w0, stk, ch);   // warm-up on the previous block's tail
     BlockRec r;
     r.scanB = ch.scan > w0 ? ch.scan : w0;
     r.spB = stk.sp;

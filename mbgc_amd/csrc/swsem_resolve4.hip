@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
                                                           const uint32_t *__restrict__ rbContig,
                                                           const uint32_t *__restrict__ order4,
                                                           Row *__restrict__ regions, uint32_t cap, uint32_t rb,
-                                                          BlockRec *__restrict__ recs) {
+                                                          BlockRec *__restrict__ recs, uint32_t overlap) {
     __shared__ uint4 ring[GC][RING4];              // {posDest, len, posSrc lo, posSrc hi} of the newest rows
     __shared__ __attribute__((aligned(16))) uint8_t qcache[GC][16 * GL + 16];   // query bytes [qb0, qb0 + 256) of every chain (+ slack: a window's last dword)
     const uint32_t lane = threadIdx.x, grp = lane >> 4, gl = lane & 15u, gbase = lane & 48u;
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
         w1 = w0 + (int32_t) (rb * RBU) < npos ? w0 + (int32_t) (rb * RBU) : npos;
         st = regions + (uint64_t) g * cap;
         phase = 0;
-        p0 = b ? w0 - OVERLAP : 0;                 // block 0 starts from the true (empty) state: its warm-up is empty
+        p0 = b ? w0 - (int32_t) overlap : 0;       // block 0 starts from the true (empty) state: its warm-up is empty
         p1 = w0;
         scan = p0;
     }

@@ -207,6 +207,11 @@ struct swsem {
     bool phase2Behind = true;              // the second phase's byte automata are handed over behind the speculative finalize
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
+    // Warm-up positions of a speculative block chain (at most RBU): a chain started from the empty state falls into step with the
+    // true one after a few emissions, and how many positions that takes depends on the collection (on how far apart its matches
+    // lie). Too short and blocks are replayed by the stitch, one after the other; too long and every block scans positions twice.
+    // Adapted from the share of replayed blocks the last full batch reported (take_counts): the results never depend on it.
+    uint32_t overlap = 1024, overlapFixed = 0, batchBlocks = 0;
     uint32_t rb = 8;                       // length of a resolve block in units of RBU positions: chosen per batch (run_batch) unless SWSEM_RB fixes it
     uint32_t rbFixed = 0;
     uint32_t slotPercent = 95;             // share of the wave slots a launch's blocks are sized for (80 %: +5 % on the 4.35e9-byte sizing, -3 % on configs[2]'s)
@@ -758,7 +763,8 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         h->mark(SWSEM_K_RESOLVE, false);
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
-        const uint32_t cap = (uint32_t) ((h->rb * RBU + OVERLAP + h->K) / h->K + 8);
+        const uint32_t cap = (uint32_t) ((h->rb * RBU + OVERLAP_MAX + h->K) / h->K + 8);
+        h->batchBlocks = rblocks;
         if ((r = h->dRegions.reserve((size_t) rblocks * cap))) return r;
         if ((r = h->dReplay.reserve((size_t) n * cap))) return r;
         if ((r = h->dRecs.reserve(rblocks))) return r;
@@ -779,11 +785,11 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         }
         h->mark(SWSEM_K_RESOLVE, true);
         if (h->chainsPerWave == (uint32_t) GC) {
-            if (wrapped) k_resolve_blocks4<true><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
-            else k_resolve_blocks4<false><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
+            if (wrapped) k_resolve_blocks4<true><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p, h->overlap);
+            else k_resolve_blocks4<false><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p, h->overlap);
         } else {
-            if (wrapped) k_resolve_blocks<true><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
-            else k_resolve_blocks<false><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p);
+            if (wrapped) k_resolve_blocks<true><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p, h->overlap);
+            else k_resolve_blocks<false><<<dim3(rslots), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRbContig.p, h->dRbOrder.p, h->dRegions.p, cap, h->rb, h->dRecs.p, h->overlap);
         }
         h->mark(SWSEM_K_RESOLVE, false);
         if (anyDeferred) {
@@ -840,6 +846,12 @@ void take_counts(swsem *h) {
     const unsigned long long *st = (const unsigned long long *) h->pin;
     h->matchCount.assign((const uint32_t *) (h->pin + 64), (const uint32_t *) (h->pin + 64) + n);
     h->stats[1] = h->hostProbes; h->stats[2] = st[2]; h->stats[5] = st[3];
+    if (!h->overlapFixed && h->batchBlocks >= 2048) {              // (a batch large enough for the share to mean something)
+        const uint64_t replayed = st[3];
+        if (replayed * 400 > h->batchBlocks) h->overlap = std::min<uint32_t>((uint32_t) RBU, h->overlap + 128);         // > 0.25 %: longer
+        else if (replayed * 2000 < h->batchBlocks) h->overlap = std::max<uint32_t>(640u, h->overlap - 128);          // < 0.05 %: shorter
+        h->batchBlocks = 0;                                          // (these counts are taken once per batch)
+    }
     uint64_t tot = 0;
     for (size_t c = 0; c < n; c++) tot += h->matchCount[c];
     h->stats[3] = tot;
@@ -951,6 +963,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
+    if (const char *e = getenv("SWSEM_OVERLAP")) { int x = atoi(e); if (x >= 0 && x <= RBU) h->overlap = h->overlapFixed = (uint32_t) std::max(1, x); }
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
