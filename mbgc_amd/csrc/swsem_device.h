@@ -6,7 +6,8 @@
 namespace swk {
 
 constexpr int WAVE = 64;
-constexpr int RBU = 1024;             // unit of a resolve block's length: a block scans rb * RBU query positions
+constexpr int RBU = 256;              // unit of a resolve block's length: a block scans rb * RBU query positions (fine enough for the blocks of a
+                                      // batch to fill the wave slots they are sized for: 6 656 positions at configs[2], not 6 144 or 7 168)
 constexpr int OVERLAP_MATCH_MAX_LENGTH = 1 << 13;   // SlidingWindowSparseEMMatcher.h:18
 
 // Hash-table entry: (epoch << 32) | (pos >> k1ord). The reference's table is "last writer wins" in

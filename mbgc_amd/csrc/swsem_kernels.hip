@@ -217,7 +217,7 @@ constexpr int RING = 64;
 __device__ __forceinline__ uint32_t rl32(uint32_t x, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) x, lane); }
 __device__ __forceinline__ uint32_t rfl32(uint32_t x) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) x); }
 __device__ __forceinline__ uint64_t rfl64(uint64_t x) { return ((uint64_t) rfl32((uint32_t) (x >> 32)) << 32) | rfl32((uint32_t) x); }
-constexpr int OVERLAP_MAX = RBU;       // warm-up positions of a speculative block chain: at most a block's unit; the launch says how many (run_batch adapts it)
+constexpr int OVERLAP_MAX = 1024;      // warm-up positions of a speculative block chain, at most; the launch says how many (run_batch adapts it)
 constexpr int SNAP = 4;                // stack elements snapshotted at a block boundary / end
 
 // A row of a block chain's stack: the match plus the scan position the chain had right after emitting it.
@@ -683,7 +683,7 @@ __global__ void __launch_bounds__(WAVE) k_resolve_seq(RefView v, const uint8_t *
 // ------------------------------------------------------------------------------------------------
 // Block-parallel resolution. The greedy chain is sequential, but its state at a query position is
 // tiny (scan position + the few newest matches), and chains started from different states fall into
-// step after a few emissions. So every tile gets its own wave: it warms up on the last OVERLAP
+// step after a few emissions. So every tile gets its own wave: it warms up on the last `overlap`
 // positions of the previous tile from an empty stack (speculation), snapshots its state at the tile
 // boundary, then replays its own tile. The stitch kernel walks the tiles of a contig in order with
 // the TRUE state, accepts a block when its boundary snapshot equals the true state as deep as the
@@ -730,7 +730,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     const int32_t w0 = (int32_t) (b * rb * RBU);
     const int32_t w1 = w0 + (int32_t) (rb * RBU) < npos ? w0 + (int32_t) (rb * RBU) : npos;
     Chain ch;
-    ch.scan = b ? w0 - (int32_t) overlap : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
+    const int32_t warm0 = w0 > (int32_t) overlap ? w0 - (int32_t) overlap : 0;   // (from the contig's start the empty state IS the true one)
+    ch.scan = b ? warm0 : 0; ch.minTouched = 0x7fffffff; ch.minKeep = 0x7fffffff; ch.visited = 0; ch.cands = 0; ch.emitted = false;
 #ifdef SWSEM_DIAG_PHASES
     ch.tRefill = ch.tVisit = ch.tLcp = 0; ch.nRefill = ch.nLcp = 0;
 #endif
@@ -741,7 +742,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_num_sgpr(SWSEM_RES
     ArrayStack<Row> stk;
     stk.st = regions + (uint64_t) g * cap; stk.ring = ring; stk.sp = 0; stk.ringLow = 0;
     const uint8_t *q = qbuf + cg.qoff;
-    if (b) chain_run<LAPS>(v, cg, q, w0 - (int32_t) overlap, w0, stk, ch);   // warm-up on the previous block's tail
+    if (b) chain_run<LAPS>(v, cg, q, warm0, w0, stk, ch);   // warm-up on the previous block's tail
     BlockRec r;
     r.scanB = ch.scan > w0 ? ch.scan : w0;
     r.spB = stk.sp;

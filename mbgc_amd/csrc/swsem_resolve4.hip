@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(WAVE, SWSEM_RESOLVE4_WAVES) k_resolve_blocks4(
         w1 = w0 + (int32_t) (rb * RBU) < npos ? w0 + (int32_t) (rb * RBU) : npos;
         st = regions + (uint64_t) g * cap;
         phase = 0;
-        p0 = b ? w0 - (int32_t) overlap : 0;       // block 0 starts from the true (empty) state: its warm-up is empty
+        p0 = b && w0 > (int32_t) overlap ? w0 - (int32_t) overlap : 0;   // block 0 starts from the true (empty) state: its warm-up is empty
         p1 = w0;
         scan = p0;
     }

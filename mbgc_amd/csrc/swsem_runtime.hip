@@ -207,7 +207,7 @@ struct swsem {
     bool phase2Behind = true;              // the second phase's byte automata are handed over behind the speculative finalize
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
-    // Warm-up positions of a speculative block chain (at most RBU): a chain started from the empty state falls into step with the
+    // Warm-up positions of a speculative block chain (at most OVERLAP_MAX): a chain started from the empty state falls into step with the
     // true one after a few emissions, and how many positions that takes depends on the collection (on how far apart its matches
     // lie). Too short and blocks are replayed by the stitch, one after the other; too long and every block scans positions twice.
     // Adapted from the share of replayed blocks the last full batch reported (take_counts): the results never depend on it.
@@ -705,8 +705,8 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         // Block chains are latency-bound and a launch lasts as long as its slowest wave: the blocks are sized so
         // that all of them are resident at once and there are as many as that allows.
         // Fewer, longer blocks leave wave slots empty; more of them run in two generations and lengthen the
-        // sequential stitch. At least 2 units: a small batch (one target of the sequential schedule) fills few wave slots
-        // whatever the block length, and then short chains are what is fast (1024 warm-up positions per 2048 of its own).
+        // sequential stitch. At least 2048 positions: a small batch (one target of the sequential schedule) fills few wave slots
+        // whatever the block length, and then short chains are what is fast (the warm-up positions per 2048 of its own).
         uint64_t allUnits = 0;                          // in units of RBU positions
         for (int c = 0; c < n; c++) {
             const uint64_t len = offsets[c + 1] - offsets[c];
@@ -715,7 +715,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         h->chainsPerWave = (h->simt && !h->seqResolve && h->K <= K_MAX4) ? (uint32_t) GC : 1u;
         const uint64_t waves = h->chainsPerWave > 1 ? (uint64_t) h->waveSlots / RESOLVE_WAVES_PER_SIMD * RESOLVE4_WAVES_PER_SIMD : h->waveSlots;
         const uint64_t slots = std::max<uint64_t>(1, waves * h->chainsPerWave * h->slotPercent / 100);
-        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(64, std::max<uint64_t>(2, (allUnits + slots - 1) / slots));   // (a small batch — one target of the sequential schedule — runs short chains: it is their length that takes the time)
+        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(65536 / RBU, std::max<uint64_t>(2048 / RBU, (allUnits + slots - 1) / slots));   // (a small batch — one target of the sequential schedule — runs short chains: it is their length that takes the time)
     }
     for (int c = 0; c < n; c++) {
         Contig &cg = h->contigs[c];
@@ -848,7 +848,7 @@ void take_counts(swsem *h) {
     h->stats[1] = h->hostProbes; h->stats[2] = st[2]; h->stats[5] = st[3];
     if (!h->overlapFixed && h->batchBlocks >= 2048) {              // (a batch large enough for the share to mean something)
         const uint64_t replayed = st[3];
-        if (replayed * 400 > h->batchBlocks) h->overlap = std::min<uint32_t>((uint32_t) RBU, h->overlap + 128);         // > 0.25 %: longer
+        if (replayed * 400 > h->batchBlocks) h->overlap = std::min<uint32_t>((uint32_t) OVERLAP_MAX, h->overlap + 128);         // > 0.25 %: longer
         else if (replayed * 2000 < h->batchBlocks) h->overlap = std::max<uint32_t>(640u, h->overlap - 128);          // < 0.05 %: shorter
         h->batchBlocks = 0;                                          // (these counts are taken once per batch)
     }
@@ -963,8 +963,8 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
-    if (const char *e = getenv("SWSEM_OVERLAP")) { int x = atoi(e); if (x >= 0 && x <= RBU) h->overlap = h->overlapFixed = (uint32_t) std::max(1, x); }
-    if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x; }
+    if (const char *e = getenv("SWSEM_OVERLAP")) { int x = atoi(e); if (x >= 0 && x <= OVERLAP_MAX) h->overlap = h->overlapFixed = (uint32_t) std::max(1, x); }
+    if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x * (1024 / RBU); }   // (in units of 1024 positions)
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
