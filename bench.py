@@ -431,6 +431,9 @@ def main():
     for s in range(warm, warm + steps) if not args.from_host else ():
         tot_matches += int(runner.run_round(*bufs[s], next_batch=bufs[s + 1] if s + 1 < len(bufs) else None).sum())
         replayed += m.batch_stats()["replayed_blocks"]
+        if os.environ.get("MBGC_BENCH_SERIAL"):         # diagnostics: every kernel alone on the device (the line is marked)
+            runner.flush()
+            torch.cuda.synchronize()
         marks[s - warm + 1].record()
         laps_at.append(m.ref_length() == m.max_ref_length())
     runner.flush()                                     # the last round's emission (its second phase runs beside the next round)
@@ -519,6 +522,7 @@ def main():
             "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
             "round_finalizes_queued_behind_pass1": {"tried": runner.spec_local[0], "applied": runner.spec_local[1], "not_applied_at_try": runner.spec_local[2][:16]},
             **({"step_ms": [round(t, 3) for t in step_ms]} if os.environ.get("MBGC_BENCH_STEP_MS") else {}),
+            **({"INVALID": "MBGC_BENCH_SERIAL: the device was drained after every step (diagnostics)"} if os.environ.get("MBGC_BENCH_SERIAL") else {}),
         }
         if os.environ.get("MBGC_BENCH_BLOCK_TIMES"):                  # diagnostics: how even the last launch's resolve blocks were
             import ctypes
@@ -534,6 +538,8 @@ def main():
                 if len(t):
                     out["resolve_block_ticks"] = {"blocks": int(nb.value), "mean": float(t.mean()), "median": float(t[len(t) // 2]),
                                                   "p90": float(t[int(len(t) * 0.9)]), "p99": float(t[int(len(t) * 0.99)]), "max": float(t[-1])}
+        if os.environ.get("MBGC_BENCH_EMIT_STATS"):                   # diagnostics: the emission's pairing chain over the whole run
+            out["pairing_chain"] = m.emit_stats()
         if os.environ.get("MBGC_BENCH_OCC"):                          # diagnostics: share of the table's buckets that hold an entry at the end of the run
             out["table_occupancy"] = round(float(np.count_nonzero(m.ht())) / m.hash_size(), 5)
         if world > 1 or forced:

@@ -255,6 +255,10 @@ enum { SWSEM_K_LOAD = 0, SWSEM_K_INSERT = 1, SWSEM_K_PROBE = 2 /* unused: the ch
  * accumulated device time (ms) and bracket count per family are read back with swsem_profile_get.
  * EMIT = pass 1 of processMatches (main stream), EMIT2 = its second phase (second stream; the bracket also
  * covers whatever the main stream runs beside it, so it is an elapsed time, not a sum of kernel times). */
+/* counters of the emission's pairing chain since swsem_create: out[4] = steps taken with an inherited region boundary that
+   was not the match's own, out[5] = speculative blocks that were not accepted, out[6] = groups of 64 matches replayed from
+   the true state, out[7] = blocks given up because they carried too many such boundaries (diagnostics; synchronises the device) */
+int swsem_debug_emit_stats(swsem_t *h, uint64_t out[8]);
 int swsem_debug_block_times(swsem_t *h, uint64_t *out /* [cap][3]: ticks, candidates visited, stack rows */, uint64_t cap, uint64_t *nblocks);
 int swsem_profile_enable(swsem_t *h, int on);
 int swsem_profile_get(swsem_t *h, double ms[SWSEM_K_COUNT], uint64_t launches[SWSEM_K_COUNT]);

@@ -21,7 +21,7 @@ swsem_disable_sliding_window swsem_set_sliding_window_size swsem_disable_circula
 swsem_get_loading_position swsem_get_loaded_ref_length swsem_get_max_ref_length swsem_get_sliding_window_size swsem_get_dropped_bytes swsem_set_position
 swsem_acquire_lock swsem_release_lock swsem_get_K swsem_get_hash_size swsem_load_ref swsem_load_ref_dev
 swsem_load_separator swsem_finalize_targets swsem_revcomp_dev swsem_match swsem_match_batch_dev swsem_batch_counts swsem_batch_matches
-swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_emit_pack_dev_on swsem_emit_counters swsem_debug_copy_ref swsem_debug_write_ref swsem_debug_copy_ht
+swsem_batch_fingerprint swsem_emit_params_default swsem_emit swsem_emit_batch swsem_emit_batch_begin swsem_emit_batch_begin_spec swsem_emit_batch_end swsem_emit_select swsem_emit_result swsem_emit_set_host_copy swsem_emit_unmatched swsem_emit_pack_dev swsem_emit_pack_dev_on swsem_emit_counters swsem_debug_copy_ref swsem_debug_write_ref swsem_debug_copy_ht swsem_debug_emit_stats
 swsem_profile_enable swsem_profile_get swsem_batch_stats swsem_dev_malloc swsem_dev_free swsem_dev_upload swsem_dev_download swsem_dev_copy swsem_decode_contigs_dev swsem_emit_verify""".split()
 
 
@@ -180,6 +180,14 @@ class SlidingWindowSparseEMMatcher:
     def max_ref_length(self): return lib().swsem_get_max_ref_length(self.h)
     def sliding_window_size(self): return lib().swsem_get_sliding_window_size(self.h)
     def dropped_bytes(self): return lib().swsem_get_dropped_bytes(self.h)
+
+    def emit_stats(self):
+        """Counters of the emission's pairing chain since the handle was made (diagnostics)."""
+        out = (C.c_uint64 * 8)()
+        lib().swsem_debug_emit_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _chk(lib().swsem_debug_emit_stats(self.h, out))
+        return {"foreign_boundary_steps": int(out[4]), "blocks_not_accepted": int(out[5]), "groups_replayed": int(out[6]),
+                "blocks_given_up": int(out[7])}
     def set_position(self, pos, laps): lib().swsem_set_position(self.h, pos, laps)
     def acquire_lock(self): return lib().swsem_acquire_lock(self.h)
     def release_lock(self, v): _chk(lib().swsem_release_lock(self.h, v)); return 0

@@ -36,6 +36,7 @@ struct EmitContig {
     uint32_t cap;                                    // rows reserved (>= matches + 2)
     uint32_t chunk0;                                 // first of the contig's ceil(cap / CH) chunks in the chunk grid
     int32_t factor;                                  // unmatchedFractionFactor
+    uint32_t span0;                                  // first of the contig's ceil(cap / MSPAN) spans in the span grid (pairing chain)
     int64_t processed, targetIdx;                    // processedTargetsCount / targetIdx
 };
 
@@ -59,10 +60,14 @@ struct EmitView {
     uint32_t *keepIdx;
     uint32_t *meta;                                  // per kept match, see META_*
     uint32_t *corr;                                  // gapStartIdx when in a gap
+    unsigned long long *pairMask;                    // per kept match: which of the next 64 it can be paired with (k_emit_meta_masks)
+    unsigned long long *litBits;                     // per 64 kept matches (word chunk0 * 4 + m / 64): no literal follows the match
+    unsigned long long *metaBad;                     // per 64 blocks of the pairing chain (word chunk0 + b / 64): not acceptable as they are
     uint32_t *sz;                                    // 6 u32 per gap task
     uint32_t *ofs;                                   // 6 u32 per iteration: start offsets in the six streams
     uint32_t *chunkCnt;                              // [chunk] kept-match counts / offsets, 6 sums per chunk for placement
     const uint32_t *chunkOwner;                      // [chunk] -> contig of the batch (chunks of CH rows, per contig)
+    const uint32_t *spanOwner;                       // [span] -> contig of the batch (spans of the pairing chain)
     uint32_t ncontigs;
     uint64_t *packBase;                              // [contig][stream] start of the stream in the packed arena
     uint8_t *arena;                                  // streams
@@ -295,21 +300,41 @@ __global__ void __launch_bounds__(CH) k_emit_p1_finish(EmitView v, const EmitCon
 // ------------------------------------------------------------------------------------------------
 // the pairing / gap chain, MBGC_Encoder.cpp:229-278 (no sequence bytes involved). The chain's state at
 // match j is small — which of the next 64 matches are already paired, the open gap, and the inherited
-// nextSrcRegionLoadingPos values of those 64 matches — and claims reach at most 64 matches ahead, so
-// chains started from an empty state fall into step with the true one after a short warm-up. Every
-// block of META_BLOCK matches is therefore replayed by its own wave after META_WARM warm-up matches
-// (speculation); k_emit_meta_stitch accepts a block when its state at the block start equals the true
-// state and replays it from the true state otherwise — identical results by construction.
+// nextSrcRegionLoadingPos values of the paired ones — and claims reach at most 64 matches ahead, so
+// chains started from an empty state fall into step with the true one after a short warm-up.
+//   k_emit_meta_spec    every LANE runs the chain of its own block of MB matches after MWARM warm-up matches
+//                       (speculation), 256 blocks per workgroup: the chain is scalar work, and a wave that runs
+//                       one chain issues one instruction in four cycles whatever it does — 64 chains per wave
+//                       cost the same. The look-ahead masks ("which of my next 64 matches are pairedWith me")
+//                       of the workgroup's span are computed first, lane-parallel, from keys staged in LDS.
+//   k_emit_meta_stitch  accepts a block when the state it started from equals the state its predecessor
+//                       ended in (the first block of a contig starts from the true, empty state) and replays
+//                       the group of 64 matches around a block that fails, from the true state, with the
+//                       wave-wide form of the chain (meta_run) — identical results by construction.
 // ------------------------------------------------------------------------------------------------
-constexpr int META_BLOCK = 256, META_WARM = 128, META_LDS = META_BLOCK + META_WARM + WAVE;
-static_assert(META_BLOCK == CH, "the pairing chain shares the chunk grid of the other emission kernels");
+constexpr int META_GROUP = WAVE;                     // matches per replay of the stitch (one chunk of meta_run)
+constexpr int META_LDS = META_GROUP + WAVE;          // staged matches of a replay: the group + its look-ahead
+constexpr int MB = 16, MWARM = 64, MLANES = 256;     // matches per speculative block, warm-up, blocks per workgroup
+constexpr int MSPAN = MLANES * MB;                   // matches per workgroup
+constexpr int MNX = 4;                               // inherited boundaries a lane keeps (more: the block is replayed)
+static_assert(MSPAN % CH == 0 && META_GROUP % MB == 0, "spans are whole chunks of the emission grid, groups whole blocks");
+constexpr int MCHUNKS = MSPAN / CH;                  // chunks of the emission grid per span
+constexpr int MPAD_N = MSPAN + MWARM + WAVE;         // staged matches: warm-up + span + look-ahead
+// one pad word per 16: lanes 16 matches apart (the chains) and lanes one match apart (staging) both spread over the banks
+__device__ __forceinline__ int mpad(int i) { return i + (i >> 4); }
+constexpr int MPAD_SIZE = MPAD_N + (MPAD_N >> 4) + 2;
 
-struct MetaState {
-    unsigned long long claimed;      // bit g-1: match j+g is already paired (the pairedGap ring)
+// The chain's state at a block boundary J, in canonical form (entries sorted by rel, empty ones zeroed): two states are
+// equal iff every field is.
+struct MetaRec {
+    unsigned long long claimed;      // bit g-1: match J+g is already paired (the pairedGap ring)
     int64_t gapStartIdx, gapEndIdx;
-    uint32_t curClaimed, pad;        // pairedGap[gapCurIdx]
-    uint64_t nx[WAVE + 1];           // inherited nextSrcRegionLoadingPos of matches j .. j+64
+    uint32_t flags;                  // bit 0: pairedGap[gapCurIdx] (match J is paired); bit 1: more than MNX inherited values
+    uint8_t rel[MNX];                // match J + rel inherited a nextSrcRegionLoadingPos that is not its own (0xFF: no entry)
+    uint64_t val[MNX];
 };
+static_assert(sizeof(MetaRec) == 64, "one record, one 64-byte line");
+constexpr uint32_t MREC_CUR = 1, MREC_OVERFLOW = 2;
 
 struct MetaLds {
     int64_t sdiag[META_LDS];
@@ -447,101 +472,292 @@ __device__ void meta_run(const EmitView &v, const EmitContig &cg, MetaLds &L, Me
     }
 }
 
-__device__ __forceinline__ void meta_store_state(MetaState *dst, const MetaRun &st) {
-    const uint32_t lane = threadIdx.x;
-    dst->nx[lane] = st.nxA;
-    if (lane == 0) {
-        dst->nx[WAVE] = st.nxB;                      // lane 0 of nxB = match j + 64
-        dst->claimed = st.claimed; dst->gapStartIdx = st.gapStartIdx; dst->gapEndIdx = st.gapEndIdx;
-        dst->curClaimed = st.curClaimed ? 1u : 0u; dst->pad = 0;
+
+__device__ __forceinline__ bool mrec_equal(const MetaRec &a, const MetaRec &b) {
+    uint32_t ra, rb;
+    __builtin_memcpy(&ra, a.rel, 4); __builtin_memcpy(&rb, b.rel, 4);
+    uint64_t d = (a.claimed ^ b.claimed) | (uint64_t) (a.gapStartIdx ^ b.gapStartIdx) | (uint64_t) (a.gapEndIdx ^ b.gapEndIdx) |
+                 (uint64_t) (a.flags ^ b.flags) | (uint64_t) (ra ^ rb);
+#pragma unroll
+    for (int e = 0; e < MNX; e++) d |= a.val[e] ^ b.val[e];
+    return d == 0;
+}
+
+// a lane's chain state -> canonical record relative to boundary J
+__device__ __forceinline__ void mrec_store(MetaRec *dst, unsigned long long claimed, bool cur, int gs, int ge, const int (&nxPos)[MNX],
+                                           const uint64_t (&nxVal)[MNX], bool overflow, int J) {
+    uint32_t r[MNX]; uint64_t x[MNX];
+#pragma unroll
+    for (int e = 0; e < MNX; e++) { r[e] = nxPos[e] >= J ? (uint32_t) (nxPos[e] - J) : 0xFFu; x[e] = nxPos[e] >= J ? nxVal[e] : 0; }
+    auto cx = [&](int a, int b) {
+        if (r[a] > r[b]) { const uint32_t t = r[a]; r[a] = r[b]; r[b] = t; const uint64_t u = x[a]; x[a] = x[b]; x[b] = u; }
+    };
+    cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+    MetaRec R;
+    R.claimed = claimed; R.gapStartIdx = gs; R.gapEndIdx = ge;
+    R.flags = (cur ? MREC_CUR : 0u) | (overflow ? MREC_OVERFLOW : 0u);
+#pragma unroll
+    for (int e = 0; e < MNX; e++) { R.rel[e] = (uint8_t) r[e]; R.val[e] = x[e]; }
+    *dst = R;
+}
+
+// Span = MSPAN matches of one contig, one workgroup each: the span grid (spanOwner, EmitContig::span0) is laid out like the
+// chunk grid, for the rows a contig has reserved — a span beyond the matches it really has ends at once.
+struct MetaSpan { uint32_t gk; int n, B0; bool live; };
+__device__ __forceinline__ MetaSpan meta_span(const EmitView &v, const EmitContig *__restrict__ cgs) {
+    MetaSpan sp;
+    sp.gk = v.spanOwner[blockIdx.x];
+    const EmitOut o = v.out[sp.gk];
+    sp.n = (int) o.nmatches;
+    sp.B0 = (int) (blockIdx.x - cgs[sp.gk].span0) * MSPAN;
+    sp.live = o.unmatchedChars != UINT64_MAX && sp.B0 < sp.n;
+    return sp;
+}
+
+// look-ahead masks of a span's matches: bit g-1 of match m = match m+g is within the depth, pairedWith m
+// (TextMatchers.h:42-50: same diagonal, same side of the lock — two matches of one contig on one diagonal cannot both
+// start AT the lock, so equal keys say it all) and, under lazy decompression, not beyond m's OWN region boundary
+// (:253-259 when nothing else was inherited). Plus one bit per match: no literal follows it (:242).
+__global__ void __launch_bounds__(MLANES) k_emit_meta_masks(EmitView v, const EmitContig *__restrict__ cgs) {
+    __shared__ uint64_t skey[MPAD_SIZE], slp[MPAD_SIZE];
+    const MetaSpan sp = meta_span(v, cgs);
+    if (!sp.live) return;
+    const EmitContig cg = cgs[sp.gk];
+    const int n = sp.n, B0 = sp.B0, tid = (int) threadIdx.x;
+    const int P1 = B0 + MSPAN < n ? B0 + MSPAN : n;                      // masks for [B0, P1)
+    const int PK = P1 + WAVE < n ? P1 + WAVE : n;                        // from the keys of [B0, PK)
+    const EMatch *E = v.em + cg.scratchBase;
+    const bool lazy = v.p.lazyDecompressionSupport != 0;
+    const int depth = v.p.gapDepthOffsetEncoding;
+    for (int i = tid; i < ((PK - B0 + WAVE - 1) & ~(WAVE - 1)); i += MLANES) {
+        const int m = B0 + i;
+        bool lit0 = false;
+        if (m < PK) {
+            const EMatch e = E[m];
+            const uint64_t side = e.posSrc > cg.lock ? 1u : (e.posSrc < cg.lock ? 2u : 0u);
+            skey[mpad(i)] = ((e.posSrc - e.posDest) << 2) | side;
+            slp[mpad(i)] = e.lp;
+            const uint64_t nxt = m + 1 < n ? E[m + 1].posDest : cg.n;
+            lit0 = nxt - (uint32_t) (e.posDest + e.len) == 0;                       // (uint32 pos)
+        }
+        const unsigned long long lb = __ballot(lit0);
+        if ((tid & (WAVE - 1)) == 0 && m < P1) v.litBits[(size_t) cg.chunk0 * (CH / WAVE) + (size_t) (m / WAVE)] = lb;
+    }
+    __syncthreads();
+    for (int i = tid; i < P1 - B0; i += MLANES) {
+        const int m = B0 + i;
+        const int gCnt = n - m - 1 < depth ? n - m - 1 : depth;
+        const uint64_t kj = skey[mpad(i)];
+        const uint64_t own = lazy ? v.next0[cg.scratchBase + m] : UINT64_MAX;
+        unsigned long long pm = 0;
+#pragma unroll 8
+        for (int g = 1; g <= WAVE; g++) {                    // branch-free and unrolled: the LDS reads of several steps are in flight together
+            const int x = mpad(g <= gCnt ? i + g : i);
+            const bool ok = (g <= gCnt) & (skey[x] == kj) & ((slp[x] < own) | !lazy);
+            pm |= (unsigned long long) ok << (g - 1);
+        }
+        v.pairMask[cg.scratchBase + m] = pm;
     }
 }
 
-// one block per chunk of META_BLOCK (= CH) matches
-__global__ void __launch_bounds__(WAVE) k_emit_meta_blocks(EmitView v, const EmitContig *__restrict__ cgs, MetaState *__restrict__ states) {
-    __shared__ MetaLds L;
+// the chains: lane = block [j0, j1) of a span, warmed up on the MWARM matches in front of it
+__global__ void __launch_bounds__(MLANES) k_emit_meta_spec(EmitView v, const EmitContig *__restrict__ cgs, MetaRec *__restrict__ recs, int warm,
+                                                          unsigned long long *__restrict__ stats) {
+    __shared__ uint64_t spm[MPAD_SIZE], sown[MPAD_SIZE];     // masks; the matches' own region boundaries
+    __shared__ unsigned long long slit[MPAD_N / WAVE + 2];
+    const MetaSpan sp = meta_span(v, cgs);
+    if (!sp.live) return;
+    const EmitContig cg = cgs[sp.gk];
+    const int n = sp.n, B0 = sp.B0, tid = (int) threadIdx.x;
+    const int P0 = B0 >= MWARM ? B0 - MWARM : 0;                         // first staged match
+    const int P1 = B0 + MSPAN < n ? B0 + MSPAN : n;
+    const EMatch *E = v.em + cg.scratchBase;
+    const bool lazy = v.p.lazyDecompressionSupport != 0, ext = v.p.enableExtensionsWithMismatches != 0;
+    const int depth = v.p.gapDepthOffsetEncoding, depthMism = v.p.gapDepthMismatchesEncoding;
+    const int PK = P1 + WAVE < n ? P1 + WAVE : n;                        // own boundaries for [P0, PK): a claim looks at its target's
+    for (int i = tid; i < PK - P0; i += MLANES) {
+        if (P0 + i < P1) spm[mpad(i)] = v.pairMask[cg.scratchBase + P0 + i];
+        sown[mpad(i)] = lazy ? v.next0[cg.scratchBase + P0 + i] : 0;
+    }
+    if (tid < MPAD_N / WAVE + 2) {
+        const int w = P0 / WAVE + tid;                                    // (P0 is a multiple of 64)
+        slit[tid] = w * WAVE < P1 ? v.litBits[(size_t) cg.chunk0 * (CH / WAVE) + (size_t) w] : 0;
+    }
+    __syncthreads();
+    const int j0 = B0 + tid * MB;
+    const bool active = j0 < n;
+    const int j1 = j0 + MB < n ? j0 + MB : n;
+    unsigned long long claimed = 0;
+    bool cur = false, overflow = false;
+    int gs = -1, ge = -1;
+    int nxPos[MNX]; uint64_t nxVal[MNX];
+#pragma unroll
+    for (int e = 0; e < MNX; e++) { nxPos[e] = -1; nxVal[e] = 0; }
+    MetaRec *myRecs = recs + ((size_t) cg.chunk0 * (CH / MB) + (size_t) (j0 / MB)) * 2;
+    for (int s = 0; s < MWARM + MB; s++) {
+        const int j = j0 - MWARM + s;
+        if (s == MWARM && active) mrec_store(myRecs, claimed, cur, gs, ge, nxPos, nxVal, overflow, j0);
+        if (!active || j < j0 - warm || j < 0 || j >= j1) continue;         // (warm < MWARM: A/B switch and the tests' way to make blocks fail)
+        const int i = j - P0;
+        if (ext && j == ge) { gs = -1; ge = -1; }                                           // :222-225
+        const bool skipOffset = cur;                                                        // :229
+        const int gCnt = n - j - 1 < depth ? n - j - 1 : depth;
+        const bool rule = !lazy && gs == -1 && ((slit[i / WAVE] >> (i & (WAVE - 1))) & 1);  // :247, applies to g == 1
+        const unsigned long long taken = claimed | (rule ? 1ull : 0ull);
+        unsigned long long em = spm[mpad(i)] & ~taken;                                      // paired (within the own boundary) and not yet claimed
+        uint64_t inherited = 0;
+#pragma unroll
+        for (int e = 0; e < MNX; e++) if (nxPos[e] == j) { inherited = nxVal[e]; nxPos[e] = -1; }
+        uint64_t nextj = 0;
+        if (lazy) {                                                                         // :253-259
+            nextj = sown[mpad(i)];
+            if (inherited && inherited != nextj) {
+                // an inherited boundary that is not the match's own (a pair across two source regions): the mask does not
+                // hold for it — from the matches themselves
+                nextj = inherited;
+                atomicAdd(&stats[4], 1ull);
+                const EMatch mj = E[j];
+                em = 0;
+                for (int g = 1; g <= gCnt; g++) {
+                    const EMatch c = E[j + g];
+                    const bool pw = paired(mj.posSrc, mj.posDest, c.posSrc, c.posDest) &&
+                                    ((mj.posSrc > cg.lock && c.posSrc > cg.lock) || (mj.posSrc < cg.lock && c.posSrc < cg.lock));
+                    if (pw && c.lp < nextj) em |= 1ull << (g - 1);
+                }
+                em &= ~taken;
+            }
+        }
+        uint32_t gapByte = 0;
+        if (em) {
+            const int gf = __builtin_ctzll(em) + 1;
+            const unsigned long long below = gf > 1 ? ((1ull << (gf - 1)) - 1) : 0ull;
+            gapByte = (uint32_t) (gf - __popcll(taken & below));
+            claimed |= 1ull << (gf - 1);                                                    // :262
+            if (lazy && nextj != sown[mpad(i + gf)]) {                                      // :260 (its own boundary: nothing to carry, :254)
+                bool put = false;
+#pragma unroll
+                for (int e = 0; e < MNX; e++) if (!put && nxPos[e] < 0) { nxPos[e] = j + gf; nxVal[e] = nextj; put = true; }
+                overflow |= !put;
+            }
+            if (ext && ge <= j + gf && gf <= depthMism) { gs = j; ge = j + gf; }
+        }
+        cur = claimed & 1ull;                                                               // :272-273: advance the ring
+        claimed >>= 1;
+        if (j >= j0) {
+            const bool s0 = gs == j, e0 = ge == j + 1, m0 = gs < j && j + 1 < ge;
+            const bool isGap = s0 || m0 || e0;
+            const uint32_t mw = (skipOffset ? META_SKIPOFF : 0) | (gCnt ? META_HASGAP : 0) | (isGap ? META_ISGAP : 0) |
+                                (s0 ? META_GSTART : 0) | (m0 ? META_GMID : 0) | (e0 ? META_GEND : 0) | (gapByte << 8);
+            v.meta[cg.scratchBase + j] = mw;
+            v.corr[cg.scratchBase + j] = (uint32_t) (isGap ? gs : j);
+        }
+    }
+    if (active) mrec_store(myRecs + 1, claimed, cur, gs, ge, nxPos, nxVal, overflow, j1);
+    if (active && overflow) atomicAdd(&stats[7], 1ull);
+}
+
+// which blocks cannot be accepted as they are: one bit per block, one word per 64 blocks of a contig (word chunk0 + b / 64).
+// A block is held against its predecessor's end; the first block of a contig started from the true, empty state.
+__global__ void __launch_bounds__(WAVE) k_emit_meta_check(EmitView v, const EmitContig *__restrict__ cgs, const MetaRec *__restrict__ recs,
+                                                          unsigned long long *__restrict__ stats) {
+    constexpr int CPW = WAVE * MB / CH;                              // chunks of the emission grid per word of blocks
     const uint32_t gk = v.chunkOwner[blockIdx.x];
     const EmitContig cg = cgs[gk];
     const uint32_t gx = blockIdx.x - cg.chunk0;
+    if (gx % CPW) return;
     const EmitOut o = v.out[gk];
     if (o.unmatchedChars == UINT64_MAX) return;
-    const int64_t n = (int64_t) o.nmatches;
-    const int64_t j0 = (int64_t) gx * META_BLOCK;
-    if (j0 >= n) return;
-    const int64_t j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
-    const int64_t w = j0 >= META_WARM ? j0 - META_WARM : 0;
-    const bool lazy = v.p.lazyDecompressionSupport != 0;
-    meta_load(v, cg, L, w, j1 + WAVE < n ? j1 + WAVE : n, lazy);
-    MetaRun st;
-    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1; st.nxA = 0; st.nxB = 0;
-    meta_run<false>(v, cg, L, st, w, w, j0, n);                     // warm-up, nothing written
-    MetaState *S = states + ((size_t) blockIdx.x) * 2;
-    meta_store_state(S, st);
-    meta_run<true>(v, cg, L, st, w, j0, j1, n);
-    meta_store_state(S + 1, st);
+    const int64_t n = (int64_t) o.nmatches, nblk = (n + MB - 1) / MB;
+    const int64_t b = (int64_t) (gx / CPW) * WAVE + threadIdx.x;
+    if (b - (int64_t) threadIdx.x >= nblk) return;
+    const MetaRec *R0 = recs + (size_t) cg.chunk0 * (CH / MB) * 2;
+    bool bad = false;
+    if (b < nblk) {
+        const MetaRec S = R0[2 * b], F = R0[2 * b + 1];
+        bad = ((S.flags | F.flags) & MREC_OVERFLOW) != 0;
+        if (b > 0 && !bad) bad = !mrec_equal(S, R0[2 * b - 1]);
+    }
+    const unsigned long long mb = __ballot(bad);
+    if (threadIdx.x == 0) {
+        v.metaBad[cg.chunk0 + gx / CPW] = mb;
+        if (mb) atomicAdd(&stats[5], (unsigned long long) __popcll(mb));
+    }
 }
 
-__global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const EmitContig *__restrict__ cgs, const MetaState *__restrict__ states,
+// a record (wave-uniform) in the wave-wide form of the chain's state
+__device__ __forceinline__ void mrec_expand(const MetaRec &R, MetaRun &st) {
+    st.claimed = rfl64(R.claimed); st.curClaimed = (rfl32(R.flags) & MREC_CUR) != 0;
+    st.gapStartIdx = (int64_t) rfl64((uint64_t) R.gapStartIdx); st.gapEndIdx = (int64_t) rfl64((uint64_t) R.gapEndIdx);
+    st.nxA = 0; st.nxB = 0;
+#pragma unroll
+    for (int e = 0; e < MNX; e++) {
+        const int rel = (int) rfl32(R.rel[e]);
+        const uint64_t val = rfl64(R.val[e]);
+        if (rel < WAVE) st.nxA = wl64(val, rel, st.nxA);
+        else if (rel == WAVE) st.nxB = wl64(val, 0, st.nxB);
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) k_emit_meta_stitch(EmitView v, const EmitContig *__restrict__ cgs, const MetaRec *__restrict__ recs,
                                                            unsigned long long *__restrict__ stats) {
     __shared__ MetaLds L;
     const EmitContig cg = cgs[blockIdx.x];
     const EmitOut o = v.out[blockIdx.x];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
-    const uint32_t lane = threadIdx.x;
+    const int lane = (int) threadIdx.x;
     const bool lazy = v.p.lazyDecompressionSupport != 0;
-    const int64_t nb = (n + META_BLOCK - 1) / META_BLOCK;
-    // A block that started from the state its predecessor ended in is correct if the predecessor is (block 0 starts
-    // from the true, empty state). That comparison needs nothing but the stored states, so it is made for 64
-    // blocks at a time; the sequential walk below only starts at the first block that fails it — on similar
-    // genomes there is none and the kernel ends here.
-    const MetaState *S0 = states + (size_t) cg.chunk0 * 2;
-    int64_t firstBad = nb;
-    for (int64_t g0 = 1; g0 < nb && firstBad == nb; g0 += WAVE) {
-        const int64_t b = g0 + lane;
-        bool bad = false;
-        if (b < nb) {
-            const MetaState *A = S0 + 2 * b, *F = S0 + 2 * (b - 1) + 1;      // b's start, b-1's end
-            bad = A->claimed != F->claimed || A->gapStartIdx != F->gapStartIdx || A->gapEndIdx != F->gapEndIdx ||
-                  (A->curClaimed != 0) != (F->curClaimed != 0);
-            for (int k = 0; k <= WAVE && !bad; k++) bad = A->nx[k] != F->nx[k];
-        }
-        const unsigned long long mb = __ballot(bad);
-        if (mb) firstBad = g0 + __builtin_ctzll(mb);
-    }
-    if (firstBad == nb) return;
-    MetaRun st;                                                      // true state at the start of block b
-    {
-        const MetaState *F = S0 + 2 * (firstBad - 1) + 1;
-        st.claimed = rfl64(F->claimed); st.curClaimed = rfl32(F->curClaimed) != 0;
-        st.gapStartIdx = (int64_t) rfl64((uint64_t) F->gapStartIdx); st.gapEndIdx = (int64_t) rfl64((uint64_t) F->gapEndIdx);
-        st.nxA = F->nx[lane];
-        st.nxB = lane == 0 ? F->nx[WAVE] : 0;
-    }
+    const int64_t nblk = (n + MB - 1) / MB, ngrp = (n + META_GROUP - 1) / META_GROUP;
+    constexpr int BPG = META_GROUP / MB;                             // blocks per group
+    const MetaRec *R0 = recs + (size_t) cg.chunk0 * (CH / MB) * 2;   // block b: R0[2b] where it started, R0[2b + 1] where it ended
+    MetaRun st;                                                      // the true state at the start of group g
+    st.claimed = 0; st.curClaimed = false; st.gapStartIdx = -1; st.gapEndIdx = -1; st.nxA = 0; st.nxB = 0;
     uint32_t replayed = 0;
-    for (int64_t b = firstBad; b < nb; b++) {
-        const int64_t j0 = b * META_BLOCK, j1 = j0 + META_BLOCK < n ? j0 + META_BLOCK : n;
-        const MetaState *S = states + ((size_t) cg.chunk0 + b) * 2;
-        bool same = true;
-        if (b > 0) {
-            const uint64_t tnx64 = rl64(st.nxB, 0);
-            const bool d = S->nx[lane] != st.nxA || (lane == 0 && (S->nx[WAVE] != tnx64 || S->claimed != st.claimed ||
-                           S->gapStartIdx != st.gapStartIdx || S->gapEndIdx != st.gapEndIdx ||
-                           (S->curClaimed != 0) != st.curClaimed));
-            same = __ballot(d) == 0;
+    const unsigned long long *BW = v.metaBad + cg.chunk0;           // k_emit_meta_check's bits, word b / 64
+    const int64_t nwords = (nblk + WAVE - 1) / WAVE;
+    for (int64_t g = 0; g < ngrp;) {
+        // the first block from BPG * g on that cannot be accepted. The group's first block is held against the true state
+        // (behind a replay its predecessor's record is not the truth any more); every later one was held against its
+        // predecessor's end by k_emit_meta_check — on similar genomes no bit is set and the kernel ends here.
+        const int64_t h = BPG * g;
+        int64_t first = nblk;
+        {
+            const MetaRec S = R0[2 * h], F = R0[2 * h + 1];
+            bool bad = ((S.flags | F.flags) & MREC_OVERFLOW) != 0;
+            if (!bad && g > 0) {
+                // (records carry an inherited boundary only where it differs from the match's own, :254 treats both alike)
+                MetaRun t;
+                mrec_expand(S, t);
+                const int64_t J = h * MB;
+                const uint64_t ownA = lazy && J + lane < n ? v.next0[cg.scratchBase + J + lane] : 0;
+                const uint64_t ownB = lazy && J + WAVE < n ? v.next0[cg.scratchBase + J + WAVE] : 0;
+                if (st.nxA == ownA) st.nxA = 0;
+                if (st.nxB == ownB) st.nxB = 0;
+                const bool d = t.nxA != st.nxA || (lane == 0 && (t.nxB != st.nxB || t.claimed != st.claimed || t.gapStartIdx != st.gapStartIdx ||
+                                                                 t.gapEndIdx != st.gapEndIdx || t.curClaimed != st.curClaimed));
+                bad = __ballot(d) != 0;
+            }
+            if (bad) first = h;
         }
-        if (same) {
-            const MetaState *F = S + 1;
-            st.claimed = rfl64(F->claimed); st.curClaimed = rfl32(F->curClaimed) != 0;
-            st.gapStartIdx = (int64_t) rfl64((uint64_t) F->gapStartIdx); st.gapEndIdx = (int64_t) rfl64((uint64_t) F->gapEndIdx);
-            st.nxA = F->nx[lane];
-            st.nxB = lane == 0 ? F->nx[WAVE] : 0;
-        } else {
-            // replay the block from the true state
-            meta_load(v, cg, L, j0, j1 + WAVE < n ? j1 + WAVE : n, lazy);
-            meta_run<true>(v, cg, L, st, j0, j0, j1, n);
-            replayed++;
+        for (int64_t w0 = (h + 1) / WAVE; w0 < nwords && first == nblk; w0 += WAVE) {
+            const int64_t w = w0 + lane;
+            unsigned long long bits = w < nwords ? BW[w] : 0ull;
+            if (w == (h + 1) / WAVE) bits &= ~0ull << ((h + 1) & (WAVE - 1));              // (blocks up to h are settled)
+            const unsigned long long any = __ballot(bits != 0);
+            if (any) {
+                const int l = __builtin_ctzll(any);
+                first = (w0 + l) * WAVE + __builtin_ctzll(rl64(bits, l));
+            }
         }
+        if (first >= nblk) break;
+        const int64_t gb = first / BPG;
+        if (gb > g) mrec_expand(R0[2 * (BPG * gb - 1) + 1], st);     // (the block in front of group gb was accepted: its end is the true state)
+        g = gb;
+        const int64_t j0 = g * META_GROUP, j1 = j0 + META_GROUP < n ? j0 + META_GROUP : n;
+        meta_load(v, cg, L, j0, j1 + WAVE < n ? j1 + WAVE : n, lazy);
+        meta_run<true>(v, cg, L, st, j0, j0, j1, n);                 // replay the group from the true state
+        replayed++;
+        g++;
     }
     if (lane == 0 && replayed) atomicAdd(&stats[6], (unsigned long long) replayed);
 }

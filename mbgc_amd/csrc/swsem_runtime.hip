@@ -134,15 +134,16 @@ struct swsem {
         DevBuf<EmitContig> dECg;
         DevBuf<EmitOut> dEOut;
         DevBuf<int> dEWhich;
-        DevBuf<uint32_t> dEOwner;
+        DevBuf<uint32_t> dEOwner, dESpanOwner;
         DevBuf<EMatch> dEM;
         DevBuf<uint64_t> dENext0, dELoaded, dEPack;
         DevBuf<uint8_t> dERm, dEArena;
         DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs, dEChunk;
-        DevBuf<MetaState> dEStates;
-        DevBuf<unsigned long long> dEStat;
+        DevBuf<MetaRec> dEStates;
+        DevBuf<unsigned long long> dEStat, dEPm, dELit, dEBad;
+        bool statZeroed = false;
         std::vector<EmitContig> ecg;
-        std::vector<uint32_t> chunkOwner;
+        std::vector<uint32_t> chunkOwner, spanOwner;
         std::vector<int> ewhich;
         std::vector<uint64_t> eloaded;
         std::vector<EmitOut> eout;
@@ -179,9 +180,9 @@ struct swsem {
         bool hostStreamsValid = false;
         uint64_t packedBytes = 0;
         void release() {
-            dECg.release(); dEOut.release(); dEWhich.release(); dEOwner.release(); dEM.release(); dENext0.release(); dELoaded.release();
+            dECg.release(); dEOut.release(); dEWhich.release(); dEOwner.release(); dESpanOwner.release(); dEM.release(); dENext0.release(); dELoaded.release();
             dEPack.release(); dERm.release(); dEArena.release(); dEKeep.release(); dEMeta.release(); dECorr.release();
-            dESz.release(); dEOfs.release(); dEChunk.release(); dEStates.release(); dEStat.release();
+            dESz.release(); dEOfs.release(); dEChunk.release(); dEStates.release(); dEStat.release(); dEPm.release(); dELit.release(); dEBad.release();
             if (pinE) { (void) hipHostFree(pinE); pinE = nullptr; pinECap = 0; }
             hostStreams.release();
             if (evDone) { (void) hipEventDestroy(evDone); evDone = nullptr; }
@@ -204,6 +205,7 @@ struct swsem {
     hipEvent_t evFin = nullptr;            // behind the speculative finalize (see emit_begin_impl)
     hipEvent_t evMeta = nullptr;           // behind the last emission's k_emit_meta_blocks
     bool metaPending = false;
+    int metaWarm = swk::MWARM;             // warm-up matches of the pairing chain's speculative blocks (SWSEM_META_WARM: fewer, so that blocks fail)
     bool phase2Behind = true;              // the second phase's byte automata are handed over behind the speculative finalize
     bool emitHostCopy = true;              // copy the streams to the host inside swsem_emit_batch
     bool seqResolve = false;               // SWSEM_RESOLVE=seq: one wave per contig (cross-check path)
@@ -963,6 +965,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
+    if (const char *e = getenv("SWSEM_META_WARM")) h->metaWarm = std::min(swk::MWARM, std::max(0, atoi(e)));
     if (const char *e = getenv("SWSEM_OVERLAP")) { int x = atoi(e); if (x >= 0 && x <= OVERLAP_MAX) h->overlap = h->overlapFixed = (uint32_t) std::max(1, x); }
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x * (1024 / RBU); }   // (in units of 1024 positions)
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
@@ -999,6 +1002,12 @@ void swsem_destroy(swsem_t *h) {
     if (h->stream2) (void) hipStreamSynchronize(h->stream2);
     if (h->stream3) (void) hipStreamSynchronize(h->stream3);
     h->drain_events();
+    if (getenv("SWSEM_DEBUG_STATS")) {                               // diagnostics: the pairing chain's counters of this handle
+        uint64_t t[8];
+        if (swsem_debug_emit_stats(h, t) == SWSEM_OK && (t[4] | t[5] | t[6] | t[7]))
+            fprintf(stderr, "swsem pairing chain: foreign-boundary steps %llu, blocks not accepted %llu, groups replayed %llu, blocks given up %llu\n",
+                    (unsigned long long) t[4], (unsigned long long) t[5], (unsigned long long) t[6], (unsigned long long) t[7]);
+    }
     if (h->ref) (void) hipFree(h->ref);
     if (h->tags) (void) hipFree(h->tags);
     if (h->ht) (void) hipFree(h->ht);
@@ -1298,6 +1307,21 @@ int swsem_debug_block_times(swsem_t *h, uint64_t *out, uint64_t cap, uint64_t *n
     return SWSEM_OK;
 }
 
+// counters of the emission's pairing chain since the handle was made, summed over the emission slots:
+// out[4] steps that went by an inherited boundary other than the match's own, out[5] blocks of the speculative pass that were
+// not accepted, out[6] groups of 64 matches the stitch replayed, out[7] blocks given up for too many inherited boundaries
+int swsem_debug_emit_stats(swsem_t *h, uint64_t out[8]) {
+    HIPCHK(hipDeviceSynchronize());
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (auto &E : h->slot) {
+        if (!E.dEStat.p || !E.statZeroed) continue;
+        unsigned long long t[8];
+        HIPCHK(hipMemcpy(t, E.dEStat.p, sizeof t, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; k++) out[k] += t[k];
+    }
+    return SWSEM_OK;
+}
+
 #ifdef SWSEM_DIAG_PHASES
 // diagnostics build only: phase sums of every resolve launch since the last call (g_diag), then reset
 int swsem_debug_phases(swsem_t *h, uint64_t *out) {
@@ -1380,7 +1404,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     std::vector<int> &which = E.ewhich;       // uploaded asynchronously: must outlive this call
     which.assign(n, 0);
     uint64_t rows = 0, arena = 0;
-    E.chunkOwner.clear();
+    E.chunkOwner.clear(); E.spanOwner.clear();
     for (int k = 0; k < n; k++) {
         const int c = contigIdx ? contigIdx[k] : k;
         if (c < 0 || c >= (int) h->contigs.size()) return fail(SWSEM_EINVAL, "swsem_emit: no contig %d in the batch", c);
@@ -1397,13 +1421,15 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         rows += e.cap;
         e.chunk0 = (uint32_t) E.chunkOwner.size();
         E.chunkOwner.insert(E.chunkOwner.end(), (e.cap + CH - 1) / CH, (uint32_t) k);
+        e.span0 = (uint32_t) E.spanOwner.size();
+        E.spanOwner.insert(E.spanOwner.end(), (e.cap + MSPAN - 1) / MSPAN, (uint32_t) k);
         e.factor = factor ? factor[k] : 128;
         e.processed = processed ? processed[k] : 0;
         e.targetIdx = targetIdx ? targetIdx[k] : 0;
         const uint64_t szs[SWSEM_NSTREAMS] = {cg.n + nm + 16, 4 * nm + 16, nm + 16, 14 * nm + 16, nm + 16, cg.n + 2 * nm + 16};
         for (int st = 0; st < SWSEM_NSTREAMS; st++) { e.streamBase[st] = arena; arena += (szs[st] + 15) & ~15ull; }
     }
-    const uint32_t chunks = (uint32_t) E.chunkOwner.size();
+    const uint32_t chunks = (uint32_t) E.chunkOwner.size(), spans = (uint32_t) E.spanOwner.size();
     h->capN = std::max<uint64_t>(h->capN, (uint64_t) n); h->capRows = std::max(h->capRows, rows); h->capArena = std::max(h->capArena, arena);
     if (nLoaded + 1 > h->capLoaded) h->capLoaded = std::max<uint64_t>(4096, 2 * (nLoaded + 1));   // (regrowing a buffer waits for the whole device: rarely)
     h->capChunks = std::max<uint64_t>(h->capChunks, chunks);
@@ -1413,11 +1439,13 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
             (r = E.dENext0.reserve(R)) || (r = E.dERm.reserve(R)) ||
             (r = E.dEKeep.reserve(R)) || (r = E.dEMeta.reserve(R)) || (r = E.dECorr.reserve(R)) ||
             (r = E.dESz.reserve(R * 6)) || (r = E.dEOfs.reserve(R * 6)) || (r = E.dEArena.reserve(A)) || (r = E.dELoaded.reserve(h->capLoaded)) ||
-            (r = E.dEStat.reserve(8)) || (r = E.dEOwner.reserve(Cn)) || (r = E.dEStates.reserve((size_t) Cn * 2)) || (r = E.dEChunk.reserve((size_t) Cn * 6)) ||
+            (r = E.dEStat.reserve(8)) || (r = E.dEPm.reserve(R)) || (r = E.dELit.reserve((size_t) Cn * (CH / WAVE))) || (r = E.dEBad.reserve(Cn)) || (r = E.dEOwner.reserve(Cn)) || (r = E.dESpanOwner.reserve(Cn)) || (r = E.dEStates.reserve((size_t) Cn * (CH / MB) * 2)) || (r = E.dEChunk.reserve((size_t) Cn * 6)) ||
             (r = E.dEPack.reserve((size_t) N * SWSEM_NSTREAMS)))
             return r;
     }
+    if (!E.statZeroed) { HIPCHK(hipMemsetAsync(E.dEStat.p, 0, 8 * sizeof(unsigned long long), h->stream)); E.statZeroed = true; }
     if ((r = upload(h, E.dEOwner.p, E.chunkOwner.data(), chunks * sizeof(uint32_t), h->stream))) return r;
+    if ((r = upload(h, E.dESpanOwner.p, E.spanOwner.data(), spans * sizeof(uint32_t), h->stream))) return r;
     if ((r = upload(h, E.dECg.p, E.ecg.data(), n * sizeof(EmitContig), h->stream)) || (r = upload(h, E.dEWhich.p, which.data(), n * sizeof(int), h->stream))) return r;
     E.eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
     if ((r = upload(h, E.dELoaded.p, E.eloaded.data(), nLoaded * sizeof(uint64_t), h->stream))) return r;
@@ -1434,9 +1462,10 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     v.em = E.dEM.p; v.next0 = E.dENext0.p; v.removed = E.dERm.p; v.keepIdx = E.dEKeep.p;
     v.meta = E.dEMeta.p; v.corr = E.dECorr.p; v.sz = E.dESz.p; v.arena = E.dEArena.p; v.out = E.dEOut.p;
     v.packBase = E.dEPack.p;
+    v.pairMask = E.dEPm.p; v.litBits = E.dELit.p; v.metaBad = E.dEBad.p;
     v.ofs = E.dEOfs.p;
     v.chunkCnt = E.dEChunk.p;
-    v.chunkOwner = E.dEOwner.p;
+    v.chunkOwner = E.dEOwner.p; v.spanOwner = E.dESpanOwner.p;
     v.ncontigs = (uint32_t) n;
     const dim3 grid2(chunks);
     h->mark(SWSEM_K_EMIT, true);
@@ -1462,12 +1491,14 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     }
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
     h->mark(SWSEM_K_EMIT2, true, h->stream2);
-    k_emit_meta_blocks<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p);
+    k_emit_meta_masks<<<dim3(spans), dim3(MLANES), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_meta_spec<<<dim3(spans), dim3(MLANES), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, h->metaWarm, E.dEStat.p);
     // (the next batch's resolve is launched behind this kernel, run_batch: a launch of thousands of waves that is still
     // running takes the slots the resolve's blocks are sized for, and the blocks that have to wait double its time)
     if (!h->evMeta) HIPCHK(hipEventCreateWithFlags(&h->evMeta, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->evMeta, h->stream2));
     h->metaPending = true;
+    k_emit_meta_check<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
     k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
