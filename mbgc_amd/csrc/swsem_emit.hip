@@ -222,14 +222,9 @@ __global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitCo
         while (d - 1 >= 0 && s - 1 >= 0 && q[d - 1] == v.ref[s - 1]) { d--; s--; x++; }
         e.posSrc -= x; e.posDest -= x; e.len += x;               // shiftStartPos(-leftExtension)
     }
-    e.lp = v.p.lazyDecompressionSupport ? loaded_pos(v, e.posSrc) : 0;
+    e.lp = 0;                                                     // (k_emit_meta_regions: nothing in this pass asks for it)
     v.em[cg.scratchBase + t] = e;
     v.keepIdx[cg.scratchBase + t] = (uint32_t) j;
-    if (v.p.lazyDecompressionSupport) {                           // std::upper_bound, :254-256
-        uint32_t lo = 0, hi = v.nLoaded;
-        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (v.loaded[mid] <= e.lp) lo = mid + 1; else hi = mid; }
-        v.next0[cg.scratchBase + t] = lo == v.nLoaded ? UINT64_MAX : v.loaded[lo];
-    }
 }
 
 // (e) unmatchedChars / totalMatched with the reference's integer types (uint32 pos, :145,:193-196): per-chunk
@@ -512,6 +507,25 @@ __device__ __forceinline__ MetaSpan meta_span(const EmitView &v, const EmitConti
     sp.B0 = (int) (blockIdx.x - cgs[sp.gk].span0) * MSPAN;
     sp.live = o.unmatchedChars != UINT64_MAX && sp.B0 < sp.n;
     return sp;
+}
+
+// the source region of every kept match: getMatchLoadedPos (:137-141) and the loading position of the region behind it
+// (std::upper_bound, :254-256) — what the pairing chain's lazy-decompression rule compares. Off pass 1's path: the
+// extension policy does not wait for a binary search per match.
+__global__ void __launch_bounds__(CH) k_emit_meta_regions(EmitView v, const EmitContig *__restrict__ cgs) {
+    if (!v.p.lazyDecompressionSupport) return;
+    const uint32_t gk = v.chunkOwner[blockIdx.x];
+    const EmitContig cg = cgs[gk];
+    const uint32_t gx = blockIdx.x - cg.chunk0;
+    const EmitOut o = v.out[gk];
+    if (o.unmatchedChars == UINT64_MAX) return;
+    const uint64_t t = (uint64_t) gx * CH + threadIdx.x;
+    if (t >= o.nmatches) return;
+    const uint64_t lp = loaded_pos(v, v.em[cg.scratchBase + t].posSrc);
+    v.em[cg.scratchBase + t].lp = lp;
+    uint32_t lo = 0, hi = v.nLoaded;
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (v.loaded[mid] <= lp) lo = mid + 1; else hi = mid; }
+    v.next0[cg.scratchBase + t] = lo == v.nLoaded ? UINT64_MAX : v.loaded[lo];
 }
 
 // look-ahead masks of a span's matches: bit g-1 of match m = match m+g is within the depth, pairedWith m

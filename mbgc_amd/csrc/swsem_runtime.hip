@@ -1491,6 +1491,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     }
     HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
     h->mark(SWSEM_K_EMIT2, true, h->stream2);
+    k_emit_meta_regions<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
     k_emit_meta_masks<<<dim3(spans), dim3(MLANES), 0, h->stream2>>>(v, E.dECg.p);
     k_emit_meta_spec<<<dim3(spans), dim3(MLANES), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, h->metaWarm, E.dEStat.p);
     // (the next batch's resolve is launched behind this kernel, run_batch: a launch of thousands of waves that is still
