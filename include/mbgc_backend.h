@@ -73,6 +73,23 @@ int mbgc_backend_compress_streams(const mbgc_backend_params_t *p, const uint8_t 
                                   mbgc_leaf_compress_fn leaf, void *ctx, int threads, uint8_t **out, uint64_t *outLen);
 void mbgc_backend_free(uint8_t *p);
 
+/* The incremental form: the same section while the streams are still growing — the backend beside the matching (SURVEY.md
+ * §8(f) row 3's reason to exist). Streams are fed in any number of pieces and in any interleaving; a stream that the job
+ * table splits (ParallelBlocksCoderProps) gives up a block of `blockBytes` to the pool of `threads` coder threads as soon
+ * as more than a block has arrived, every other stream is coded at the end. The container is parallelBlocksCompress's
+ * (CodersLib.cpp:292-314) with the blocks as they were cut — other block boundaries than the reference chooses, so other
+ * bytes, and the same streams out of the reference's reader, which takes every block's length from the block's own header
+ * (parallelBlocksDecompress, CodersLib.cpp:316-345). finish() codes what is left, writes the section (malloc'd, free with
+ * mbgc_backend_free) and tells how many blocks were coded before it was called; it takes the one parameter that is only known
+ * when the matching is over (the final reference length: the 5th-byte stream is enrolled beyond 2^32, MBGC_Encoder.cpp:698-699;
+ * bytes fed for a stream that turns out not to be enrolled are dropped, as the one-shot call ignores them). close() frees the
+ * object (also without finish). */
+typedef struct mbgc_backend_stream mbgc_backend_stream_t;
+mbgc_backend_stream_t *mbgc_backend_stream_open(const mbgc_backend_params_t *p, mbgc_leaf_compress_fn leaf, void *ctx, int threads, uint64_t blockBytes);
+int mbgc_backend_stream_feed(mbgc_backend_stream_t *s, int st, const uint8_t *data, uint64_t n);
+int mbgc_backend_stream_finish(mbgc_backend_stream_t *s, uint64_t refFinalTotalLength, uint8_t **out, uint64_t *outLen, uint64_t *blocksCodedEarly);
+void mbgc_backend_stream_close(mbgc_backend_stream_t *s);
+
 #ifdef __cplusplus
 }
 #endif

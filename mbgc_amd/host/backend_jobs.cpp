@@ -3,6 +3,9 @@
 #include "../../include/mbgc_backend.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -121,8 +124,32 @@ bool leafCompress(const Ctx &x, const mbgc_leaf_coder_t &c, const uint8_t *src, 
 
 bool compress(const Ctx &x, Job &j, bool inBlocks);
 
+// header + payload of one compressed job, writeHeader (CodersLib.cpp:202-218) + the bytes; a job that does not shrink is stored raw
+void writeJob(Sink &out, Job &j) {
+    if (j.n == 0) { out.put<uint64_t>(0); return; }
+    const size_t destLen = j.packed.size();
+    out.put<uint64_t>(j.n);
+    if (j.coder.compound && !j.coder.blocks) {
+        out.put<uint64_t>(destLen + 17);                                // + primaryCoder->getHeaderLen()
+        out.put<uint8_t>(MBGC_COMPOUND_CODER);
+        out.put<uint64_t>(j.compLen);
+        out.put<uint8_t>(j.compLen == j.n ? MBGC_NO_CODER : (uint8_t) j.coder.primary.coder);
+        out.put<uint64_t>(j.compLen);                                   // the secondary coder's own header over the primary's output
+        if (destLen >= j.compLen) { out.put<uint64_t>(j.compLen); out.put<uint8_t>(MBGC_NO_CODER); }
+        else { out.put<uint64_t>(destLen); out.put<uint8_t>((uint8_t) j.coder.leaf.coder); }
+    } else if (destLen >= j.n) {
+        out.put<uint64_t>(j.n); out.put<uint8_t>(MBGC_NO_CODER);
+    } else {
+        out.put<uint64_t>(destLen);
+        out.put<uint8_t>(j.coder.blocks ? (uint8_t) MBGC_PARALLEL_BLOCKS_CODER : (uint8_t) j.coder.leaf.coder);
+    }
+    if (destLen < j.n) out.put((const uint8_t *) j.packed.data(), destLen);
+    else out.put(j.src, j.n);
+    j.packed.clear(); j.packed.shrink_to_fit();
+}
+
 // CompressionJob::writeCompressedCollectiveParallel, CodersLib.cpp:372-415: every job compressed (in parallel), then
-// header + payload per job in order; a job that does not shrink is stored raw
+// header + payload per job in order
 bool collective(const Ctx &x, std::vector<Job> &jobs, Sink &out, int threads) {
     std::atomic<size_t> next{0};
     auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < jobs.size();) if (jobs[i].n) jobs[i].failed = !compress(x, jobs[i], false); };
@@ -131,30 +158,8 @@ bool collective(const Ctx &x, std::vector<Job> &jobs, Sink &out, int threads) {
     for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
     work();
     for (auto &t : pool) t.join();
-    for (Job &j : jobs) {
-        if (j.failed) return false;
-        if (j.n == 0) { out.put<uint64_t>(0); continue; }
-        const size_t destLen = j.packed.size();
-        // writeHeader, CodersLib.cpp:202-218
-        out.put<uint64_t>(j.n);
-        if (j.coder.compound && !j.coder.blocks) {
-            out.put<uint64_t>(destLen + 17);                                // + primaryCoder->getHeaderLen()
-            out.put<uint8_t>(MBGC_COMPOUND_CODER);
-            out.put<uint64_t>(j.compLen);
-            out.put<uint8_t>(j.compLen == j.n ? MBGC_NO_CODER : (uint8_t) j.coder.primary.coder);
-            out.put<uint64_t>(j.compLen);                                   // the secondary coder's own header over the primary's output
-            if (destLen >= j.compLen) { out.put<uint64_t>(j.compLen); out.put<uint8_t>(MBGC_NO_CODER); }
-            else { out.put<uint64_t>(destLen); out.put<uint8_t>((uint8_t) j.coder.leaf.coder); }
-        } else if (destLen >= j.n) {
-            out.put<uint64_t>(j.n); out.put<uint8_t>(MBGC_NO_CODER);
-        } else {
-            out.put<uint64_t>(destLen);
-            out.put<uint8_t>(j.coder.blocks ? (uint8_t) MBGC_PARALLEL_BLOCKS_CODER : (uint8_t) j.coder.leaf.coder);
-        }
-        if (destLen < j.n) out.put((const uint8_t *) j.packed.data(), destLen);
-        else out.put(j.src, j.n);
-        j.packed.clear(); j.packed.shrink_to_fit();
-    }
+    for (Job &j : jobs) if (j.failed) return false;
+    for (Job &j : jobs) writeJob(out, j);
     return true;
 }
 
@@ -191,6 +196,54 @@ bool compress(const Ctx &x, Job &j, bool inBlocks) {
     return leafCompress(x, j.coder.leaf, j.src, j.n, j.packed);
 }
 
+
+// ---- the incremental form: blocks of the split streams are coded while the streams still grow ---------------------------
+struct Piece { std::string raw; Job job; };
+
+}  // namespace
+
+struct mbgc_backend_stream {
+    mbgc_backend_params_t p{};
+    Ctx x{};
+    uint64_t blockBytes = 0;
+    struct St { bool enrolled = false; Coder coder; std::string pending; uint64_t total = 0; std::deque<std::unique_ptr<Piece>> pieces; } st[MBGC_ST_COUNT];
+    std::mutex mu;
+    std::condition_variable cv, idle;
+    std::deque<Piece *> queue;
+    size_t running = 0, codedEarly = 0;
+    bool closing = false, failed = false, finishing = false;
+    std::vector<std::thread> pool;
+
+    void work() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return closing || !queue.empty(); });
+            if (queue.empty()) return;
+            Piece *pc = queue.front();
+            queue.pop_front();
+            running++;
+            lk.unlock();
+            const bool ok = compress(x, pc->job, true);                // (a block is coded by the stream's coder itself, CodersLib.cpp:300-306)
+            lk.lock();
+            running--;
+            if (!ok) failed = true;
+            if (!finishing) codedEarly++;
+            if (queue.empty() && running == 0) idle.notify_all();
+        }
+    }
+    void enqueue(St &t, std::string &&raw) {                            // mu held
+        t.pieces.emplace_back(new Piece());
+        Piece *pc = t.pieces.back().get();
+        pc->raw = std::move(raw);
+        Coder inner = t.coder;
+        inner.blocks = 0;
+        pc->job = Job{(const uint8_t *) pc->raw.data(), pc->raw.size(), inner};
+        queue.push_back(pc);
+        cv.notify_one();
+    }
+};
+
+namespace {
 }  // namespace
 
 extern "C" {
@@ -227,5 +280,83 @@ int mbgc_backend_compress_streams(const mbgc_backend_params_t *p, const uint8_t 
 }
 
 void mbgc_backend_free(uint8_t *p) { free(p); }
+
+mbgc_backend_stream_t *mbgc_backend_stream_open(const mbgc_backend_params_t *p, mbgc_leaf_compress_fn leaf, void *ctx, int threads, uint64_t blockBytes) {
+    if (!p || !leaf) { fail("mbgc_backend_stream_open: null argument"); return nullptr; }
+    if (blockBytes < (1u << 20) || blockBytes % 16) { fail("mbgc_backend_stream_open: blocks are multiples of 16 bytes, 2^20 at least (CodersLib.h:163-171)"); return nullptr; }
+    auto *s = new mbgc_backend_stream();
+    s->p = *p;
+    s->x = Ctx{leaf, ctx, 1};
+    s->blockBytes = blockBytes;
+    for (int st = 0; st < MBGC_ST_COUNT; st++) s->st[st].enrolled = jobFor(*p, st, s->st[st].coder);
+    for (int t = 0; t < (threads > 0 ? threads : 1); t++) s->pool.emplace_back([s] { s->work(); });
+    return s;
+}
+
+int mbgc_backend_stream_feed(mbgc_backend_stream_t *s, int st, const uint8_t *data, uint64_t n) {
+    if (!s || st < 0 || st >= MBGC_ST_COUNT || (n && !data)) return fail("mbgc_backend_stream_feed: bad argument");
+    auto &t = s->st[st];
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->finishing) return fail("mbgc_backend_stream_feed: the section is being written");
+    t.pending.append((const char *) data, n);
+    t.total += n;
+    // a split stream gives up a block as soon as more than a block is waiting (the rest stays: the last block is what is left)
+    while (t.coder.blocks && t.pending.size() > s->blockBytes) {
+        std::string rest = t.pending.substr(s->blockBytes);
+        t.pending.resize(s->blockBytes);
+        s->enqueue(t, std::move(t.pending));
+        t.pending = std::move(rest);
+    }
+    return 0;
+}
+
+int mbgc_backend_stream_finish(mbgc_backend_stream_t *s, uint64_t refFinalTotalLength, uint8_t **out, uint64_t *outLen, uint64_t *blocksCodedEarly) {
+    if (!s || !out || !outLen) return fail("mbgc_backend_stream_finish: null argument");
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        if (s->finishing) return fail("mbgc_backend_stream_finish: called twice");
+        s->finishing = true;
+        if (blocksCodedEarly) *blocksCodedEarly = s->codedEarly;
+        s->p.refFinalTotalLength = refFinalTotalLength;                 // (known when the matching is over; it decides the 5th-byte stream, :698-699)
+        for (int st = 0; st < MBGC_ST_COUNT; st++) {
+            Coder c;
+            const bool en = jobFor(s->p, st, c);
+            if (s->st[st].pieces.empty()) { s->st[st].enrolled = en; s->st[st].coder = c; }
+        }
+        for (auto &t : s->st)
+            if (t.enrolled && !t.pending.empty()) s->enqueue(t, std::move(t.pending));
+        s->idle.wait(lk, [&] { return s->queue.empty() && s->running == 0; });
+        if (s->failed) return fail("Error during compression.");
+    }
+    Sink sec;
+    for (auto &t : s->st) {
+        if (!t.enrolled) continue;
+        if (t.pieces.empty()) { sec.put<uint64_t>(0); continue; }
+        if (!t.coder.blocks) { writeJob(sec, t.pieces.front()->job); continue; }
+        // parallelBlocksCompress's container (CodersLib.cpp:292-314) over the blocks as they were cut: the reader takes every
+        // block's length from the block's own header (parallelBlocksDecompress, :316-345)
+        Sink blocks;
+        blocks.put<int32_t>((int32_t) t.pieces.size());
+        std::string whole;
+        for (auto &pc : t.pieces) { whole += pc->raw; writeJob(blocks, pc->job); }
+        Job outer{(const uint8_t *) whole.data(), whole.size(), t.coder};
+        outer.packed = std::move(blocks.s);
+        writeJob(sec, outer);
+    }
+    *out = (uint8_t *) malloc(sec.s.size() ? sec.s.size() : 1);
+    if (!*out) return fail("out of memory");
+    memcpy(*out, sec.s.data(), sec.s.size());
+    *outLen = sec.s.size();
+    return 0;
+}
+
+void mbgc_backend_stream_close(mbgc_backend_stream_t *s) {
+    if (!s) return;
+    { std::lock_guard<std::mutex> lk(s->mu); s->closing = true; s->queue.clear(); }
+    s->cv.notify_all();
+    for (auto &t : s->pool) t.join();
+    delete s;
+}
+
 
 }  // extern "C"

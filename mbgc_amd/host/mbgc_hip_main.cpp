@@ -70,7 +70,8 @@ int main(int argc, char **argv) {
     std::string transport = "rccl";
     size_t shmMb = 64;
     std::string backend;                                                        // a library with the reference's leaf coders (mbgc_leaf_compress)
-    int backendThreads = 8, backendBlocksScale = 1, coderThreads = 0;           // coderThreads: the reference's -t as the coders see it (0: the pool's size)
+    int backendThreads = 8, backendBlocksScale = 1, coderThreads = 0;
+    uint64_t backendOverlapBlock = 0;                                           // > 0: the backend runs beside the matching, blocks of this many bytes           // coderThreads: the reference's -t as the coders see it (0: the pool's size)
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "c") continue;
@@ -91,12 +92,13 @@ int main(int argc, char **argv) {
         else if (a == "--backend" && i + 1 < argc) backend = argv[++i];
         else if (a == "--backend-threads" && i + 1 < argc) backendThreads = atoi(argv[++i]);
         else if (a == "--backend-blocks" && i + 1 < argc) backendBlocksScale = atoi(argv[++i]);
+        else if (a == "--backend-overlap" && i + 1 < argc) backendOverlapBlock = (uint64_t) atoll(argv[++i]) << 20;
         else if (a == "--coder-threads" && i + 1 < argc) coderThreads = atoi(argv[++i]);
         else pos.push_back(a);
     }
     if (pos.size() != 2) {
         fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--verify | --verify-every K] [--ref-factor F] [--bench [--warmup rounds]] "
-                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T] [--backend-blocks K] [--coder-threads t]] <sequencesListFile> <outputPrefix>\n"
+                        "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T] [--backend-blocks K | --backend-overlap MiB] [--coder-threads t]] <sequencesListFile> <outputPrefix>\n"
                         "  --backend writes <outputPrefix>.collective: the collective section of the matcher-side streams (the header-side streams are the CLI's and\n"
                         "  go in empty); --coder-threads = the reference's -t as its coders see it (LZMA runs two threads when it is > 1)\n");
         return EXIT_FAILURE;
@@ -169,7 +171,23 @@ int main(int argc, char **argv) {
     };
     MultipleGenomeMatchingProcessor::bindHostThreadsToDeviceNode(params.device);
     MBGC_Encoder enc(&params);
+    mbgc_leaf_compress_fn leaf = nullptr;
+    if (!backend.empty() && rank == 0 && !params.benchMode) {
+        // the reference's unchanged PPMd7 / LZMA: a library whose symbol mbgc_leaf_compress has the callback's signature
+        void *lib = dlopen(backend.c_str(), RTLD_NOW | RTLD_LOCAL);
+        leaf = lib ? (mbgc_leaf_compress_fn) dlsym(lib, "mbgc_leaf_compress") : nullptr;
+        if (!leaf) { fprintf(stderr, "cannot load the leaf coders from %s: %s\n", backend.c_str(), dlerror()); return finish(EXIT_FAILURE); }
+        if (backendOverlapBlock) {
+            mbgc_backend_params_t bp;
+            enc.backendParams(bp, 1, coderThreads > 0 ? coderThreads : backendThreads);
+            enc.backendStream = mbgc_backend_stream_open(&bp, leaf, nullptr, backendThreads, backendOverlapBlock);
+            if (!enc.backendStream) { fprintf(stderr, "%s\n", mbgc_backend_last_error()); return finish(EXIT_FAILURE); }
+        }
+    }
+    struct timespec tEnc0, tEnc1;
+    clock_gettime(CLOCK_MONOTONIC, &tEnc0);
     enc.encode(files);
+    clock_gettime(CLOCK_MONOTONIC, &tEnc1);
     if (rank != 0) return finish(0);
     if (params.benchMode) {
         // the C++ host's own measurement of the hot path (BASELINE.json metric): inputs resident in HBM, rounds of -R targets
@@ -192,19 +210,25 @@ int main(int argc, char **argv) {
     dump(pos[1], "refExtSize", enc.refExtSizeStream);
     if (!backend.empty()) {
         // the streams through the backend's job table and container framing (include/mbgc_backend.h), entropy-coded by the
-        // library given: the reference's unchanged PPMd7 / LZMA (its symbol mbgc_leaf_compress has the callback's signature)
-        void *lib = dlopen(backend.c_str(), RTLD_NOW | RTLD_LOCAL);
-        mbgc_leaf_compress_fn leaf = lib ? (mbgc_leaf_compress_fn) dlsym(lib, "mbgc_leaf_compress") : nullptr;
-        if (!leaf) { fprintf(stderr, "cannot load the leaf coders from %s: %s\n", backend.c_str(), dlerror()); return finish(EXIT_FAILURE); }
+        // library given
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        const std::string section = enc.compressStreams(leaf, nullptr, backendThreads, backendBlocksScale, coderThreads);
+        uint64_t early = 0;
+        const std::string section = enc.backendStream ? enc.finishBackendStream(&early)
+                                                      : enc.compressStreams(leaf, nullptr, backendThreads, backendBlocksScale, coderThreads);
         clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (enc.backendStream) { mbgc_backend_stream_close(enc.backendStream); enc.backendStream = nullptr; }
         dump(pos[1], "collective", section);
         const size_t raw = enc.literals.size() + enc.rcMapOff.size() + enc.rcMapLen.size() + enc.locksPosStream.size() + enc.gapDeltas.size() +
                            enc.gapMismatchesFlags.size() + enc.mapOff.size() + enc.mapOff5thByte.size() + enc.mapLen.size() + enc.refExtSizeStream.size();
-        printf("backend: %zu stream bytes to %zu in %.0f ms (%d threads, %d x the reference's blocks)\n", raw, section.size(),
-               (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, backendThreads, std::max(1, backendBlocksScale));
+        const double ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+        if (backendOverlapBlock)
+            printf("backend: %zu stream bytes to %zu, %.0f ms after the matching's %.0f ms (%d threads, blocks of %llu MiB, %llu of them coded while the matching ran)\n",
+                   raw, section.size(), ms, (tEnc1.tv_sec - tEnc0.tv_sec) * 1e3 + (tEnc1.tv_nsec - tEnc0.tv_nsec) * 1e-6, backendThreads,
+                   (unsigned long long) (backendOverlapBlock >> 20), (unsigned long long) early);
+        else
+            printf("backend: %zu stream bytes to %zu in %.0f ms (%d threads, %d x the reference's blocks)\n", raw, section.size(), ms, backendThreads,
+                   std::max(1, backendBlocksScale));
     }
     if (params.verifyEmissions) printf("verified on the device: %llu contigs, %llu bases decoded back to their bytes\n",
                                        (unsigned long long) params.verifiedContigs, (unsigned long long) params.verifiedBases);

@@ -869,6 +869,8 @@ void MBGC_Encoder::processG0RefContig(const char *seq, size_t len) {
     literals.push_back(SEQ_SEPARATOR_MARK);
 }
 
+static const uint32_t BACKEND_FEED_EVERY = 8;                      // targets between two hand-overs to a backend that runs beside the matching
+
 static void appendStreams(MBGC_Encoder &e, const EmittedStreams &s) {
     e.literals.append(s.s[SWSEM_LIT]);
     e.mapOff.append(s.s[SWSEM_OFF]);
@@ -946,6 +948,7 @@ void MBGC_Encoder::appendContigInOrder(const swsem_streams_t &st) {
 void MBGC_Encoder::endTargetInOrder() {
     targetsAppended++;
     if (params->emit.enableExtensionsWithMismatches) gapMismatchesFlags.push_back(FILE_SEPARATOR_MARK);
+    if (backendStream && targetsAppended % BACKEND_FEED_EVERY == 0) feedBackendStream(false);
 }
 
 void MBGC_Encoder::processAfterSequence(uint32_t targetIdx) {
@@ -954,9 +957,11 @@ void MBGC_Encoder::processAfterSequence(uint32_t targetIdx) {
 }
 
 void MBGC_Encoder::processAfterTarget(uint32_t targetIdx) {
-    if (!params->emit.enableExtensionsWithMismatches) return;
-    if (params->sequentialMatching) gapMismatchesFlags.push_back(FILE_SEPARATOR_MARK);
-    else targetStreams[targetIdx].s[SWSEM_FLAGS].push_back(FILE_SEPARATOR_MARK);
+    if (params->emit.enableExtensionsWithMismatches) {
+        if (params->sequentialMatching) gapMismatchesFlags.push_back(FILE_SEPARATOR_MARK);
+        else targetStreams[targetIdx].s[SWSEM_FLAGS].push_back(FILE_SEPARATOR_MARK);
+    }
+    if (backendStream && params->sequentialMatching && ++sequentialTargetsDone % BACKEND_FEED_EVERY == 0) feedBackendStream(false);
 }
 
 void MBGC_Encoder::processAfterTargetWithParallelIO(size_t matcherLoaderStartPos) {
@@ -983,6 +988,7 @@ void MBGC_Encoder::finalizeParallelProcessingOfTarget(uint32_t targetIdx, size_t
     appendStreams(*this, targetStreams[targetIdx]);                                             // ENC.cpp:543-556
     targetStreams[targetIdx] = EmittedStreams();
     targetsAppended++;
+    if (backendStream && targetsAppended % BACKEND_FEED_EVERY == 0) feedBackendStream(false);
     if (params->lazyDecompressionSupport) {
         matcher->loadSeparator(REF_REGION_SEPARATOR);
         const size_t refExtSize = matcher->getLoadedRefLength() - matcherLoaderStartPos;
@@ -1004,6 +1010,7 @@ void MBGC_Encoder::appendTargetStreams(uint32_t targetIdx) {
     appendStreams(*this, targetStreams[targetIdx]);                                             // ENC.cpp:543-556
     targetStreams[targetIdx] = EmittedStreams();
     targetsAppended++;
+    if (backendStream && targetsAppended % BACKEND_FEED_EVERY == 0) feedBackendStream(false);
 }
 
 void MBGC_Encoder::encode(const std::vector<std::string> &files) {
@@ -1044,15 +1051,20 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
         PgTools::SimpleSequenceMatcher::rcMatchSequence(literals, rcMapOff, rcMapLen, params->rcMatchMinLength, UINT32_MAX, device);
 }
 
-std::string MBGC_Encoder::compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale, int numberOfThreads) {
-    mbgc_backend_params_t bp = {};
+void MBGC_Encoder::backendParams(mbgc_backend_params_t &bp, int blocksScale, int numberOfThreads) const {
+    bp = {};
     bp.coderMode = params->coderMode; bp.k = params->k;
     bp.enableExtensionsWithMismatches = params->emit.enableExtensionsWithMismatches;
     bp.mismatchesWithExclusion = params->emit.mismatchesWithExclusion;
     bp.sequentialMatching = params->sequentialMatching; bp.rcRedundancyRemoval = params->rcRedundancyRemoval;
     bp.frugal64bitLenEncoding = params->emit.frugal64bitLenEncoding; bp.lazyDecompressionSupport = params->lazyDecompressionSupport;
     bp.refFinalTotalLength = refFinalTotalLength; bp.blocksScale = blocksScale;
-    bp.numberOfThreads = numberOfThreads > 0 ? numberOfThreads : threads;       // PgHelpers::numberOfThreads (the reference's -t): > 1 gives LZMA two threads, PropsLibrary.cpp:9
+    bp.numberOfThreads = numberOfThreads;                                       // PgHelpers::numberOfThreads (the reference's -t): > 1 gives LZMA two threads, PropsLibrary.cpp:9
+}
+
+std::string MBGC_Encoder::compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale, int numberOfThreads) {
+    mbgc_backend_params_t bp;
+    backendParams(bp, blocksScale, numberOfThreads > 0 ? numberOfThreads : threads);
     const std::string factors((const char *) unmatchedFractionFactors.data(), unmatchedFractionFactors.size());
     const std::string *src[MBGC_ST_COUNT] = {};
     src[MBGC_ST_UNMATCHED_FRACTION_FACTORS] = &factors; src[MBGC_ST_LITERALS] = &literals; src[MBGC_ST_RC_MAP_OFF] = &rcMapOff;
@@ -1066,6 +1078,41 @@ std::string MBGC_Encoder::compressStreams(mbgc_leaf_compress_fn leaf, void *ctx,
     uint8_t *out = nullptr;
     uint64_t n = 0;
     if (mbgc_backend_compress_streams(&bp, data, size, leaf, ctx, threads, &out, &n) != 0) {
+        fprintf(stderr, "%s\n", mbgc_backend_last_error());
+        exit(EXIT_FAILURE);
+    }
+    std::string res((const char *) out, n);
+    mbgc_backend_free(out);
+    return res;
+}
+
+// what the streams have grown by since the last call (every stream at the end; while the rounds go on only those that the job
+// table splits into blocks and that nothing rewrites later)
+void MBGC_Encoder::feedBackendStream(bool everything) {
+    if (!backendStream) return;
+    const std::string factors = everything ? std::string((const char *) unmatchedFractionFactors.data(), unmatchedFractionFactors.size()) : std::string();
+    const std::string *src[MBGC_ST_COUNT] = {};
+    src[MBGC_ST_GAP_DELTAS] = &gapDeltas; src[MBGC_ST_GAP_MISMATCHES_FLAGS] = &gapMismatchesFlags; src[MBGC_ST_MAP_OFF] = &mapOff; src[MBGC_ST_MAP_LEN] = &mapLen;
+    if (!params->rcRedundancyRemoval || everything) src[MBGC_ST_LITERALS] = &literals;
+    if (everything) {
+        src[MBGC_ST_UNMATCHED_FRACTION_FACTORS] = &factors; src[MBGC_ST_RC_MAP_OFF] = &rcMapOff; src[MBGC_ST_RC_MAP_LEN] = &rcMapLen;
+        src[MBGC_ST_LOCKS_POS] = &locksPosStream; src[MBGC_ST_MAP_OFF_5TH_BYTE] = &mapOff5thByte; src[MBGC_ST_REF_EXT_SIZE] = &refExtSizeStream;
+    }
+    for (int st = 0; st < MBGC_ST_COUNT; st++) {
+        if (!src[st] || src[st]->size() <= backendFed[st]) continue;
+        if (mbgc_backend_stream_feed(backendStream, st, (const uint8_t *) src[st]->data() + backendFed[st], src[st]->size() - backendFed[st]) != 0) {
+            fprintf(stderr, "%s\n", mbgc_backend_last_error());
+            exit(EXIT_FAILURE);
+        }
+        backendFed[st] = src[st]->size();
+    }
+}
+
+std::string MBGC_Encoder::finishBackendStream(uint64_t *blocksCodedEarly) {
+    feedBackendStream(true);
+    uint8_t *out = nullptr;
+    uint64_t n = 0;
+    if (mbgc_backend_stream_finish(backendStream, refFinalTotalLength, &out, &n, blocksCodedEarly) != 0) {
         fprintf(stderr, "%s\n", mbgc_backend_last_error());
         exit(EXIT_FAILURE);
     }

@@ -170,6 +170,8 @@ class MBGC_Encoder : public MultipleGenomeMatchingProcessor {
     std::vector<size_t> refExtLoadedPosArr;                                             // MBGC_Encoder.h:48
     std::vector<EmittedStreams> targetStreams;                                          // per-target streams (round mode)
     uint32_t targetsAppended = 0;                                                       // targets whose streams arrived in order
+    uint32_t sequentialTargetsDone = 0;
+    size_t backendFed[MBGC_ST_COUNT] = {};                                              // bytes of every stream the backend has been handed
 
     void initStreamsForG0Ref() override;                                                // ENC.cpp:25-32
     void processG0RefContig(const char *seq, size_t len) override;                      // :34-37
@@ -204,6 +206,14 @@ public:
     // The header-side streams (names, sequence counts, header templates, headers, line lengths) are the CLI's and go in empty:
     // the section is what the reference's reader takes for the matcher-side streams, not a complete archive.
     std::string compressStreams(mbgc_leaf_compress_fn leaf, void *ctx, int threads, int blocksScale = 1, int numberOfThreads = 0);
+    // The backend beside the matching (include/mbgc_backend.h, the incremental form): set before encode(), the encoder hands
+    // over what its streams have grown by every few targets, so that the blocks of the split streams are coded while the rounds
+    // go on; finishBackendStream() hands over the rest and returns the section. The literals wait for the end under -m3 (the
+    // reverse-complement pass rewrites them, ENC.cpp:636-638).
+    mbgc_backend_stream_t *backendStream = nullptr;
+    void feedBackendStream(bool everything);
+    std::string finishBackendStream(uint64_t *blocksCodedEarly);
+    void backendParams(mbgc_backend_params_t &bp, int blocksScale, int numberOfThreads) const;
     size_t exactMatches() const { return resCount; }
     size_t finalReferenceLength() const { return refFinalTotalLength; }          // writeStats' refFinalTotalLength, ENC.cpp:734-743
     size_t droppedExtensionBytes() const { return matcher ? matcher->getDroppedBytes() : 0; }

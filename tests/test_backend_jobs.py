@@ -177,3 +177,93 @@ def test_job_table_query():
     assert (blocks.value, leaf.coder, leaf.lp, leaf.pb, leaf.fb, leaf.numThreads) == (5, 1, 1, 1, 128, 2)
     assert L.mbgc_backend_job(C.byref(p), 7, None, None, None) == -1                                       # rc streams: -m3 only
     assert L.mbgc_backend_job(C.byref(p), 13, None, None, None) == -1                                      # 5th byte: beyond 2^32 only
+
+
+def _params(mode, flags, ref_total=1 << 31, threads=1):
+    return Params(coderMode=mode, ultraStreamsCompression=flags & 1, k=32, enableExtensionsWithMismatches=1,
+                  mismatchesWithExclusion=0 if mode == 0 else 1, sequentialMatching=1 if flags & 4 or mode == 3 else 0,
+                  rcRedundancyRemoval=1 if mode == 3 else 0, frugal64bitLenEncoding=0 if mode == 0 else 1,
+                  lazyDecompressionSupport=1 if flags & 2 else 0, refFinalTotalLength=ref_total, numberOfThreads=threads, blocksScale=0)
+
+
+def _stream_api(L):
+    L.mbgc_backend_stream_open.restype = C.c_void_p
+    L.mbgc_backend_stream_open.argtypes = [C.POINTER(Params), LEAF_FN, C.c_void_p, C.c_int, C.c_uint64]
+    L.mbgc_backend_stream_feed.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64]
+    L.mbgc_backend_stream_finish.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mbgc_backend_stream_close.argtypes = [C.c_void_p]
+
+
+def fed_in_pieces(L, p, streams, block_bytes, threads, piece, ref_total, seed=1, linger=0.0):
+    """every stream handed over `piece` bytes at a time, the streams taking turns at random; -> section, blocks coded before finish"""
+    _stream_api(L)
+    cb, _ = reference_leaf()
+    h = L.mbgc_backend_stream_open(C.byref(p), cb, None, threads, block_bytes)
+    assert h, L.mbgc_backend_last_error()
+    rng = np.random.default_rng(seed)
+    at = [0] * NST
+    live = [st for st in range(NST) if len(streams[st])]
+    while live:
+        st = live[int(rng.integers(0, len(live)))]
+        chunk = streams[st][at[st]: at[st] + piece]
+        assert L.mbgc_backend_stream_feed(h, st, chunk, len(chunk)) == 0, L.mbgc_backend_last_error()
+        at[st] += len(chunk)
+        if at[st] >= len(streams[st]):
+            live.remove(st)
+    if linger:                                                      # (the matching that is still going on)
+        import time
+        time.sleep(linger)
+    out, n, early = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    assert L.mbgc_backend_stream_finish(h, C.c_uint64(ref_total), C.byref(out), C.byref(n), C.byref(early)) == 0, L.mbgc_backend_last_error()
+    section = C.string_at(out, n.value)
+    L.mbgc_backend_free(out)
+    L.mbgc_backend_stream_close(h)
+    return section, early.value
+
+
+def read_back(section, streams, enrolled):
+    R = _refh.lib()
+    R.refbk_read_collective.restype = C.c_uint64
+    sizes = (C.c_uint64 * len(enrolled))()
+    cap = sum(len(x) for x in streams) + 64
+    buf = C.create_string_buffer(cap)
+    total = R.refbk_read_collective(section, C.c_uint64(len(section)), len(enrolled), sizes, buf, C.c_uint64(cap))
+    assert total <= cap
+    at = 0
+    for st, n in zip(enrolled, sizes):
+        assert buf.raw[at: at + n] == streams[st], st
+        at += n
+
+
+def test_streams_fed_piece_by_piece_below_one_block_give_the_references_section():
+    """the incremental form (the backend beside the matching): with every stream below one block nothing is cut and the
+    section is the reference's own, byte for byte — fed in 100 kB pieces, streams interleaved"""
+    L = host()
+    streams = synthetic_streams(5, 0.15)
+    ref, mine, _ = both(L, 1, 2, streams)
+    assert mine == ref
+    fed = list(streams)
+    fed[2] = streams[2] + b"\xbb"
+    section, early = fed_in_pieces(L, _params(1, 2), fed, 1 << 20, 2, 100_000, 1 << 31)
+    assert section == ref and early == 0
+
+
+@pytest.mark.parametrize("mode,flags,threads", [(1, 2, 3), (0, 2, 1), (3, 2 | 4, 2)])
+def test_blocks_cut_while_the_streams_grow_are_read_back_by_the_references_reader(mode, flags, threads):
+    """streams of several blocks, cut at 1 MiB as they arrive and coded by the pool while the feeding goes on: other block
+    boundaries than the reference's parallelBlocksCompress chooses, the same streams out of its reader; the 5th-byte stream
+    is fed and only enrolled by what finish() is told (beyond 2^32)"""
+    L = host()
+    streams = synthetic_streams(13 + mode, 0.8)
+    fed = list(streams)
+    fed[2] = streams[2] + b"\xbb"
+    if mode == 3:
+        import _orc
+        fed[6], fed[7], fed[8], _ = _orc.rc_match_sequence(np.frombuffer(streams[6], dtype=np.uint8), 55)
+    for ref_total in (1 << 31, (1 << 32) + 9):
+        section, early = fed_in_pieces(L, _params(mode, flags, threads=threads), fed, 1 << 20, threads, 300_000, ref_total, linger=1.5)
+        enrolled = [st for st in range(NST) if (st not in (7, 8) or mode == 3) and (st != 13 or ref_total > 0xFFFFFFFF)]
+        read_back(section, fed, enrolled)
+        ref, one_shot, _ = both(L, mode, flags, streams, threads=threads, ref_total=ref_total)
+        assert one_shot == ref and section != ref and abs(len(section) - len(ref)) < 0.03 * len(ref)
+        assert early > 0                                                       # (blocks were done before the end)

@@ -8,6 +8,7 @@ import hashlib
 import json
 import lzma
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -211,6 +212,51 @@ def test_backend_section_is_read_back_by_the_reference(tmp_path, blocks):
             assert got == bytes([128, 8] * 3)                           # one pair per file in the -t1 schedule (MGMP.cpp:252-255)
         else:
             assert got == (tmp_path / ("lm." + name)).read_bytes(), name
+
+
+def test_backend_beside_the_matching_is_read_back_by_the_reference(tmp_path):
+    """`--backend-overlap 1`: the incremental form of include/mbgc_backend.h under the round loop — blocks of 1 MiB of the
+    split streams handed to the coder threads every eight targets while the rounds go on; the reference's reader gives back
+    the streams the same run dumps"""
+    import ctypes as C
+    import _refh
+    if not _refh.available():
+        pytest.skip("oracle/_ref not built")
+    base = synth.base_codes(1_500_000, 91)
+    names = []
+    for i in range(33):
+        p = tmp_path / ("g%02d.fa" % i)
+        p.write_bytes(synth.fasta_bytes(synth.genome(base, i, 0.03), i))
+        names.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    out = run_tool(["c", "-R", "4", "--backend", os.path.join(ROOT, "oracle", "_ref", "libmbgc_coders.so"), "--backend-threads", "4",
+                    "--backend-overlap", "1", "list.txt", "ov"], str(tmp_path))
+    m = re.search(r"blocks of 1 MiB, (\d+) of them coded while the matching ran", out)
+    assert m, out
+    section = (tmp_path / "ov.collective").read_bytes()
+    R = _refh.lib()
+    order = [None, None, None, None, None, "factors", "literals", "locksPos", "gapDelta", "flags", "mapOff", "mapLen", "refExtSize"]
+    sizes = (C.c_uint64 * len(order))()
+    cap = 64 << 20
+    buf = C.create_string_buffer(cap)
+    R.refbk_read_collective.restype = C.c_uint64
+    total = R.refbk_read_collective(section, C.c_uint64(len(section)), len(order), sizes, buf, C.c_uint64(cap))
+    assert total <= cap
+    at = 0
+    for name, n in zip(order, sizes):
+        got = buf.raw[at: at + n]
+        at += n
+        if name is None:
+            assert n == 0
+        elif name != "factors":
+            assert got == (tmp_path / ("ov." + name)).read_bytes(), name
+    assert len((tmp_path / "ov.literals").read_bytes()) > (2 << 20)          # (more than one block of literals)
+    plain = run_tool(["c", "-R", "4", "--backend", os.path.join(ROOT, "oracle", "_ref", "libmbgc_coders.so"), "--backend-threads", "4", "list.txt", "pl"],
+                     str(tmp_path))
+    assert "backend:" in plain
+    for name in order:
+        if name and name != "factors":
+            assert (tmp_path / ("pl." + name)).read_bytes() == (tmp_path / ("ov." + name)).read_bytes(), name
 
 
 def test_rounds_of_a_larger_collection_equal_the_oracle_loop(tmp_path):
