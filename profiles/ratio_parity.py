@@ -38,18 +38,22 @@ wall = time.time() - t0
 size = os.path.getsize(os.path.join(d, "ref.mbgc")) if r.returncode == 0 else None
 out["reference"] = dict(command="mbgc c -m1 (all hardware threads)", rc=r.returncode, wall_s=round(wall, 2), archive_bytes=size,
                         bases_per_byte=round(bases / size, 2) if size else None)
-for key, blocks, th in (("this_repo", "1", threads), ("this_repo_8x_blocks", "8", "64")):
+for key, blocks, th in (("this_repo", "1", threads), ("this_repo_8x_blocks", "8", "64"), ("this_repo_backend_beside_the_matching_16MiB_blocks", "overlap", "64"),
+                        ("this_repo_backend_beside_the_matching_4MiB_blocks", "overlap4", "64")):
     t0 = time.time()
-    r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c", "--backend", os.path.join(REF, "libmbgc_coders.so"), "--backend-threads", th,
-                        "--backend-blocks", blocks, os.path.join(d, "list.txt"), os.path.join(d, "hip")], capture_output=True, text=True)
+    how = ["--backend-blocks", blocks] if not blocks.startswith("overlap") else ["--backend-overlap", "16" if blocks == "overlap" else "4"]
+    r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c", "--backend", os.path.join(REF, "libmbgc_coders.so"), "--backend-threads", th] + how +
+                       [os.path.join(d, "list.txt"), os.path.join(d, "hip")], capture_output=True, text=True)
     wall = time.time() - t0
-    m = re.search(r"backend: (\d+) stream bytes to (\d+) in (\d+) ms", r.stdout)
+    m = re.search(r"backend: (\d+) stream bytes to (\d+)(?: in|,) (\d+) ms", r.stdout)
+    early = re.search(r"(\d+) of them coded while the matching ran", r.stdout)
     mm = re.search(r"matching finished - (\d+) \[ms\]", r.stderr)
     sec = int(m.group(2)) if m else None
-    out[key] = dict(command="mbgc-hip c --backend <the reference's leaf coders, oracle/_ref/libmbgc_coders.so> --backend-threads %s --backend-blocks %s" % (th, blocks), rc=r.returncode,
+    out[key] = dict(command="mbgc-hip c --backend <the reference's leaf coders, oracle/_ref/libmbgc_coders.so> --backend-threads %s %s" % (th, " ".join(how)), rc=r.returncode,
                     wall_s=round(wall, 2), matching_ms=int(mm.group(1)) if mm else None, stream_bytes=int(m.group(1)) if m else None,
                     collective_section_bytes=sec, backend_ms=int(m.group(3)) if m else None, bases_per_byte=round(bases / sec, 2) if sec else None,
-                    section_over_reference_archive=round(sec / size, 4) if size and sec else None)
+                    section_over_reference_archive=round(sec / size, 4) if size and sec else None,
+                    **({"blocks_coded_while_the_matching_ran": int(early.group(1))} if early else {}))
     if r.returncode:
         sys.stderr.write(r.stderr[-800:])
 out["note"] = ("the section holds the match / literal streams; the file-name, header and line-length streams (a few KB for this collection) and the "
