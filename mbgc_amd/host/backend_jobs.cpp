@@ -301,11 +301,10 @@ int mbgc_backend_stream_feed(mbgc_backend_stream_t *s, int st, const uint8_t *da
     t.pending.append((const char *) data, n);
     t.total += n;
     // a split stream gives up a block as soon as more than a block is waiting (the rest stays: the last block is what is left)
-    while (t.coder.blocks && t.pending.size() > s->blockBytes) {
-        std::string rest = t.pending.substr(s->blockBytes);
-        t.pending.resize(s->blockBytes);
-        s->enqueue(t, std::move(t.pending));
-        t.pending = std::move(rest);
+    if (t.coder.blocks && t.pending.size() > s->blockBytes) {
+        size_t at = 0;
+        for (; t.pending.size() - at > s->blockBytes; at += s->blockBytes) s->enqueue(t, t.pending.substr(at, s->blockBytes));
+        t.pending.erase(0, at);
     }
     return 0;
 }
