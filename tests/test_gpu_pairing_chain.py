@@ -112,3 +112,26 @@ def test_boundaries_inherited_across_source_regions(binding, ndiag, given_up):
     assert st["foreign_boundary_steps"] > 20, st
     # (a chain that carries a foreign boundary carries it on for good: a warm-up that starts behind the crossing cannot know it)
     assert (st["blocks_given_up"] > 0) == given_up and st["groups_replayed"] > 0, st
+
+
+@pytest.mark.parametrize("depth,depth_mism,lazy,ext,warm", [(64, 2, 1, 1, 64), (33, 5, 1, 1, 0), (7, 1, 0, 1, 64), (1, 0, 1, 1, 0), (0, 2, 1, 1, 64),
+                                                            (64, 2, 0, 0, 0), (64, 64, 1, 1, 8), (2, 2, 0, 1, 64)])
+def test_gap_depths_other_than_the_presets(binding, monkeypatch, depth, depth_mism, lazy, ext, warm):
+    """gapDepthOffsetEncoding / gapDepthMismatchesEncoding away from MBGC's 64 / 2 (MBGC_Params.h:51-52), with and without lazy
+    decompression and extensions, on genomes with duplications, moves and inversions (several diagonals interleaved)"""
+    from test_gpu_fuzz import mutate
+    monkeypatch.setenv("SWSEM_META_WARM", str(warm))
+    rng = np.random.default_rng(1000 * depth + 10 * depth_mism + lazy)
+    base = synth.ACGT[rng.integers(0, 4, 120_000)]
+    gs = [base] + [mutate(rng, base, sub=0.012, n_events=25) for _ in range(4)]
+    files = [[g[: g.size // 3], g[g.size // 3:]] for g in gs]
+    lim, _ = _driver.ref_length_limit(len(files), 120_000)
+    over = dict(lazyDecompressionSupport=lazy, enableExtensionsWithMismatches=ext, gapDepthOffsetEncoding=depth, gapDepthMismatchesEncoding=depth_mism)
+    h = binding.SlidingWindowSparseEMMatcher(lim)
+    o = _orc.OracleMatcher(lim)
+    he = HipEmitter(binding, h, binding.emit_params(1, **over))
+    oe = _orc.OracleEmitter(o, _orc.emit_params(1, **over))
+    _driver.encode_sequential(h, he, files, lazy=bool(lazy))
+    _driver.encode_sequential(o, oe, files, lazy=bool(lazy))
+    compare(he.streams(), oe.streams())
+    assert len(oe.streams()["mapLen"]) > 2000
