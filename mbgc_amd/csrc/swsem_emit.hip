@@ -6,9 +6,9 @@
 //                 locally computable predicate, so it is resolved per run of that predicate; the kept
 //                 rows are compacted and unmatchedChars / totalMatched reduced.      [1024 threads/contig]
 //   k_emit_meta_* the pairing ring, gap deltas and gap bookkeeping (:229-278) — a chain over matches
-//                 that never looks at sequence bytes; the 64-deep look-ahead of one match is evaluated
-//                 by the 64 lanes of a wave at once, blocks of matches run speculatively in parallel
-//                 and are stitched with the true state.                          [one wave/256 matches]
+//                 that never looks at sequence bytes. The 64-deep look-ahead of every match is a mask made
+//                 lane-parallel from keys in LDS; the chain itself runs one LANE per block of 16 matches,
+//                 speculatively, and is stitched with the true state.        [256 blocks/workgroup]
 //   k_emit_sizes / k_emit_place / k_emit_write
 //                 everything that touches bytes is local to the gap between two consecutive matches:
 //                 right extension of the left match, then left extension of the right match, then the

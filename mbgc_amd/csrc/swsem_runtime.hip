@@ -203,7 +203,7 @@ struct swsem {
     hipStream_t stream2 = nullptr;
     hipEvent_t evP1 = nullptr;
     hipEvent_t evFin = nullptr;            // behind the speculative finalize (see emit_begin_impl)
-    hipEvent_t evMeta = nullptr;           // behind the last emission's k_emit_meta_blocks
+    hipEvent_t evMeta = nullptr;           // behind the last emission's k_emit_meta_spec
     bool metaPending = false;
     int metaWarm = swk::MWARM;             // warm-up matches of the pairing chain's speculative blocks (SWSEM_META_WARM: fewer, so that blocks fail)
     bool phase2Behind = true;              // the second phase's byte automata are handed over behind the speculative finalize
