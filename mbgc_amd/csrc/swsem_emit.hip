@@ -889,6 +889,68 @@ __device__ ExtRes ext_right(const EmitView &v, const uint8_t *gapPtr, int64_t ga
     return r;
 }
 
+// extendMatchRight over a gap between two paired matches (isGap, :338-371), by a whole wave. In a gap the loop does not
+// stop at a score: it walks every byte of the gap — a flag per byte, a code per mismatch — and a gap is as long as the
+// stretch between two matches on one diagonal happens to be (kilobytes to megabytes in a divergent region). What a byte
+// contributes depends on the byte alone and on whether it lies in front of the first invalid reference position, so the
+// wave takes the gap 64 bytes at a time and places the codes by a ballot. All arguments are wave-uniform; the counts
+// come back to every lane. W = false: only count.
+constexpr uint32_t GAP_WIDE_MIN = 192;                                 // shorter gaps stay with their thread
+struct WideRes { uint32_t nlit, nfl, matched; };
+template <bool W>
+__device__ WideRes ext_right_gap_wide(const EmitView &v, const uint8_t *gapPtr, int64_t src0, uint32_t length, bool gapStart, bool gapEnd,
+                                      uint8_t *lit, uint8_t *fl) {
+    const swsem_emit_params_t &p = v.p;
+    const bool lazy = p.lazyDecompressionSupport != 0, excl = p.mismatchesWithExclusion != 0;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint8_t *ref = v.ref + src0;
+    uint32_t validLen = src0 == (int64_t) v.pos1 ? 0u : length;        // bytes [0, validLen) may be compared (:318-320)
+    const uint32_t s0 = gapStart ? 1u : 0u;                            // the first byte of a gap's first stretch is a literal without a flag
+    if (gapStart && lazy && validLen && ref[0] == 0) validLen = 0;     // :330
+    uint32_t e = validLen > s0 ? validLen : s0;                        // compared bytes are [s0, e): up to the first separator byte under lazy decompression
+    if (lazy && validLen > s0) {
+        for (uint32_t i0 = s0; i0 < validLen; i0 += WAVE) {
+            const uint32_t i = i0 + lane;
+            const unsigned long long z = __ballot(i < validLen && ref[i] == 0);
+            if (z) { e = i0 + (uint32_t) __builtin_ctzll(z); break; }
+        }
+    }
+    WideRes r = {0, 0, 0};
+    if (gapStart) {                                                     // :331-336
+        if (W && lane == 0) lit[0] = excl && validLen ? mismatch2code(ref[0], gapPtr[0]) : gapPtr[0];
+        r.nlit = 1;
+    }
+    constexpr int U = 4;                                                // rows of 64 bytes per round: their loads are in flight together
+    for (uint32_t i0 = s0; i0 < length; i0 += U * WAVE) {
+        uint8_t qb[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = i0 + (uint32_t) u * WAVE + lane;
+            qb[u] = i < length ? gapPtr[i] : 0;
+            rb[u] = i < e ? ref[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = i0 + (uint32_t) u * WAVE + lane;
+            const bool live = i < length, cmp = i < e;
+            const bool mm = live && (!cmp || qb[u] != rb[u]);          // behind e every byte is flagged and taken as it is (:366-371)
+            const unsigned long long mmMask = __ballot(mm);
+            if (W && live) {
+                fl[i - s0] = mm ? 1 : 0;
+                if (mm) lit[r.nlit + (uint32_t) __popcll(mmMask & ((1ull << lane) - 1ull))] = cmp && excl ? mismatch2code(rb[u], qb[u]) : qb[u];
+            }
+            const uint32_t row0 = i0 + (uint32_t) u * WAVE;
+            const uint32_t nmm = (uint32_t) __popcll(mmMask);
+            const uint32_t nlive = row0 >= length ? 0u : (length - row0 < (uint32_t) WAVE ? length - row0 : (uint32_t) WAVE);
+            r.nlit += nmm;
+            r.matched += nlive - nmm;
+        }
+    }
+    r.nfl = length - s0;
+    if (!gapEnd) { if (W && lane == 0) fl[r.nfl] = 1; r.nfl++; }       // :372
+    return r;
+}
+
 // extendMatchLeft, MBGC_Encoder.cpp:373-427
 template <bool W>
 __device__ ExtRes ext_left(const EmitView &v, const uint8_t *dest, int64_t destLen, uint64_t length, const EMatch &m, uint64_t lockPos,
@@ -978,21 +1040,34 @@ __device__ void frugal_write(uint8_t *d, uint64_t v) {
 // front of match t (or the contig tail).
 struct GapSizes { uint32_t rLit, rFl, lLit, lFl, plain, pos; };
 
-// right extension of match t-1 (t >= 1), :279-286. Returns the position after it.
-template <bool W>
-__device__ uint32_t gap_right(const EmitView &v, const EmitContig &cg, const EMatch *E, int64_t n, int64_t t, const uint8_t *q,
-                              uint8_t *rLit, uint8_t *rFl, GapSizes &s, bool &isGapBefore, uint32_t *counters) {
+// right extension of match t-1 (t >= 1), :279-286: where it starts and what it may consume
+struct RightTask { uint32_t pos; uint64_t litLeft; int64_t src; bool isGap, gStart, gMid, gEnd; };
+__device__ __forceinline__ RightTask right_task(const EmitView &v, const EmitContig &cg, const EMatch *E, int64_t n, int64_t t) {
+    RightTask k;
     const EMatch mp = E[t - 1];
     const uint32_t meta = v.meta[cg.scratchBase + t - 1];
-    uint32_t pos = (uint32_t) (mp.posDest + mp.len);                                  // uint32_t pos, :145,:240
-    const uint64_t litLeft = (t < n ? E[t].posDest : cg.n) - pos;                     // :242
-    isGapBefore = (meta & META_ISGAP) != 0;
+    k.pos = (uint32_t) (mp.posDest + mp.len);                                         // uint32_t pos, :145,:240
+    k.litLeft = (t < n ? E[t].posDest : cg.n) - k.pos;                                // :242
+    k.isGap = (meta & META_ISGAP) != 0;
+    k.gStart = (meta & META_GSTART) != 0; k.gMid = (meta & META_GMID) != 0; k.gEnd = (meta & META_GEND) != 0;
+    k.src = 0;
     if (v.p.enableExtensionsWithMismatches) {
         const EMatch core = E[v.corr[cg.scratchBase + t - 1]];
-        const int64_t src = isGapBefore ? (int64_t) (core.posSrc + (mp.posDest + mp.len) - core.posDest)
-                                        : (int64_t) (mp.posSrc + mp.len);
-        const ExtRes r = ext_right<W>(v, q + pos, (int64_t) cg.n - (int64_t) pos, src, litLeft, isGapBefore, (meta & META_GSTART) != 0,
-                                      (meta & META_GMID) != 0, (meta & META_GEND) != 0, rLit, rFl);
+        k.src = k.isGap ? (int64_t) (core.posSrc + (mp.posDest + mp.len) - core.posDest) : (int64_t) (mp.posSrc + mp.len);
+    }
+    return k;
+}
+// a gap long enough for the whole wave (ext_right_gap_wide)
+__device__ __forceinline__ bool right_task_wide(const EmitView &v, const RightTask &k) {
+    return v.p.enableExtensionsWithMismatches && k.isGap && k.litLeft > GAP_WIDE_MIN && k.litLeft <= UINT32_MAX;
+}
+// Returns the position after it.
+template <bool W>
+__device__ uint32_t gap_right(const EmitView &v, const EmitContig &cg, const RightTask &k, const uint8_t *q,
+                              uint8_t *rLit, uint8_t *rFl, GapSizes &s, uint32_t *counters) {
+    uint32_t pos = k.pos;
+    if (v.p.enableExtensionsWithMismatches) {
+        const ExtRes r = ext_right<W>(v, q + pos, (int64_t) cg.n - (int64_t) pos, k.src, k.litLeft, k.isGap, k.gStart, k.gMid, k.gEnd, rLit, rFl);
         s.rLit = r.nlit; s.rFl = r.nfl;
         pos += r.consumed;
         if (!W) { counters[0] += r.matched; counters[1] += r.mism; }
@@ -1000,12 +1075,9 @@ __device__ uint32_t gap_right(const EmitView &v, const EmitContig &cg, const EMa
     return pos;
 }
 
-__device__ GapSizes gap_sizes(const EmitView &v, const EmitContig &cg, const EMatch *E, int64_t n, int64_t t, const uint8_t *q,
-                              uint32_t *counters) {
-    GapSizes s = {0, 0, 0, 0, 0, 0};
-    uint32_t pos = 0;
-    bool isGapBefore = false;
-    if (t >= 1) pos = gap_right<false>(v, cg, E, n, t, q, nullptr, nullptr, s, isGapBefore, counters);
+// what follows the right extension of gap task t: the left extension of match t and the plain literals in front of it
+__device__ void gap_sizes_left(const EmitView &v, const EmitContig &cg, const EMatch *E, int64_t n, int64_t t, const uint8_t *q, uint32_t pos,
+                               bool isGapBefore, GapSizes &s, uint32_t *counters) {
     if (t < n) {
         const EMatch m = E[t];
         uint64_t litLeft = m.posDest - pos;                                             // :216
@@ -1019,7 +1091,6 @@ __device__ GapSizes gap_sizes(const EmitView &v, const EmitContig &cg, const EMa
     } else
         s.plain = (uint32_t) (cg.n - pos);                                              // :288-289
     s.pos = pos;
-    return s;
 }
 
 // sizes of every gap task, one block per chunk of 256 tasks
@@ -1033,8 +1104,31 @@ __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig
     if ((int64_t) gx * 256 > n) return;
     const int64_t t = (int64_t) gx * 256 + threadIdx.x;
     uint32_t cloc[2] = {0, 0};
+    const EMatch *E = v.em + cg.scratchBase;
+    const uint8_t *q = v.qbuf + cg.qoff;
+    GapSizes s = {0, 0, 0, 0, 0, 0};
+    RightTask k = {0, 0, 0, false, false, false, false};
+    uint32_t pos = 0;
+    bool wide = false;
+    if (t <= n && t >= 1) {
+        k = right_task(v, cg, E, n, t);
+        wide = right_task_wide(v, k);
+        pos = wide ? k.pos : gap_right<false>(v, cg, k, q, nullptr, nullptr, s, cloc);
+    }
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    for (unsigned long long todo = __ballot(wide); todo; todo &= todo - 1) {      // the long gaps of this wave's tasks, one after the other, all lanes on each
+        const int l = __builtin_ctzll(todo);
+        const uint32_t wpos = rl32(k.pos, l);
+        const WideRes r = ext_right_gap_wide<false>(v, q + wpos, (int64_t) rl64((uint64_t) k.src, l), rl32((uint32_t) k.litLeft, l),
+                                                    rl32(k.gStart, l) != 0, rl32(k.gEnd, l) != 0, nullptr, nullptr);
+        if ((int) lane == l) {
+            s.rLit = r.nlit; s.rFl = r.nfl;
+            pos = k.pos + (uint32_t) k.litLeft;
+            cloc[0] += r.matched; cloc[1] += r.nlit;
+        }
+    }
     if (t <= n) {
-        const GapSizes s = gap_sizes(v, cg, v.em + cg.scratchBase, n, t, v.qbuf + cg.qoff, cloc);
+        gap_sizes_left(v, cg, E, n, t, q, pos, k.isGap, s, cloc);
         uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
         z[0] = s.rLit; z[1] = s.rFl; z[2] = s.lLit; z[3] = s.lFl; z[4] = s.plain; z[5] = s.pos;
     }
@@ -1181,7 +1275,10 @@ __global__ void __launch_bounds__(CH) k_emit_place_final(EmitView v, const EmitC
 }
 
 // write: one thread per iteration; the extension codes are produced by re-running the automata that
-// belong to the iteration (left codes: gap task t, right codes: first half of gap task t+1)
+// belong to the iteration (left codes: gap task t, right codes: first half of gap task t+1). A long run of plain
+// literals — the unmatched stretch of a divergent contig can be megabytes — is not one thread's work: the wave
+// copies it together, 16 bytes per lane and round.
+constexpr uint32_t PLAIN_INLINE = 48;                                  // plain literals a thread copies itself
 __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig *__restrict__ cgs) {
     const uint32_t gk = v.chunkOwner[blockIdx.x];
     const EmitContig cg = cgs[gk];
@@ -1190,38 +1287,71 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
     const int64_t t = (int64_t) gx * 256 + threadIdx.x;
-    if (t > n) return;
-    const EMatch *E = v.em + cg.scratchBase;
     const uint8_t *q = v.qbuf + cg.qoff;
-    const uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
-    const uint32_t *w = v.ofs + (cg.scratchBase + t) * 6;
-    const bool bit40 = v.p.enable40bitReference != 0, frugal = v.p.frugal64bitLenEncoding != 0;
-    const uint64_t *pb = v.packBase + (size_t) gk * SWSEM_NSTREAMS;
-    uint8_t *lLit = v.arena + pb[SWSEM_LIT] + w[0], *lFl = v.arena + pb[SWSEM_FLAGS] + w[1];
-    uint8_t *plainDst = lLit + z[2];
-    for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
-    if (t == n) return;
-    const uint32_t *zn = z + 6;
-    uint8_t *rLit = plainDst + z[4] + 1, *rFl = lFl + z[3];
-    if (z[2] | z[3]) {
-        const EMatch m = E[t];
-        ext_left<true>(v, q, (int64_t) cg.n, m.posDest - z[5], m, cg.lock, lLit, lFl);
+    uint32_t longLen = 0;
+    const uint8_t *longSrc = nullptr;
+    uint8_t *longDst = nullptr;
+    RightTask rk = {0, 0, 0, false, false, false, false};
+    bool wide = false;
+    uint8_t *wLit = nullptr, *wFl = nullptr;
+    if (t <= n) {
+        const EMatch *E = v.em + cg.scratchBase;
+        const uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
+        const uint32_t *w = v.ofs + (cg.scratchBase + t) * 6;
+        const bool bit40 = v.p.enable40bitReference != 0, frugal = v.p.frugal64bitLenEncoding != 0;
+        const uint64_t *pb = v.packBase + (size_t) gk * SWSEM_NSTREAMS;
+        uint8_t *lLit = v.arena + pb[SWSEM_LIT] + w[0], *lFl = v.arena + pb[SWSEM_FLAGS] + w[1];
+        uint8_t *plainDst = lLit + z[2];
+        if (z[4] <= PLAIN_INLINE) for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
+        else { longLen = z[4]; longSrc = q + z[5]; longDst = plainDst; }
+        if (t < n) {
+            const uint32_t *zn = z + 6;
+            uint8_t *rLit = plainDst + z[4] + 1, *rFl = lFl + z[3];
+            if (z[2] | z[3]) {
+                const EMatch m = E[t];
+                ext_left<true>(v, q, (int64_t) cg.n, m.posDest - z[5], m, cg.lock, lLit, lFl);
+            }
+            plainDst[z[4]] = MATCH_MARK;
+            if (zn[0] | zn[1]) {
+                rk = right_task(v, cg, E, n, t + 1);
+                wide = right_task_wide(v, rk);
+                wLit = rLit; wFl = rFl;
+                if (!wide) {
+                    GapSizes tmp = {0, 0, 0, 0, 0, 0};
+                    uint32_t dummy[2];
+                    gap_right<true>(v, cg, rk, q, rLit, rFl, tmp, dummy);
+                }
+            }
+            const uint32_t meta = v.meta[cg.scratchBase + t];
+            if (!(meta & META_SKIPOFF)) {
+                put_bytes(v.arena + pb[SWSEM_OFF] + w[2], (uint32_t) E[t].posSrc, 4);
+                if (bit40) v.arena[pb[SWSEM_OFF5] + w[3]] = (uint8_t) (E[t].posSrc >> 32);
+            }
+            if (frugal) frugal_write(v.arena + pb[SWSEM_LEN] + w[4], E[t].len);
+            else put_bytes(v.arena + pb[SWSEM_LEN] + w[4], (uint32_t) E[t].len, 4);
+            if (meta & META_HASGAP) v.arena[pb[SWSEM_GAP] + w[5]] = (uint8_t) (meta >> 8);
+        }
     }
-    plainDst[z[4]] = MATCH_MARK;
-    if (zn[0] | zn[1]) {
-        GapSizes tmp = {0, 0, 0, 0, 0, 0};
-        bool gb;
-        uint32_t dummy[2];
-        gap_right<true>(v, cg, E, n, t + 1, q, rLit, rFl, tmp, gb, dummy);
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    for (unsigned long long todo = __ballot(wide); todo; todo &= todo - 1) {      // long gaps: the codes of one gap by all lanes
+        const int l = __builtin_ctzll(todo);
+        ext_right_gap_wide<true>(v, q + rl32(rk.pos, l), (int64_t) rl64((uint64_t) rk.src, l), rl32((uint32_t) rk.litLeft, l),
+                                 rl32(rk.gStart, l) != 0, rl32(rk.gEnd, l) != 0, (uint8_t *) rl64((uint64_t) wLit, l), (uint8_t *) rl64((uint64_t) wFl, l));
     }
-    const uint32_t meta = v.meta[cg.scratchBase + t];
-    if (!(meta & META_SKIPOFF)) {
-        put_bytes(v.arena + pb[SWSEM_OFF] + w[2], (uint32_t) E[t].posSrc, 4);
-        if (bit40) v.arena[pb[SWSEM_OFF5] + w[3]] = (uint8_t) (E[t].posSrc >> 32);
+    for (unsigned long long todo = __ballot(longLen != 0); todo; todo &= todo - 1) {
+        const int l = __builtin_ctzll(todo);
+        const uint32_t len = rl32(longLen, l);
+        const uint8_t *src = (const uint8_t *) rl64((uint64_t) longSrc, l);
+        uint8_t *dst = (uint8_t *) rl64((uint64_t) longDst, l);
+        for (uint32_t at = 16 * lane; at < len; at += 16 * WAVE) {
+            if (at + 16 <= len) {
+                uint4 x;
+                memcpy(&x, src + at, 16);
+                memcpy(dst + at, &x, 16);
+            } else
+                for (uint32_t k = at; k < len; k++) dst[k] = src[k];
+        }
     }
-    if (frugal) frugal_write(v.arena + pb[SWSEM_LEN] + w[4], E[t].len);
-    else put_bytes(v.arena + pb[SWSEM_LEN] + w[4], (uint32_t) E[t].len, 4);
-    if (meta & META_HASGAP) v.arena[pb[SWSEM_GAP] + w[5]] = (uint8_t) (meta >> 8);
 }
 
 // The prediction a speculative finalize was queued on (swsem_emit_batch_begin_spec): every contig's reference

@@ -202,3 +202,51 @@ def test_hip_streams_decode_back_to_the_contig(binding, mode, lazy, lim):
                 h.load_separator(0)
             loaded.append(h.loaded_ref_length())
     h.close()
+
+
+@pytest.mark.parametrize("mode,lazy", [(1, True), (1, False), (0, True), (3, True)])
+def test_long_gaps_between_paired_matches(binding, mode, lazy):
+    """A stretch between two matches on one diagonal is a gap (MBGC_Encoder.cpp:262-270): extendMatchRight walks all of it,
+    whatever its length (:338-371) — on the device a wave takes a long one together (ext_right_gap_wide). Divergent stretches
+    of 100 B .. 70 kB that keep their length, one of them across a separator byte of the reference (where the comparison
+    stops under lazy decompression), and the same with unmatched runs of plain literals that long."""
+    rng = np.random.default_rng(41 + mode)
+    base = synth.ACGT[rng.integers(0, 4, 400_000)]
+
+    def diverged(g, spots, same_length=True):
+        g = g.copy()
+        out, at = [], 0
+        for a, n in spots:
+            out.append(g[at:a])
+            out.append(synth.ACGT[rng.integers(0, 4, n if same_length else n + 7)])
+            at = a + n
+        out.append(g[at:])
+        return np.concatenate(out)
+
+    spots = [(20_000, 100), (40_000, 193), (60_000, 500), (90_000, 5_000), (150_000, 70_000), (300_000, 1_000)]
+    files = [[base], [diverged(base, spots)], [diverged(base, spots[1:], same_length=False)], [diverged(base, spots[::2])]]
+    lim, _ = _driver.ref_length_limit(len(files) + 1, base.size)
+    margin = 24 if mode >= 2 else 16
+    h = binding.SlidingWindowSparseEMMatcher(lim, skip_margin=margin)
+    o = _orc.OracleMatcher(lim, skip_margin=margin)
+    he = HipEmitter(binding, h, binding.emit_params(mode, lazyDecompressionSupport=int(lazy)))
+    oe = _orc.OracleEmitter(o, _orc.emit_params(mode, lazyDecompressionSupport=int(lazy)))
+    pol = _driver.Policy(mode)
+    a = _driver.encode_sequential(h, he, files, pol, lazy=lazy)
+    b = _driver.encode_sequential(o, oe, files, pol, lazy=lazy)
+    loaded = a["loaded"]
+    assert loaded == b["loaded"]
+    # a contig that lies across a separator of the reference as it stands now, its middle (the separator's surroundings) diverged
+    ref = h.ref(h.loaded_ref_length() + 1, 0)
+    seps = np.nonzero(ref[1:] == 0)[0] + 1
+    sep = int(seps[len(seps) // 2]) if seps.size else int(h.loaded_ref_length() // 2)      # (no separators in the buffer without lazy decompression)
+    q = ref[sep - 3_000: sep + 3_000].copy()
+    q[3_000 - 200: 3_000 + 200] = synth.ACGT[rng.integers(0, 4, 400)]
+    mh, mo = h.match(q, 32, NO_LOCK), o.match(q, 32, NO_LOCK)
+    assert np.array_equal(np.asarray(mh), np.asarray(mo)) and len(mo) >= 2
+    assert he.process(mh, q, NO_LOCK, 128, 0, 0, loaded) == oe.process(mo, q, NO_LOCK, 128, 0, 0, loaded)
+    compare(he.streams(), oe.streams())
+    oc = oe.counters()
+    for k in he.counters:
+        assert he.counters[k] == oc[k], k
+    assert len(oe.streams()["flags"]) > 140_000                      # (the long gaps are in the flags, a byte each)
