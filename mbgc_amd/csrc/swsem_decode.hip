@@ -26,6 +26,10 @@ constexpr uint8_t DEC_MATCH_MARK = 0xA5;                  // MBGC_Params.h:45
 constexpr int DEC_MAX_GAP_DEPTH = 128;                    // MBGC_Params.h:50
 constexpr int64_t DEC_MAX_EXT_LEFT = 1 << 24;             // MAX_EXTEND_MATCH_LEFT_LENGTH, MBGC_Params.h:55
 constexpr uint64_t DEC_NPOS = UINT64_MAX;
+constexpr uint64_t DEC_WIDE_MIN = 192;                   // k_decode_fill: longer copies and gap extensions are a wave's work, not a thread's
+__device__ __forceinline__ uint64_t rl64d(uint64_t x, int lane) {
+    return ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (x >> 32), lane) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) x, lane);
+}
 
 struct DecodeJob {                                        // == swsem_decode_job_t (device pointers)
     const uint8_t *stream[SWSEM_NSTREAMS];
@@ -208,6 +212,30 @@ __device__ uint64_t plan_extend_right(Plan &d, bool isGap, bool gapStart, bool g
     if (d.litPos == guardLitPos && !gapMiddle) return 0;
     uint64_t n = 0;
     if (gapStart || !isGap) { plan_lit_skip(d); n++; }
+    if (isGap) {
+        // In a gap the score plays no part (:441): the walk passes every flag up to the mismatch that takes the last literal in
+        // front of the mark — and, in a stretch that is not the gap's last, up to the set flag behind it, which finds none left
+        // (:447) and is not a byte. That is a count of set flags, taken a window of 64 at a time; a gap is as long as the
+        // stretch between two matches on one diagonal (megabytes in a divergent region).
+        uint64_t need = (guardLitPos - d.litPos) + (gapEnd ? 0 : 1), passed = 0;
+        while (need && !d.bad) {
+            if (d.flPos >= d.nFlags) { d.bad = 1; break; }
+            if (d.flPos - d.fl.base >= (uint64_t) WAVE) bw_load<false>(d.fl, d.flPos);
+            const uint64_t rel = d.flPos - d.fl.base;
+            unsigned long long m = d.fl.mask >> rel;                           // (flags past the end of the stream: clear)
+            const uint64_t avail = (uint64_t) WAVE - rel < d.nFlags - d.flPos ? (uint64_t) WAVE - rel : d.nFlags - d.flPos;
+            const uint64_t c = (uint64_t) __popcll(m);
+            if (c < need) { need -= c; d.flPos += avail; passed += avail; }
+            else {
+                for (uint64_t q = 1; q < need; q++) m &= m - 1;
+                const uint64_t take = (uint64_t) __builtin_ctzll(m) + 1;
+                d.flPos += take; passed += take; need = 0;
+            }
+        }
+        if (!d.bad) { d.litPos = guardLitPos; n += passed - (gapEnd ? 0 : 1); }
+        plan_grow(d, n);
+        return n;
+    }
     int score = d.initialScore;
     while (!d.bad && (!gapEnd || d.litPos != guardLitPos) && (isGap || score < d.threshold)) {
         const uint64_t z = plan_zero_run(d, d.flPos);
@@ -458,8 +486,11 @@ __global__ void __launch_bounds__(256) k_decode_fill(const uint8_t *__restrict__
                                                      const DecPlanOut *__restrict__ plans, uint32_t *__restrict__ badFlags, uint64_t refBytes) {
     const uint32_t c = blockIdx.y;
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (plans[c].unmatched < 0 || i >= plans[c].nrec) return;
-    const DecRec r = recs[recBase[c] + i];
+    if (plans[c].unmatched < 0 || (uint64_t) blockIdx.x * blockDim.x >= plans[c].nrec) return;
+    // (a lane without a record of its own stays: the long pieces below are the work of all 64 lanes of a wave)
+    DecRec r = {};
+    r.flags = REC_TAIL;
+    if (i < plans[c].nrec) r = recs[recBase[c] + i];
     const DecodeJob &jb = jobs[c];
     Dec d;
     d.ref = ref; d.solo = true; d.refBytes = refBytes;
@@ -475,24 +506,87 @@ __global__ void __launch_bounds__(256) k_decode_fill(const uint8_t *__restrict__
         LeftExt e; e.srcMatch = r.leftSrcMatch; e.srcGuard = r.leftSrcGuard; e.len = r.leftLen; e.codes = r.leftCodes;
         dec_left_write(d, e, r.destAt + plain, r.mark);
     }
+    // what is long goes to the whole wave (below): a run of plain literals, the match itself, the right extension across a gap
+    uint64_t copyLen[2] = {0, 0};
+    const uint8_t *copySrc[2] = {nullptr, nullptr};
+    uint8_t *copyDst[2] = {nullptr, nullptr};
+    bool wideRight = false;
     {
         const uint8_t *s = d.lit + r.litFrom + r.leftCodes;
         uint8_t *t = d.dest + r.destAt;
-        for (uint64_t k = 0; k < plain; k++) t[k] = s[k];
+        if (plain <= DEC_WIDE_MIN) for (uint64_t k = 0; k < plain; k++) t[k] = s[k];
+        else { copyLen[0] = plain; copySrc[0] = s; copyDst[0] = t; }
     }
+    const uint64_t at = r.destAt + plain + r.leftLen;
     if (!(r.flags & REC_TAIL)) {
-        const uint64_t at = r.destAt + plain + r.leftLen;
         const uint8_t *s = ref + r.src;
         uint8_t *t = d.dest + at;
-        uint64_t k = 0;
-        for (; k + 16 <= r.len; k += 16) { const uint4 x = ld_u128(s + k); __builtin_memcpy(t + k, &x, 16); }
-        for (; k < r.len; k++) t[k] = s[k];
+        if (r.len <= DEC_WIDE_MIN) {
+            uint64_t k = 0;
+            for (; k + 16 <= r.len; k += 16) { const uint4 x = ld_u128(s + k); __builtin_memcpy(t + k, &x, 16); }
+            for (; k < r.len; k++) t[k] = s[k];
+        } else { copyLen[1] = r.len; copySrc[1] = s; copyDst[1] = t; }
         if (r.flags & REC_RIGHT) {
-            d.litPos = r.mark + 1; d.flPos = r.flRight; d.destLen = at + r.len;
-            const uint64_t n = dec_extend_right(d, r.offsetDelta, (r.flags & REC_GAP) != 0, (r.flags & REC_GAP_START) != 0, (r.flags & REC_GAP_MIDDLE) != 0,
-                                                (r.flags & REC_GAP_END) != 0, r.guardLit);
-            if (n != r.rightLen) d.bad = 1;
+            wideRight = (r.flags & REC_GAP) != 0 && r.rightLen > DEC_WIDE_MIN;
+            if (!wideRight) {
+                d.litPos = r.mark + 1; d.flPos = r.flRight; d.destLen = at + r.len;
+                const uint64_t n = dec_extend_right(d, r.offsetDelta, (r.flags & REC_GAP) != 0, (r.flags & REC_GAP_START) != 0, (r.flags & REC_GAP_MIDDLE) != 0,
+                                                    (r.flags & REC_GAP_END) != 0, r.guardLit);
+                if (n != r.rightLen) d.bad = 1;
+            }
         }
+    }
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+        for (unsigned long long todo = __ballot(copyLen[w] != 0); todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const uint64_t len = rl64d(copyLen[w], l);
+            const uint8_t *src = (const uint8_t *) rl64d((uint64_t) copySrc[w], l);
+            uint8_t *dst = (uint8_t *) rl64d((uint64_t) copyDst[w], l);
+            for (uint64_t o = 16 * (uint64_t) lane; o < len; o += 16 * WAVE) {
+                if (o + 16 <= len) { const uint4 x = ld_u128(src + o); __builtin_memcpy(dst + o, &x, 16); }
+                else for (uint64_t k = o; k < len; k++) dst[k] = src[k];
+            }
+        }
+    for (unsigned long long todo = __ballot(wideRight); todo; todo &= todo - 1) {
+        // extendMatchRight across a gap (:434-460) by the wave: byte i of the extension is the reference byte at its place or,
+        // where its flag is set, the mismatch the next literal code stands for — the code's place is the count of set flags
+        // in front of it
+        const int l = __builtin_ctzll(todo);
+        const uint64_t n = rl64d(r.rightLen, l), dst0 = rl64d(at + r.len, l), fl0 = rl64d(r.flRight, l), lit0 = rl64d(r.mark + 1, l);
+        const int64_t src0 = (int64_t) rl64d((uint64_t) ((int64_t) (at + r.len) + r.offsetDelta), l);
+        const uint32_t s0 = (rl64d(r.flags, l) & REC_GAP_START) ? 1u : 0u;
+        int bad = dst0 + n > d.destCap;
+        uint64_t rank = s0;                                                    // literal codes taken so far
+        if (!bad && s0 && lane == 0) {
+            Dec t = d;
+            t.bad = 0; t.litPos = lit0;
+            d.dest[dst0] = dec_code2mismatch(t, dec_ref_at(t, src0), dec_lit_next(t));
+            bad |= t.bad;
+        }
+        bad = __ballot(bad != 0) != 0;
+        for (uint64_t i0 = s0; i0 < n && !bad; i0 += WAVE) {
+            const uint64_t i = i0 + lane;
+            const bool live = i < n;
+            Dec t = d;
+            t.bad = 0;
+            const uint8_t f = live ? dec_flag_at(t, fl0 + (i - s0)) : (uint8_t) 0;
+            const unsigned long long set = __ballot(live && f != 0);
+            if (live) {
+                const uint8_t rb = dec_ref_at(t, src0 + (int64_t) i);
+                uint8_t b = rb;
+                if (f) {
+                    t.litPos = lit0 + rank + (uint64_t) __popcll(set & ((1ull << lane) - 1ull));
+                    b = dec_code2mismatch(t, rb, dec_lit_next(t));
+                }
+                d.dest[dst0 + i] = b;
+            }
+            rank += (uint64_t) __popcll(set);
+            bad |= __ballot(t.bad != 0) != 0;
+        }
+        bad = __ballot(bad != 0) != 0;
+        if (bad && (int) lane == l) d.bad = 1;
     }
     if (d.bad) atomicOr(&badFlags[c], 1u);
 }

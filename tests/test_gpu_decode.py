@@ -158,3 +158,28 @@ def test_many_contigs_decode_side_by_side(binding):
     dt = time.perf_counter() - t0
     print("device decode + compare of %d x %d bases: %.1f ms = %.2f Gbases/s" % (R, L, dt * 1e3, R * L / dt / 1e9))
     h.close()
+
+
+@pytest.mark.parametrize("mode,lazy", [(1, 1), (0, 1), (1, 0)])
+def test_long_gaps_long_matches_and_long_literal_runs_decode_back(binding, mode, lazy):
+    """what k_decode_fill hands to a whole wave: right extensions across gaps of 193 B .. 300 kB (the plan counts their set flags
+    a window at a time), matches of hundreds of kilobytes, runs of plain literals as long — the emission of such a contig
+    must decode back to it, in one contig and side by side with an ordinary one"""
+    rng = np.random.default_rng(5 + mode)
+    base = synth.ACGT[rng.integers(0, 4, 1_500_000)]
+    h = binding.SlidingWindowSparseEMMatcher(32_000_000)
+    h.disable_sliding_window()
+    h.load_ref(base, load_rc=False, add_sep=True, sep=0)
+    loaded = [h.loading_position()]
+    t = base.copy()
+    for a, n in ((50_000, 193), (100_000, 2_000), (200_000, 300_000), (700_000, 64), (900_000, 40_000)):
+        t[a:a + n] = synth.ACGT[rng.integers(0, 4, n)]                       # same length: the flanks stay on one diagonal (a gap)
+    t = np.concatenate([t[:1_200_000], synth.ACGT[rng.integers(0, 4, 150_000)], t[1_200_000:]])      # an insertion: plain literals
+    p = binding.emit_params(mode, lazyDecompressionSupport=lazy)
+    m = h.match(t, 32, binding.NO_LOCK)
+    un, streams, st = h.emit(p, 0, binding.NO_LOCK, 128, 0, 0, loaded)
+    assert len(m) < 40 and len(streams["flags"]) > 300_000 and len(streams["literals"]) > 350_000
+    assert h.emit_verify() == (0, -1, 2 ** 64 - 1)
+    # the oracle's decoder on the same streams (the CPU restatement of MBGC_Decoder.cpp:319-523)
+    back, un2 = _orc.decode_contig(h.ref(h.max_ref_length()), _orc.emit_params(mode, lazyDecompressionSupport=lazy), streams, _orc.NO_LOCK, t.size + 16)
+    assert un2 == un and np.array_equal(back, t)
