@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""`mbgc-hip c` on the mixed-species collection (mbgc_amd/synth.py: MixedSpecies — BASELINE configs[4]'s kind of data: 8 unrelated
+species x 4 strains, 0.2-10 % divergence, 1-4 contigs, reverse-complemented contigs, N runs) from FASTA files in the page cache:
+the `-m 3` presets (sequential schedule) and `-m1` in window-sized rounds — the tool's own "matching finished" clock.
+usage: cpp_host_mixed.py [genomes=200]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mbgc_amd import synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+d = tempfile.mkdtemp(prefix="mbgc_mix_", dir=os.environ.get("TMPDIR", "/tmp"))
+coll = synth.MixedSpecies()
+paths, bases = [], 0
+for i in range(n):
+    p = os.path.join(d, "m%05d.fa" % i)
+    with open(p, "wb") as f:
+        f.write(coll.fasta(i))
+    bases += sum(c.size for c in coll.contigs(i))
+    paths.append(p)
+with open(os.path.join(d, "list.txt"), "w") as f:
+    f.write("\n".join(paths) + "\n")
+out = {}
+for name, args in (("m3", ["-m", "3"]), ("m1_rounds", []), ("m1_t1", ["-t1"])):
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c"] + args + [os.path.join(d, "list.txt"), os.path.join(d, "out")],
+                       capture_output=True, text=True, env=dict(os.environ, MBGC_HIP_TIMES="1"))
+    wall = time.time() - t0
+    m = re.search(r"matching finished - (\d+) \[ms\]", r.stderr)
+    ms = int(m.group(1)) if m else None
+    um = re.search(r"final unmatched chars: (\d+)", r.stdout)
+    rd = re.search(r"rounds of (\d+) targets", r.stdout)
+    out[name] = dict(rc=r.returncode, wall_s=round(wall, 2), matching_ms=ms, gbases_per_s=round(bases / (ms / 1e3) / 1e9, 3) if ms else None,
+                     final_unmatched_chars=int(um.group(1)) if um else None, targets_per_round=int(rd.group(1)) if rd else None)
+    where = [x.strip() for x in r.stderr.splitlines() if "reader threads:" in x]
+    if where:
+        out[name]["host_threads"] = where[-1]
+    if r.returncode:
+        sys.stderr.write(r.stderr[-800:])
+print(json.dumps(dict(genomes=n, bases=bases, runs=out)))
+subprocess.run(["rm", "-rf", d])
