@@ -52,6 +52,7 @@ static void writeUInt64Frugal(std::string &dest, uint64_t value) {
 static double nowSeconds() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 // where the host's wall time goes (MBGC_HIP_TIMES=1 prints it with "matching finished"): reading + inflating files,
 // upload + device parse, taking the streams over
+static uint64_t g_retryPasses = 0, g_retryContigs = 0;          // passes of processRoundWithRetries and the contigs they matched
 static double g_tRead = 0, g_tParse = 0, g_tCollect = 0, g_tWait = 0, g_tCollectWait = 0, g_tAppend = 0, g_tAppendWait = 0, g_tPrepareSync = 0, g_tReadWait = 0, g_tMatch = 0, g_tEmit = 0, g_tFinalize = 0;
 
 // ---------------------------------------------------------------- input stage
@@ -585,9 +586,14 @@ void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B, siz
                 tidx.push_back(targetOf(c));
             }
             offs.push_back(offsets[at + n] - offsets[at]);
+            const double tm0 = nowSeconds();
             matcher->matchRound(dev + offsets[at], offs, params->k, locks, counts);            // :379
+            const double te0 = nowSeconds();
+            g_tMatch += te0 - tm0;
             std::vector<EmittedStreams> out;
             matcher->emitRound(emitParams(), locks, factors, processed, tidx, loadedPositions(), out);   // :381
+            g_tEmit += nowSeconds() - te0;
+            g_retryPasses++; g_retryContigs += n;
             if (params->verifyEmissions) verifyEmission(n, offs[n]);
             for (size_t k = 0; k < n; k++) {
                 const int c = (int) (at + k);
@@ -621,16 +627,24 @@ void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B, siz
             extensionStrings(B, ext, rc, finalized - r0, upto - r0, extDev, extLen);
             for (uint32_t t = finalized; t < upto; t++) tlocks.push_back(matchingLocksPos[t]);
             size_t startPos = matcher->getLoadedRefLength();
+            const double tf0 = nowSeconds();
             matcher->finalizeTargets(extDev, extLen, params->refRegionSeparators, REF_REGION_SEPARATOR, lazyMode(), tlocks, loadedAfter);   // :440-457
+            g_tFinalize += nowSeconds() - tf0;
             for (uint32_t t = finalized; t < upto; t++) {
-                // the target's streams: contig by contig, then the target separator
+                // the target's streams: contig by contig, then the target separator — the targets arrive in order here, so the
+                // bytes go straight to where appendTargetStreams (ENC.cpp:543-556) would put them (divergent collections, which
+                // take this path, have the large streams: 0.4 bytes per base)
                 for (size_t c = 0; c < ncont; c++)
                     if (targetOf(c) == t) {
-                        takeRoundStreams(t, emitted[c]);
-                        processAfterSequence(t);
+                        swsem_streams_t view = {};
+                        for (int i = 0; i < SWSEM_NSTREAMS; i++) { view.data[i] = (const uint8_t *) emitted[c].s[i].data(); view.size[i] = emitted[c].s[i].size(); }
+                        view.unmatchedChars = emitted[c].unmatchedChars; view.extensionsMatchedChars = emitted[c].extensionsMatchedChars;
+                        view.extensionsMismatches = emitted[c].extensionsMismatches; view.totalMatched = emitted[c].totalMatched;
+                        view.removedGapBreakingMatches = emitted[c].removedGapBreakingMatches; view.nmatches = emitted[c].nmatches;
+                        appendContigInOrder(view);
+                        emitted[c] = EmittedStreams();
                     }
-                processAfterTarget(t);
-                appendTargetStreams(t);                                                         // ENC.cpp:543-556
+                endTargetInOrder();
                 noteTargetLoaded(t, startPos, loadedAfter[t - finalized]);                      // :557-563
                 startPos = loadedAfter[t - finalized];
                 processedTargetsCount = t + 1;
@@ -857,8 +871,9 @@ void MultipleGenomeMatchingProcessor::performMatching() {
         fprintf(stderr, "matching finished - %.0f [ms]\n", (nowSeconds() - t0) * 1e3);
     if (getenv("MBGC_HIP_TIMES"))
         fprintf(stderr, "  reader threads: reading files %.0f ms; input thread: waiting for them %.0f ms, upload + parse %.0f ms; main thread: waiting for it %.0f ms, taking the streams over %.0f ms"
-                        " (%.0f of them waiting for the bytes; appends on their thread %.0f ms, waited for %.0f ms); rounds prepared by the main thread itself %.0f ms; match-finding calls %.0f ms, processMatches' first pass %.0f ms, loadRef calls %.0f ms\n",
-                g_tRead * 1e3, g_tReadWait * 1e3, g_tParse * 1e3, g_tWait * 1e3, g_tCollect * 1e3, g_tCollectWait * 1e3, g_tAppend * 1e3, g_tAppendWait * 1e3, g_tPrepareSync * 1e3, g_tMatch * 1e3, g_tEmit * 1e3, g_tFinalize * 1e3);
+                        " (%.0f of them waiting for the bytes; appends on their thread %.0f ms, waited for %.0f ms); rounds prepared by the main thread itself %.0f ms; match-finding calls %.0f ms, processMatches calls %.0f ms, loadRef calls %.0f ms; rounds cut at a dissimilar contig: %llu passes over %llu contigs\n",
+                g_tRead * 1e3, g_tReadWait * 1e3, g_tParse * 1e3, g_tWait * 1e3, g_tCollect * 1e3, g_tCollectWait * 1e3, g_tAppend * 1e3, g_tAppendWait * 1e3, g_tPrepareSync * 1e3, g_tMatch * 1e3, g_tEmit * 1e3, g_tFinalize * 1e3,
+                (unsigned long long) g_retryPasses, (unsigned long long) g_retryContigs);
 }
 
 // ---------------------------------------------------------------- MBGC_Encoder
