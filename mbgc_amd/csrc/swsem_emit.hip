@@ -46,6 +46,10 @@ struct EmitOut {                                     // per contig, read back by
     uint64_t extMatched, extMismatches, totalMatched, removed, nmatches;
 };
 
+struct LongCopy { uint8_t *dst; const uint8_t *src; uint64_t len; };
+constexpr uint32_t LONG_COPY_CAP = 4096;             // entries of the list (a run that finds it full is copied by its wave)
+constexpr uint32_t LONG_COPY_MIN = 32768;            // bytes from which a run goes to the list
+
 struct EmitView {
     const uint8_t *ref, *qbuf;
     const Match *matches;
@@ -71,6 +75,8 @@ struct EmitView {
     uint32_t ncontigs;
     uint64_t *packBase;                              // [contig][stream] start of the stream in the packed arena
     uint8_t *arena;                                  // streams
+    struct LongCopy *longCopies;                     // runs of plain literals too long for one wave (k_emit_write lists, k_emit_copy_long copies)
+    uint32_t *longCount;
     EmitOut *out;
 };
 
@@ -798,27 +804,33 @@ __device__ __forceinline__ int zero_hi(uint64_t w) {
 
 template <bool FWD>
 struct ByteWin {
-    const uint8_t *base;
+    static constexpr int N = 32;      // bytes per window: four loads in flight for one wait
+    const uint8_t *__restrict__ base; // (never the arena the automata write to)
     int64_t hi;                       // bytes [0, hi) of base may be read
     int64_t at;
-    uint64_t w;
-    __device__ __forceinline__ ByteWin(const uint8_t *b, int64_t limit) : base(b), hi(limit), at(INT64_MIN / 2), w(0) {}
+    uint64_t w[N / 8];
+    __device__ __forceinline__ ByteWin(const uint8_t *b, int64_t limit) : base(b), hi(limit), at(INT64_MIN / 2) {}
     __device__ __forceinline__ uint8_t get(int64_t i) {
-        if (hi < 8) return base[i];
-        if (i < at || i >= at + 8) {
-            at = FWD ? i : i - 7;
+        if (hi < N) return base[i];
+        if (i < at || i >= at + N) {
+            at = FWD ? i : i - (N - 1);
             if (at < 0) at = 0;
-            if (at + 8 > hi) at = hi - 8;
-            __builtin_memcpy(&w, base + at, 8);
+            if (at + N > hi) at = hi - N;
+#pragma unroll
+            for (int k = 0; k < N / 8; k++) __builtin_memcpy(&w[k], base + at + 8 * k, 8);
         }
-        return (uint8_t) (w >> (8 * (int) (i - at)));
+        const int r = (int) (i - at);
+        uint64_t x = w[0];
+#pragma unroll
+        for (int k = 1; k < N / 8; k++) x = (r >> 3) == k ? w[k] : x;
+        return (uint8_t) (x >> (8 * (r & 7)));
     }
 };
 
 // extendMatchRight, MBGC_Encoder.cpp:310-371
 template <bool W>
-__device__ ExtRes ext_right(const EmitView &v, const uint8_t *gapPtr, int64_t gapAvail, int64_t src, uint64_t length, bool isGap, bool gapStart,
-                            bool gapMiddle, bool gapEnd, uint8_t *lit, uint8_t *fl) {
+__device__ ExtRes ext_right(const EmitView &v, const uint8_t *__restrict__ gapPtr, int64_t gapAvail, int64_t src, uint64_t length, bool isGap, bool gapStart,
+                            bool gapMiddle, bool gapEnd, uint8_t *__restrict__ lit, uint8_t *__restrict__ fl) {
     ExtRes r = {0, 0, 0, 0, 0};
     const swsem_emit_params_t &p = v.p;
     if (length == 0) {
@@ -889,72 +901,147 @@ __device__ ExtRes ext_right(const EmitView &v, const uint8_t *gapPtr, int64_t ga
     return r;
 }
 
-// extendMatchRight over a gap between two paired matches (isGap, :338-371), by a whole wave. In a gap the loop does not
-// stop at a score: it walks every byte of the gap — a flag per byte, a code per mismatch — and a gap is as long as the
-// stretch between two matches on one diagonal happens to be (kilobytes to megabytes in a divergent region). What a byte
-// contributes depends on the byte alone and on whether it lies in front of the first invalid reference position, so the
-// wave takes the gap 64 bytes at a time and places the codes by a ballot. All arguments are wave-uniform; the counts
-// come back to every lane. W = false: only count.
-constexpr uint32_t GAP_WIDE_MIN = 192;                                 // shorter gaps stay with their thread
-struct WideRes { uint32_t nlit, nfl, matched; };
+// A long extension by a whole wave. One thread takes 0.6 us per byte, and extensions are long exactly where they matter:
+// between two paired matches the right extension walks the whole stretch whatever its length (isGap, :338-371), and in a
+// collection that diverges by a few percent the score of an ordinary extension (+penalty on a mismatch, -bonus but not below
+// zero on a match, :346-365, :404-421) rarely reaches the threshold, so it runs from one match to the next — kilobytes.
+// What byte k contributes depends on the byte alone (in front of position e: compared with the reference; behind it: a
+// mismatch taken as it is) — except where the walk stops: behind the first byte that lifts the score to the threshold. The
+// score after every byte of a row of 64 is a prefix composition of x -> max(x + a, b) steps, which compose: the wave scans
+// them, finds the first lane at the threshold by a ballot and places the codes by another. Arguments are wave-uniform.
+constexpr uint32_t EXT_WIDE_MIN = 192;                                 // shorter stretches stay with their thread
+constexpr int SCORE_NEG = -(1 << 28);
+struct WideOut { uint32_t nlit, matched, consumed; bool crossed; };    // (flags written = consumed)
+// bytes k0 .. n-1: byte k = q[qdir * k] against ref[rdir * k] while k < e, where e is `valid` or — under lazy decompression —
+// the first k with a separator byte (0) in the reference, found on the way; flags to fl[k - k0], codes to lit[nlit0 ...]
 template <bool W>
-__device__ WideRes ext_right_gap_wide(const EmitView &v, const uint8_t *gapPtr, int64_t src0, uint32_t length, bool gapStart, bool gapEnd,
-                                      uint8_t *lit, uint8_t *fl) {
+__device__ WideOut ext_wide(const uint8_t *ref, int rdir, const uint8_t *q, int qdir, uint32_t k0, uint32_t n, uint32_t valid, bool lazy, bool excl,
+                            bool useScore, int score, int pen, int bonus, int thr, uint8_t *lit, uint32_t nlit0, uint8_t *fl) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    WideOut r = {nlit0, 0, 0, false};
+    if (useScore && score >= thr) { r.crossed = true; return r; }
+    uint32_t e = valid > k0 ? valid : k0;
+    constexpr int U = 4;                                               // rows of 64 bytes whose loads are in flight together
+    uint8_t nq[U], nr[U];                                              // the next group's bytes: loaded before this group's codes are stored
+    auto load_group = [&](uint32_t b0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = b0 + (uint32_t) u * WAVE + lane;
+            nq[u] = k < n ? q[(int64_t) qdir * (int64_t) k] : 0;
+            nr[u] = k < n && k < e ? ref[(int64_t) rdir * (int64_t) k] : 1;
+        }
+    };
+    load_group(k0);
+    for (uint32_t base0 = k0; base0 < n && !r.crossed; base0 += U * WAVE) {
+        uint8_t qbs[U], rbs[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { qbs[u] = nq[u]; rbs[u] = nr[u]; }
+        if (base0 + U * WAVE < n) load_group(base0 + U * WAVE);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t base = base0 + (uint32_t) u * WAVE;
+            if (base >= n || r.crossed) break;
+            const uint32_t k = base + lane;
+            const bool live = k < n;
+            const uint8_t qb = qbs[u], rb = rbs[u];
+            if (lazy) {                                                // the comparison ends at the first separator byte
+                const unsigned long long z = __ballot(live && k < e && rb == 0);
+                if (z) e = base + (uint32_t) __builtin_ctzll(z);
+            }
+            const bool cmp = k < e;
+            const bool mm = live && (!cmp || qb != rb);
+            uint32_t last = (n - base < (uint32_t) WAVE ? n - base : (uint32_t) WAVE) - 1;    // last lane of the row that is walked
+            int after = score;
+            if (useScore) {
+                int fa = !live ? 0 : (mm ? pen : -bonus), fb = !live || mm ? SCORE_NEG : 0;     // this byte's step x -> max(x + fa, fb)
+                for (int d = 1; d < WAVE; d <<= 1) {                                            // inclusive scan: steps of lanes 0 .. lane, composed
+                    const int pa = __shfl_up(fa, d), pb = __shfl_up(fb, d);
+                    if ((int) lane >= d) { const int nb = pb + fa > fb ? pb + fa : fb; fa = pa + fa; fb = nb < SCORE_NEG ? SCORE_NEG : nb; }
+                }
+                after = score + fa > fb ? score + fa : fb;
+                const unsigned long long cm = __ballot(live && after >= thr);
+                if (cm) { r.crossed = true; last = (uint32_t) __builtin_ctzll(cm); }
+            }
+            const bool proc = live && lane <= last;
+            const unsigned long long mmMask = __ballot(proc && mm);
+            if (W && proc) {
+                fl[k - k0] = mm ? 1 : 0;
+                if (mm) lit[r.nlit + (uint32_t) __popcll(mmMask & ((1ull << lane) - 1ull))] = cmp && excl ? mismatch2code(rb, qb) : qb;
+            }
+            const uint32_t nmm = (uint32_t) __popcll(mmMask);
+            r.nlit += nmm;
+            r.matched += last + 1 - nmm;
+            r.consumed += last + 1;
+            if (useScore) score = (int) rl32((uint32_t) after, (int) last);
+        }
+    }
+    return r;
+}
+
+// extendMatchRight (:310-371) of a stretch of `length` bytes by the wave
+template <bool W>
+__device__ ExtRes ext_right_wide(const EmitView &v, const uint8_t *gapPtr, int64_t src0, uint32_t length, bool isGap, bool gapStart, bool gapEnd,
+                                 uint8_t *lit, uint8_t *fl) {
     const swsem_emit_params_t &p = v.p;
     const bool lazy = p.lazyDecompressionSupport != 0, excl = p.mismatchesWithExclusion != 0;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint8_t *ref = v.ref + src0;
-    uint32_t validLen = src0 == (int64_t) v.pos1 ? 0u : length;        // bytes [0, validLen) may be compared (:318-320)
-    const uint32_t s0 = gapStart ? 1u : 0u;                            // the first byte of a gap's first stretch is a literal without a flag
-    if (gapStart && lazy && validLen && ref[0] == 0) validLen = 0;     // :330
-    uint32_t e = validLen > s0 ? validLen : s0;                        // compared bytes are [s0, e): up to the first separator byte under lazy decompression
-    if (lazy && validLen > s0) {
-        for (uint32_t i0 = s0; i0 < validLen; i0 += WAVE) {
-            const uint32_t i = i0 + lane;
-            const unsigned long long z = __ballot(i < validLen && ref[i] == 0);
-            if (z) { e = i0 + (uint32_t) __builtin_ctzll(z); break; }
-        }
+    const int64_t loading = (int64_t) v.pos1;
+    int64_t valid = src0 + (int64_t) length;                            // :318-335
+    if (src0 == loading) valid = src0;
+    if (!isGap) {
+        if (valid > (int64_t) v.maxRefLength) valid = (int64_t) v.maxRefLength;
+        if (src0 <= loading && loading < valid) valid = loading;
     }
-    WideRes r = {0, 0, 0};
-    if (gapStart) {                                                     // :331-336
+    uint32_t validLen = valid > src0 ? (uint32_t) (valid - src0) : 0u;
+    const uint32_t first = gapStart || !isGap ? 1u : 0u;                // the stretch opens with a literal that has no flag
+    if (first && lazy && ref[0] == 0) validLen = 0;
+    uint32_t nlit = 0;
+    if (first) {
         if (W && lane == 0) lit[0] = excl && validLen ? mismatch2code(ref[0], gapPtr[0]) : gapPtr[0];
-        r.nlit = 1;
+        nlit = 1;
     }
-    constexpr int U = 4;                                                // rows of 64 bytes per round: their loads are in flight together
-    for (uint32_t i0 = s0; i0 < length; i0 += U * WAVE) {
-        uint8_t qb[U], rb[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t i = i0 + (uint32_t) u * WAVE + lane;
-            qb[u] = i < length ? gapPtr[i] : 0;
-            rb[u] = i < e ? ref[i] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t i = i0 + (uint32_t) u * WAVE + lane;
-            const bool live = i < length, cmp = i < e;
-            const bool mm = live && (!cmp || qb[u] != rb[u]);          // behind e every byte is flagged and taken as it is (:366-371)
-            const unsigned long long mmMask = __ballot(mm);
-            if (W && live) {
-                fl[i - s0] = mm ? 1 : 0;
-                if (mm) lit[r.nlit + (uint32_t) __popcll(mmMask & ((1ull << lane) - 1ull))] = cmp && excl ? mismatch2code(rb[u], qb[u]) : qb[u];
-            }
-            const uint32_t row0 = i0 + (uint32_t) u * WAVE;
-            const uint32_t nmm = (uint32_t) __popcll(mmMask);
-            const uint32_t nlive = row0 >= length ? 0u : (length - row0 < (uint32_t) WAVE ? length - row0 : (uint32_t) WAVE);
-            r.nlit += nmm;
-            r.matched += nlive - nmm;
-        }
-    }
-    r.nfl = length - s0;
-    if (!gapEnd) { if (W && lane == 0) fl[r.nfl] = 1; r.nfl++; }       // :372
+    const WideOut o = ext_wide<W>(ref, 1, gapPtr, 1, first, length, validLen, lazy, excl, !isGap, p.mmsMismatchesInitialScore, p.mmsMismatchPenalty, p.mmsMatchBonus,
+                                  p.mmsMismatchesScoreThreshold, lit, nlit, fl);
+    ExtRes r;
+    r.nlit = o.nlit; r.nfl = o.consumed; r.matched = o.matched; r.mism = o.nlit; r.consumed = first + o.consumed;
+    if ((isGap && !gapEnd) || (!isGap && !o.crossed)) { if (W && lane == 0) fl[r.nfl] = 1; r.nfl++; }     // :372
+    return r;
+}
+
+// extendMatchLeft (:373-427) of at most `length` bytes in front of match m by the wave
+template <bool W>
+__device__ ExtRes ext_left_wide(const EmitView &v, const uint8_t *dest, uint64_t length, uint64_t mPosSrc, uint64_t mPosDest, uint64_t lockPos,
+                                uint8_t *lit, uint8_t *fl) {
+    ExtRes r = {0, 0, 0, 0, 0};
+    const swsem_emit_params_t &p = v.p;
+    const bool lazy = p.lazyDecompressionSupport != 0, excl = p.mismatchesWithExclusion != 0;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const int64_t srcMatch = (int64_t) mPosSrc;
+    int64_t guard = 1;
+    if (guard < srcMatch - MAX_EXTEND_MATCH_LEFT_LENGTH) guard = srcMatch - MAX_EXTEND_MATCH_LEFT_LENGTH;
+    const int64_t srcLock = (int64_t) lockPos;
+    if (guard < srcLock && srcLock <= srcMatch) guard = srcLock;
+    bool guardKnown = true;
+    if (guard < srcMatch - (int64_t) length) { guard = srcMatch - (int64_t) length; guardKnown = false; }
+    if (guard == srcMatch) return r;
+    const uint32_t maxBytes = (uint32_t) (srcMatch - guard);            // bytes srcMatch-1 .. guard, walked downwards
+    const uint8_t *ref = v.ref + srcMatch - 1, *q = dest + mPosDest - 1;
+    const bool validRegion = !lazy || ref[0] != 0;
+    if (W && lane == 0) lit[0] = excl && validRegion ? mismatch2code(ref[0], q[0]) : q[0];
+    // compared bytes: [1, maxBytes) up to a separator byte — it and what lies below it are taken as they are
+    const WideOut o = ext_wide<W>(ref, -1, q, -1, 1, maxBytes, validRegion ? maxBytes : 1u, lazy, excl, true, p.mmsMismatchesInitialScore, p.mmsMismatchPenalty, p.mmsMatchBonus,
+                                  p.mmsMismatchesScoreThreshold, lit, 1, fl);
+    r.nlit = o.nlit; r.nfl = o.consumed; r.matched = o.matched; r.mism = o.nlit; r.consumed = 1 + o.consumed;
+    const bool atGuard = r.consumed == maxBytes;
+    if ((!atGuard || !guardKnown) && !o.crossed) { if (W && lane == 0) fl[r.nfl] = 1; r.nfl++; }             // :424
     return r;
 }
 
 // extendMatchLeft, MBGC_Encoder.cpp:373-427
 template <bool W>
-__device__ ExtRes ext_left(const EmitView &v, const uint8_t *dest, int64_t destLen, uint64_t length, const EMatch &m, uint64_t lockPos,
-                           uint8_t *lit, uint8_t *fl) {
+__device__ ExtRes ext_left(const EmitView &v, const uint8_t *__restrict__ dest, int64_t destLen, uint64_t length, const EMatch &m, uint64_t lockPos,
+                           uint8_t *__restrict__ lit, uint8_t *__restrict__ fl) {
     ExtRes r = {0, 0, 0, 0, 0};
     const swsem_emit_params_t &p = v.p;
     ByteWin<false> ref(v.ref, (int64_t) v.maxRefLength + 8), gq(dest, destLen);
@@ -1057,9 +1144,9 @@ __device__ __forceinline__ RightTask right_task(const EmitView &v, const EmitCon
     }
     return k;
 }
-// a gap long enough for the whole wave (ext_right_gap_wide)
+// a stretch long enough for the whole wave (ext_right_wide)
 __device__ __forceinline__ bool right_task_wide(const EmitView &v, const RightTask &k) {
-    return v.p.enableExtensionsWithMismatches && k.isGap && k.litLeft > GAP_WIDE_MIN && k.litLeft <= UINT32_MAX;
+    return v.p.enableExtensionsWithMismatches && k.litLeft > EXT_WIDE_MIN && k.litLeft <= UINT32_MAX;
 }
 // Returns the position after it.
 template <bool W>
@@ -1073,24 +1160,6 @@ __device__ uint32_t gap_right(const EmitView &v, const EmitContig &cg, const Rig
         if (!W) { counters[0] += r.matched; counters[1] += r.mism; }
     }
     return pos;
-}
-
-// what follows the right extension of gap task t: the left extension of match t and the plain literals in front of it
-__device__ void gap_sizes_left(const EmitView &v, const EmitContig &cg, const EMatch *E, int64_t n, int64_t t, const uint8_t *q, uint32_t pos,
-                               bool isGapBefore, GapSizes &s, uint32_t *counters) {
-    if (t < n) {
-        const EMatch m = E[t];
-        uint64_t litLeft = m.posDest - pos;                                             // :216
-        if (v.p.enableExtensionsWithMismatches && !isGapBefore && litLeft) {            // :218-221
-            const ExtRes r = ext_left<false>(v, q, (int64_t) cg.n, litLeft, m, cg.lock, nullptr, nullptr);
-            s.lLit = r.nlit; s.lFl = r.nfl;
-            litLeft -= r.consumed;
-            counters[0] += r.matched; counters[1] += r.mism;
-        }
-        s.plain = (uint32_t) litLeft;
-    } else
-        s.plain = (uint32_t) (cg.n - pos);                                              // :288-289
-    s.pos = pos;
 }
 
 // sizes of every gap task, one block per chunk of 256 tasks
@@ -1116,19 +1185,48 @@ __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig
         pos = wide ? k.pos : gap_right<false>(v, cg, k, q, nullptr, nullptr, s, cloc);
     }
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    for (unsigned long long todo = __ballot(wide); todo; todo &= todo - 1) {      // the long gaps of this wave's tasks, one after the other, all lanes on each
+    for (unsigned long long todo = __ballot(wide); todo; todo &= todo - 1) {      // the long stretches of this wave's tasks, one after the other, all lanes on each
         const int l = __builtin_ctzll(todo);
         const uint32_t wpos = rl32(k.pos, l);
-        const WideRes r = ext_right_gap_wide<false>(v, q + wpos, (int64_t) rl64((uint64_t) k.src, l), rl32((uint32_t) k.litLeft, l),
-                                                    rl32(k.gStart, l) != 0, rl32(k.gEnd, l) != 0, nullptr, nullptr);
+        const ExtRes r = ext_right_wide<false>(v, q + wpos, (int64_t) rl64((uint64_t) k.src, l), rl32((uint32_t) k.litLeft, l), rl32(k.isGap, l) != 0,
+                                               rl32(k.gStart, l) != 0, rl32(k.gEnd, l) != 0, nullptr, nullptr);
         if ((int) lane == l) {
             s.rLit = r.nlit; s.rFl = r.nfl;
-            pos = k.pos + (uint32_t) k.litLeft;
-            cloc[0] += r.matched; cloc[1] += r.nlit;
+            pos = k.pos + r.consumed;
+            cloc[0] += r.matched; cloc[1] += r.mism;
+        }
+    }
+    // the left extension of match t (:218-221) and the plain literals in front of it
+    uint64_t litLeft = 0;
+    EMatch m = {0, 0, 0, 0};
+    bool wideL = false;
+    if (t <= n) {
+        if (t < n) {
+            m = E[t];
+            litLeft = m.posDest - pos;                                                      // :216
+            if (v.p.enableExtensionsWithMismatches && !k.isGap && litLeft) {
+                wideL = litLeft > EXT_WIDE_MIN;
+                if (!wideL) {
+                    const ExtRes r = ext_left<false>(v, q, (int64_t) cg.n, litLeft, m, cg.lock, nullptr, nullptr);
+                    s.lLit = r.nlit; s.lFl = r.nfl;
+                    litLeft -= r.consumed;
+                    cloc[0] += r.matched; cloc[1] += r.mism;
+                }
+            }
+        } else
+            litLeft = cg.n - pos;                                                           // :288-289
+    }
+    for (unsigned long long todo = __ballot(wideL); todo; todo &= todo - 1) {
+        const int l = __builtin_ctzll(todo);
+        const ExtRes r = ext_left_wide<false>(v, q, rl64(litLeft, l), rl64(m.posSrc, l), rl64(m.posDest, l), cg.lock, nullptr, nullptr);
+        if ((int) lane == l) {
+            s.lLit = r.nlit; s.lFl = r.nfl;
+            litLeft -= r.consumed;
+            cloc[0] += r.matched; cloc[1] += r.mism;
         }
     }
     if (t <= n) {
-        gap_sizes_left(v, cg, E, n, t, q, pos, k.isGap, s, cloc);
+        s.plain = (uint32_t) litLeft; s.pos = pos;
         uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
         z[0] = s.rLit; z[1] = s.rFl; z[2] = s.lLit; z[3] = s.lFl; z[4] = s.plain; z[5] = s.pos;
     }
@@ -1224,6 +1322,7 @@ __global__ void __launch_bounds__(CH) k_emit_place_scan(EmitView v, const EmitCo
 // the six streams of all contigs back to back, (contig, stream) major: the arena is written packed
 __global__ void __launch_bounds__(CH) k_emit_packoffs(EmitView v) {
     __shared__ uint32_t lds[CH / WAVE + 2];
+    if (threadIdx.x == 0) *v.longCount = 0;                          // (k_emit_write, behind this kernel, fills the list)
     uint64_t run = 0;
     for (uint32_t k0 = 0; k0 < v.ncontigs; k0 += CH) {
         const uint32_t k = k0 + threadIdx.x;
@@ -1292,8 +1391,10 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
     const uint8_t *longSrc = nullptr;
     uint8_t *longDst = nullptr;
     RightTask rk = {0, 0, 0, false, false, false, false};
-    bool wide = false;
-    uint8_t *wLit = nullptr, *wFl = nullptr;
+    bool wide = false, wideL = false;
+    uint8_t *wLit = nullptr, *wFl = nullptr, *wlLit = nullptr, *wlFl = nullptr;
+    EMatch lm = {0, 0, 0, 0};
+    uint64_t leftLen = 0;
     if (t <= n) {
         const EMatch *E = v.em + cg.scratchBase;
         const uint32_t *z = v.sz + (cg.scratchBase + t) * 6;
@@ -1303,13 +1404,21 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
         uint8_t *lLit = v.arena + pb[SWSEM_LIT] + w[0], *lFl = v.arena + pb[SWSEM_FLAGS] + w[1];
         uint8_t *plainDst = lLit + z[2];
         if (z[4] <= PLAIN_INLINE) for (uint32_t k = 0; k < z[4]; k++) plainDst[k] = q[z[5] + k];
-        else { longLen = z[4]; longSrc = q + z[5]; longDst = plainDst; }
+        else {
+            uint32_t slot = LONG_COPY_CAP;
+            if (z[4] >= LONG_COPY_MIN) slot = atomicAdd(v.longCount, 1u);                   // the unmatched stretch of a contig without a relative: megabytes
+            if (slot < LONG_COPY_CAP) { LongCopy lc; lc.dst = plainDst; lc.src = q + z[5]; lc.len = z[4]; v.longCopies[slot] = lc; }
+            else { longLen = z[4]; longSrc = q + z[5]; longDst = plainDst; }
+        }
         if (t < n) {
             const uint32_t *zn = z + 6;
             uint8_t *rLit = plainDst + z[4] + 1, *rFl = lFl + z[3];
             if (z[2] | z[3]) {
-                const EMatch m = E[t];
-                ext_left<true>(v, q, (int64_t) cg.n, m.posDest - z[5], m, cg.lock, lLit, lFl);
+                lm = E[t];
+                leftLen = lm.posDest - z[5];
+                wideL = leftLen > EXT_WIDE_MIN;
+                wlLit = lLit; wlFl = lFl;
+                if (!wideL) ext_left<true>(v, q, (int64_t) cg.n, leftLen, lm, cg.lock, lLit, lFl);
             }
             plainDst[z[4]] = MATCH_MARK;
             if (zn[0] | zn[1]) {
@@ -1333,10 +1442,15 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
         }
     }
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    for (unsigned long long todo = __ballot(wide); todo; todo &= todo - 1) {      // long gaps: the codes of one gap by all lanes
+    for (unsigned long long todo = __ballot(wideL); todo; todo &= todo - 1) {     // long extensions: the codes of one by all lanes
         const int l = __builtin_ctzll(todo);
-        ext_right_gap_wide<true>(v, q + rl32(rk.pos, l), (int64_t) rl64((uint64_t) rk.src, l), rl32((uint32_t) rk.litLeft, l),
-                                 rl32(rk.gStart, l) != 0, rl32(rk.gEnd, l) != 0, (uint8_t *) rl64((uint64_t) wLit, l), (uint8_t *) rl64((uint64_t) wFl, l));
+        ext_left_wide<true>(v, q, rl64(leftLen, l), rl64(lm.posSrc, l), rl64(lm.posDest, l), cg.lock, (uint8_t *) rl64((uint64_t) wlLit, l),
+                            (uint8_t *) rl64((uint64_t) wlFl, l));
+    }
+    for (unsigned long long todo = __ballot(wide); todo; todo &= todo - 1) {
+        const int l = __builtin_ctzll(todo);
+        ext_right_wide<true>(v, q + rl32(rk.pos, l), (int64_t) rl64((uint64_t) rk.src, l), rl32((uint32_t) rk.litLeft, l), rl32(rk.isGap, l) != 0,
+                             rl32(rk.gStart, l) != 0, rl32(rk.gEnd, l) != 0, (uint8_t *) rl64((uint64_t) wLit, l), (uint8_t *) rl64((uint64_t) wFl, l));
     }
     for (unsigned long long todo = __ballot(longLen != 0); todo; todo &= todo - 1) {
         const int l = __builtin_ctzll(todo);
@@ -1350,6 +1464,22 @@ __global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig
                 memcpy(dst + at, &x, 16);
             } else
                 for (uint32_t k = at; k < len; k++) dst[k] = src[k];
+        }
+    }
+}
+
+// the listed runs, 16 KB pieces dealt over all blocks
+__global__ void __launch_bounds__(256) k_emit_copy_long(EmitView v) {
+    const uint32_t n = *v.longCount < LONG_COPY_CAP ? *v.longCount : LONG_COPY_CAP;
+    constexpr uint64_t PIECE = 16384;
+    for (uint32_t e = 0; e < n; e++) {
+        const LongCopy lc = v.longCopies[e];
+        for (uint64_t at = (uint64_t) blockIdx.x * PIECE; at < lc.len; at += (uint64_t) gridDim.x * PIECE) {
+            const uint64_t end = at + PIECE < lc.len ? at + PIECE : lc.len;
+            for (uint64_t o = at + 16 * (uint64_t) threadIdx.x; o < end; o += 16 * 256) {
+                if (o + 16 <= end) { uint4 x; memcpy(&x, lc.src + o, 16); memcpy(lc.dst + o, &x, 16); }
+                else for (uint64_t k = o; k < end; k++) lc.dst[k] = lc.src[k];
+            }
         }
     }
 }

@@ -141,6 +141,8 @@ struct swsem {
         DevBuf<uint32_t> dEKeep, dEMeta, dECorr, dESz, dEOfs, dEChunk;
         DevBuf<MetaRec> dEStates;
         DevBuf<unsigned long long> dEStat, dEPm, dELit, dEBad;
+        DevBuf<LongCopy> dELong;
+        DevBuf<uint32_t> dELongCount;
         bool statZeroed = false;
         std::vector<EmitContig> ecg;
         std::vector<uint32_t> chunkOwner, spanOwner;
@@ -182,7 +184,7 @@ struct swsem {
         void release() {
             dECg.release(); dEOut.release(); dEWhich.release(); dEOwner.release(); dESpanOwner.release(); dEM.release(); dENext0.release(); dELoaded.release();
             dEPack.release(); dERm.release(); dEArena.release(); dEKeep.release(); dEMeta.release(); dECorr.release();
-            dESz.release(); dEOfs.release(); dEChunk.release(); dEStates.release(); dEStat.release(); dEPm.release(); dELit.release(); dEBad.release();
+            dESz.release(); dEOfs.release(); dEChunk.release(); dEStates.release(); dEStat.release(); dEPm.release(); dELit.release(); dEBad.release(); dELong.release(); dELongCount.release();
             if (pinE) { (void) hipHostFree(pinE); pinE = nullptr; pinECap = 0; }
             hostStreams.release();
             if (evDone) { (void) hipEventDestroy(evDone); evDone = nullptr; }
@@ -372,6 +374,7 @@ int run_phase2b(swsem *h, swsem::EmitSlot &E, bool gated) {
     k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
     k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
     k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
+    k_emit_copy_long<<<dim3(512), dim3(256), 0, h->stream2>>>(v);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
     int r2;
@@ -1439,7 +1442,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
             (r = E.dENext0.reserve(R)) || (r = E.dERm.reserve(R)) ||
             (r = E.dEKeep.reserve(R)) || (r = E.dEMeta.reserve(R)) || (r = E.dECorr.reserve(R)) ||
             (r = E.dESz.reserve(R * 6)) || (r = E.dEOfs.reserve(R * 6)) || (r = E.dEArena.reserve(A)) || (r = E.dELoaded.reserve(h->capLoaded)) ||
-            (r = E.dEStat.reserve(8)) || (r = E.dEPm.reserve(R)) || (r = E.dELit.reserve((size_t) Cn * (CH / WAVE))) || (r = E.dEBad.reserve(Cn)) || (r = E.dEOwner.reserve(Cn)) || (r = E.dESpanOwner.reserve(Cn)) || (r = E.dEStates.reserve((size_t) Cn * (CH / MB) * 2)) || (r = E.dEChunk.reserve((size_t) Cn * 6)) ||
+            (r = E.dEStat.reserve(8)) || (r = E.dELong.reserve(LONG_COPY_CAP)) || (r = E.dELongCount.reserve(4)) || (r = E.dEPm.reserve(R)) || (r = E.dELit.reserve((size_t) Cn * (CH / WAVE))) || (r = E.dEBad.reserve(Cn)) || (r = E.dEOwner.reserve(Cn)) || (r = E.dESpanOwner.reserve(Cn)) || (r = E.dEStates.reserve((size_t) Cn * (CH / MB) * 2)) || (r = E.dEChunk.reserve((size_t) Cn * 6)) ||
             (r = E.dEPack.reserve((size_t) N * SWSEM_NSTREAMS)))
             return r;
     }
@@ -1463,6 +1466,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     v.meta = E.dEMeta.p; v.corr = E.dECorr.p; v.sz = E.dESz.p; v.arena = E.dEArena.p; v.out = E.dEOut.p;
     v.packBase = E.dEPack.p;
     v.pairMask = E.dEPm.p; v.litBits = E.dELit.p; v.metaBad = E.dEBad.p;
+    v.longCopies = E.dELong.p; v.longCount = E.dELongCount.p;
     v.ofs = E.dEOfs.p;
     v.chunkCnt = E.dEChunk.p;
     v.chunkOwner = E.dEOwner.p; v.spanOwner = E.dESpanOwner.p;
