@@ -804,26 +804,20 @@ __device__ __forceinline__ int zero_hi(uint64_t w) {
 
 template <bool FWD>
 struct ByteWin {
-    static constexpr int N = 32;      // bytes per window: four loads in flight for one wait
     const uint8_t *__restrict__ base; // (never the arena the automata write to)
     int64_t hi;                       // bytes [0, hi) of base may be read
     int64_t at;
-    uint64_t w[N / 8];
-    __device__ __forceinline__ ByteWin(const uint8_t *b, int64_t limit) : base(b), hi(limit), at(INT64_MIN / 2) {}
+    uint64_t w;
+    __device__ __forceinline__ ByteWin(const uint8_t *b, int64_t limit) : base(b), hi(limit), at(INT64_MIN / 2), w(0) {}
     __device__ __forceinline__ uint8_t get(int64_t i) {
-        if (hi < N) return base[i];
-        if (i < at || i >= at + N) {
-            at = FWD ? i : i - (N - 1);
+        if (hi < 8) return base[i];
+        if (i < at || i >= at + 8) {
+            at = FWD ? i : i - 7;
             if (at < 0) at = 0;
-            if (at + N > hi) at = hi - N;
-#pragma unroll
-            for (int k = 0; k < N / 8; k++) __builtin_memcpy(&w[k], base + at + 8 * k, 8);
+            if (at + 8 > hi) at = hi - 8;
+            __builtin_memcpy(&w, base + at, 8);
         }
-        const int r = (int) (i - at);
-        uint64_t x = w[0];
-#pragma unroll
-        for (int k = 1; k < N / 8; k++) x = (r >> 3) == k ? w[k] : x;
-        return (uint8_t) (x >> (8 * (r & 7)));
+        return (uint8_t) (w >> (8 * (int) (i - at)));
     }
 };
 
