@@ -250,3 +250,37 @@ def test_long_gaps_between_paired_matches(binding, mode, lazy):
     for k in he.counters:
         assert he.counters[k] == oc[k], k
     assert len(oe.streams()["flags"]) > 140_000                      # (the long gaps are in the flags, a byte each)
+
+
+@pytest.mark.parametrize("bonus,penalty,threshold,initial,mode", [(50, 50, 500, 125, 1), (10, 70, 300, 0, 1), (100, 30, 90, 60, 1), (1, 1, 4, 0, 0),
+                                                                  (50, 50, 500, 500, 1), (0, 25, 2000, 10, 1)])
+def test_extensions_across_divergent_stretches_with_other_scores(binding, bonus, penalty, threshold, initial, mode):
+    """genomes a few percent apart: the extensions with mismatches run from one exact match to the next, hundreds of bytes to
+    kilobytes — on the device the whole wave walks such a stretch, the score automaton (MBGC_Encoder.cpp:346-365, 404-421) as a
+    prefix composition. The reference's scores (MBGC_Params.h:92-97) and others: a threshold reached early, late, at once, never."""
+    rng = np.random.default_rng(bonus * 7 + penalty)
+    base = synth.ACGT[rng.integers(0, 4, 300_000)]
+
+    def drift(g, rate, burst):
+        g = g.copy()
+        m = rng.random(g.size) < rate
+        for a in rng.integers(0, g.size - 4_000, 12):                      # stretches that diverge more than the rest
+            m[a:a + 3_000] |= rng.random(3_000) < burst
+        g[m] = synth.ACGT[rng.integers(0, 4, int(m.sum()))]
+        return g
+
+    files = [[base], [drift(base, 0.04, 0.25)], [drift(base, 0.07, 0.4)[:200_000], drift(base, 0.02, 0.15)[200_000:]], [drift(base, 0.10, 0.3)]]
+    over = dict(mmsMatchBonus=bonus, mmsMismatchPenalty=penalty, mmsMismatchesScoreThreshold=threshold, mmsMismatchesInitialScore=initial)
+    lim, _ = _driver.ref_length_limit(len(files), base.size)
+    h = binding.SlidingWindowSparseEMMatcher(lim)
+    o = _orc.OracleMatcher(lim)
+    he = HipEmitter(binding, h, binding.emit_params(mode, **over))
+    oe = _orc.OracleEmitter(o, _orc.emit_params(mode, **over))
+    a = _driver.encode_sequential(h, he, files)
+    b = _driver.encode_sequential(o, oe, files)
+    assert a["refExtSize"] == b["refExtSize"]
+    compare(he.streams(), oe.streams())
+    oc = oe.counters()
+    for k in he.counters:
+        assert he.counters[k] == oc[k], k
+    assert oc["extensionsMatchedChars"] > 100_000 or initial >= threshold
