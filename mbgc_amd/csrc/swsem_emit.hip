@@ -204,9 +204,14 @@ __global__ void __launch_bounds__(CH) k_emit_p1_scan(EmitView v, const EmitConti
     }
 }
 
-// (d) compaction; an abutting successor of a removed match is extended to the left (:180-186)
+// (d) compaction; an abutting successor of a removed match is extended to the left (:180-186). Also (e): unmatchedChars /
+// totalMatched with the reference's integer types (uint32 pos, :145,:193-196) as per-chunk partial sums — what lies between a
+// kept match and the kept match in front of it, which is its predecessor or, behind a removed one, the match before that (two
+// removed matches never follow each other; a left extension moves a match's start, not its end) — two u64 at the chunk's slot
+// of the size scratch, which nothing else uses before the second phase.
 __global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitContig *__restrict__ cgs, const int *__restrict__ which) {
     __shared__ uint32_t lds[CH / WAVE + 2];
+    __shared__ unsigned long long part[2 * (CH / WAVE)];
     const uint32_t gk = v.chunkOwner[blockIdx.x];
     const EmitContig cg = cgs[gk];
     const uint32_t gx = blockIdx.x - cg.chunk0;
@@ -218,37 +223,25 @@ __global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitCo
     const uint32_t keep = (j < n && !rm[j]) ? 1u : 0u;
     uint32_t tot;
     const uint32_t ex = block_scan<CH>(keep, lds, &tot);
-    if (!keep) return;
-    const uint32_t t = v.chunkCnt[(size_t) blockIdx.x] + ex;
-    EMatch e;
-    e.posSrc = M[j].posSrc; e.len = M[j].len; e.posDest = M[j].posDest;
-    if (j >= 1 && rm[j - 1] && M[j - 1].posDest + M[j - 1].len == M[j].posDest) {
-        int64_t s = (int64_t) e.posSrc, d = (int64_t) e.posDest;
-        uint64_t x = 0;
-        while (d - 1 >= 0 && s - 1 >= 0 && q[d - 1] == v.ref[s - 1]) { d--; s--; x++; }
-        e.posSrc -= x; e.posDest -= x; e.len += x;               // shiftStartPos(-leftExtension)
-    }
-    e.lp = 0;                                                     // (k_emit_meta_regions: nothing in this pass asks for it)
-    v.em[cg.scratchBase + t] = e;
-    v.keepIdx[cg.scratchBase + t] = (uint32_t) j;
-}
-
-// (e) unmatchedChars / totalMatched with the reference's integer types (uint32 pos, :145,:193-196): per-chunk
-// partial sums (two u64 at the chunk's slot of chunkCnt, whose kept-match offsets compaction has consumed) ...
-__global__ void __launch_bounds__(CH) k_emit_p1_sums(EmitView v, const EmitContig *__restrict__ cgs) {
-    __shared__ unsigned long long part[2 * (CH / WAVE)];
-    const uint32_t gk = v.chunkOwner[blockIdx.x];
-    const EmitContig cg = cgs[gk];
-    const uint32_t gx = blockIdx.x - cg.chunk0;
-    const uint32_t nk = (uint32_t) v.out[gk].nmatches;
-    if (gx * CH >= nk) return;
-    const uint32_t t = gx * CH + threadIdx.x;
-    const EMatch *E = v.em + cg.scratchBase;
     unsigned long long um = 0, tm = 0;
-    if (t < nk) {
-        const uint32_t pos = t ? (uint32_t) (E[t - 1].posDest + E[t - 1].len) : 0u;
-        um = E[t].posDest - (uint64_t) pos;
-        tm = (uint32_t) E[t].len;
+    if (keep) {
+        const uint32_t t = v.chunkCnt[(size_t) blockIdx.x] + ex;
+        EMatch e;
+        e.posSrc = M[j].posSrc; e.len = M[j].len; e.posDest = M[j].posDest;
+        const bool behindRemoved = j >= 1 && rm[j - 1];
+        if (behindRemoved && M[j - 1].posDest + M[j - 1].len == M[j].posDest) {
+            int64_t s = (int64_t) e.posSrc, d = (int64_t) e.posDest;
+            uint64_t x = 0;
+            while (d - 1 >= 0 && s - 1 >= 0 && q[d - 1] == v.ref[s - 1]) { d--; s--; x++; }
+            e.posSrc -= x; e.posDest -= x; e.len += x;               // shiftStartPos(-leftExtension)
+        }
+        e.lp = 0;                                                     // (k_emit_meta_regions: nothing in this pass asks for it)
+        v.em[cg.scratchBase + t] = e;
+        v.keepIdx[cg.scratchBase + t] = (uint32_t) j;
+        const int64_t jp = behindRemoved ? j - 2 : j - 1;            // the kept match in front
+        const uint32_t pos = jp >= 0 ? (uint32_t) (M[jp].posDest + M[jp].len) : 0u;
+        um = e.posDest - (uint64_t) pos;
+        tm = (uint32_t) e.len;
     }
     for (int d = WAVE / 2; d > 0; d >>= 1) {
         um += (unsigned long long) __shfl_down((long long) um, d);
@@ -259,12 +252,12 @@ __global__ void __launch_bounds__(CH) k_emit_p1_sums(EmitView v, const EmitConti
     if (threadIdx.x == 0) {
         unsigned long long a = 0, b = 0;
         for (int w = 0; w < CH / WAVE; w++) { a += part[2 * w]; b += part[2 * w + 1]; }
-        unsigned long long *o = (unsigned long long *) (v.chunkCnt + (size_t) blockIdx.x * 6);
+        unsigned long long *o = (unsigned long long *) (v.sz + (size_t) blockIdx.x * 6);
         o[0] = a; o[1] = b;
     }
 }
 
-// (f) ... summed per contig (one block each), the tail literal and the dissimilarity early-out (:200-205,
+// (f) the chunks' partial sums per contig (one block each), the tail literal and the dissimilarity early-out (:200-205,
 // isContigDissimilar MGMP_Params.h:193-196)
 __global__ void __launch_bounds__(CH) k_emit_p1_finish(EmitView v, const EmitContig *__restrict__ cgs) {
     __shared__ unsigned long long part[2 * (CH / WAVE)];
@@ -272,10 +265,11 @@ __global__ void __launch_bounds__(CH) k_emit_p1_finish(EmitView v, const EmitCon
     const EmitContig cg = cgs[k];
     EmitOut *o = v.out + k;
     const uint32_t nk = (uint32_t) o->nmatches;
-    const uint32_t nch = (nk + CH - 1) / CH;
+    const uint64_t nAll = o->nmatches + o->removed;                  // the chunks k_emit_p1_compact ran over: matches before the removal
+    const uint32_t nch = (uint32_t) ((nAll + CH - 1) / CH);
     unsigned long long um = 0, tm = 0;
     for (uint32_t c = threadIdx.x; c < nch; c += CH) {
-        const unsigned long long *p = (const unsigned long long *) (v.chunkCnt + ((size_t) cg.chunk0 + c) * 6);
+        const unsigned long long *p = (const unsigned long long *) (v.sz + ((size_t) cg.chunk0 + c) * 6);
         um += p[0]; tm += p[1];
     }
     for (int d = WAVE / 2; d > 0; d >>= 1) {

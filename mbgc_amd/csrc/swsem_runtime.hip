@@ -1476,7 +1476,6 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
     k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
     k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
-    k_emit_p1_sums<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p);
     k_emit_p1_finish<<<dim3(n), dim3(CH), 0, h->stream>>>(v, E.dECg.p);
     h->mark(SWSEM_K_EMIT, false);
     HIPCHK(hipGetLastError());
