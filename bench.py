@@ -255,27 +255,102 @@ def cpu_baseline(sample_targets, length, emit, max_ref):
     return allc
 
 
-def spawn_ranks(n):
+def error_line(n_gpus, steps, warm, msg, ranks_seen=None, extra=None):
+    """the line rank 0 prints when a run cannot produce a value: the same keys, value null, what went wrong"""
+    out = {"metric": "input Gbases/s (compress hot path, -m1: match-finding + stream emission)", "value": None, "unit": "Gbases/s",
+           "n_gpus": n_gpus, "steps": steps, "warmup": warm, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": {"workload": "configs[%d]" % (3 if n_gpus > 1 else 2)},
+           "error": msg, "rccl_ranks_seen": ranks_seen}
+    if extra:
+        out.update(extra)
+    return json.dumps(out)
+
+
+def spawn_ranks(n, argv=None, grace=5.0, limit=None):
     """`python bench.py --gpus N` outside a launcher: start N ranks of this script as children (this process has not
-    touched a GPU and never does), relay rank 0's JSON line, exit with the worst return code."""
+    touched a GPU and never does), relay rank 0's JSON line, exit with the worst return code.
+
+    A rank that dies must not leave the run hanging: the others would sit inside a collective until the process group's
+    timeout, and the caller would get no line at all. Every child is polled; on the first abnormal end the others get
+    `grace` seconds to notice by themselves (a gloo peer does, an RCCL peer may not), then SIGTERM, then SIGKILL, and a JSON
+    line with "value": null and the error is printed unless rank 0 already printed one. `limit` (MBGC_BENCH_TIMEOUT, seconds) bounds the whole run
+    the same way. argv: the children's command (tests pass their own)."""
+    import shutil
+    import signal
+    import tempfile
+    import threading
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    if limit is None:
+        limit = float(os.environ.get("MBGC_BENCH_TIMEOUT", "540"))
+    rundir = tempfile.mkdtemp(prefix="mbgc_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+    cmd = argv if argv is not None else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out.decode())
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MBGC_BENCH_RUNDIR=rundir)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      start_new_session=True))                  # (its own process group: workers it forks die with it)
+    with open(os.path.join(rundir, "pids"), "w") as f:
+        f.write(" ".join(str(p.pid) for p in procs) + "\n")
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+
+    def stop(p, sig):
+        try:
+            os.killpg(p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def on_signal(signum, _frame):                      # the spawner itself is told to end: the ranks go with it
+        for p in procs:
+            stop(p, signal.SIGKILL)
+        sys.exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, on_signal)
+
+    t0, failed, failed_at, cause_rc = time.monotonic(), None, None, 0
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        now = time.monotonic()
+        if failed is None:
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                failed = "rank %d ended %s while the run was going on" % (r, "on signal %d" % -c if c < 0 else "with exit code %d" % c)
+                failed_at, cause_rc = now, (c if c > 0 else 128 - c)
+            elif now - t0 > limit:
+                failed, failed_at = "the run exceeded its limit of %.0f s (MBGC_BENCH_TIMEOUT)" % limit, now - grace
+        if failed is not None:
+            if now - failed_at > grace + 5.0:
+                for p in procs:
+                    stop(p, signal.SIGKILL)
+            elif now - failed_at > grace:
+                for p in procs:
+                    stop(p, signal.SIGTERM)
+        time.sleep(0.1)
+    reader.join(timeout=5)
+    out = b"".join(c for c in chunks if c).decode(errors="replace")
+    rc = cause_rc                                       # the rank that failed first, not the ones stopped because of it
+    for p in procs:
+        rc = rc or (p.returncode if p.returncode > 0 else (128 - p.returncode if p.returncode < 0 else 0))
+    if failed is None and rc:
+        failed = "a rank ended with exit code %d" % rc
+    seen = len([f for f in os.listdir(rundir) if f.endswith(".up")])
+    shutil.rmtree(rundir, ignore_errors=True)
+    has_line = any(l.startswith("{") and '"metric"' in l for l in out.splitlines())
+    sys.stdout.write(out)
+    if failed is not None and not has_line:
+        print(error_line(n, 0, 0, failed, ranks_seen=seen))
+    if failed is not None:
+        print("bench.py: " + failed, file=sys.stderr)
     sys.stdout.flush()
-    sys.exit(rc)
+    sys.exit(rc or (1 if failed is not None else 0))
 
 
 def main():
@@ -351,10 +426,15 @@ def main():
         dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
                                 **({"device_id": dev} if backend == "nccl" else {}))
     if world > 1:
+        # a rank that never arrives (or dies inside a collective) ends the others after this long, not after torch's ten minutes
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=float(os.environ.get("MBGC_BENCH_PG_TIMEOUT", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
+        if os.environ.get("MBGC_BENCH_RUNDIR"):                      # (spawn_ranks counts these for its error line)
+            open(os.path.join(os.environ["MBGC_BENCH_RUNDIR"], "rank%d.up" % rank), "w").close()
 
     from mbgc_amd import binding
     from mbgc_amd.rounds import RoundRunner
@@ -590,4 +670,20 @@ def check_against_oracle(runner, base, targets, length, emit, max_ref):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:                                         # rank 0 still prints a line: value null and what went wrong
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0 and not isinstance(e, KeyboardInterrupt):
+            seen = None
+            try:
+                import torch.distributed as dist
+                seen = dist.get_world_size() if dist.is_initialized() else 0
+            except Exception:
+                pass
+            print(error_line(int(os.environ.get("WORLD_SIZE", "1")), 0, 0, "%s: %s" % (type(e).__name__, e), ranks_seen=seen), flush=True)
+        sys.stdout.flush()
+        os._exit(1)                                                     # (no destructors of a half-dead process group: they can hang)

@@ -483,8 +483,8 @@ __global__ void __launch_bounds__(WAVE) k_decode_plan(swsem_emit_params_t p, con
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_decode_fill(const uint8_t *__restrict__ ref, swsem_emit_params_t p, const DecodeJob *__restrict__ jobs,
                                                      const DecRec *__restrict__ recs, const uint64_t *__restrict__ recBase,
-                                                     const DecPlanOut *__restrict__ plans, uint32_t *__restrict__ badFlags, uint64_t refBytes) {
-    const uint32_t c = blockIdx.y;
+                                                     const DecPlanOut *__restrict__ plans, uint32_t *__restrict__ badFlags, uint64_t refBytes, uint32_t c0) {
+    const uint32_t c = c0 + blockIdx.y;                                     // (grid.y holds at most 65 535: the host launches slices of contigs)
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (plans[c].unmatched < 0 || (uint64_t) blockIdx.x * blockDim.x >= plans[c].nrec) return;
     // (a lane without a record of its own stays: the long pieces below are the work of all 64 lanes of a wave)
@@ -592,8 +592,8 @@ __global__ void __launch_bounds__(256) k_decode_fill(const uint8_t *__restrict__
 }
 
 // the contig the streams gave back against the one that was encoded: first differing byte per contig (DEC_NPOS: equal)
-__global__ void __launch_bounds__(256) k_decode_check(const DecodeJob *__restrict__ jobs, const DecPlanOut *__restrict__ plans, unsigned long long *__restrict__ firstDiff) {
-    const uint32_t c = blockIdx.y;
+__global__ void __launch_bounds__(256) k_decode_check(const DecodeJob *__restrict__ jobs, const DecPlanOut *__restrict__ plans, unsigned long long *__restrict__ firstDiff, uint32_t c0) {
+    const uint32_t c = c0 + blockIdx.y;
     const DecodeJob &jb = jobs[c];
     if (!jb.expect || plans[c].unmatched < 0) return;
     const uint64_t n = plans[c].destLen;

@@ -232,6 +232,14 @@ __global__ void __launch_bounds__(CH) k_emit_p1_compact(EmitView v, const EmitCo
         if (behindRemoved && M[j - 1].posDest + M[j - 1].len == M[j].posDest) {
             int64_t s = (int64_t) e.posSrc, d = (int64_t) e.posDest;
             uint64_t x = 0;
+            // (eight bytes a step where there are eight: a dependent load per byte of a run of dozens is what this kernel's
+            // slowest threads would be made of)
+            while (d >= 8 && s >= 8) {
+                uint64_t a, b;
+                __builtin_memcpy(&a, q + d - 8, 8); __builtin_memcpy(&b, v.ref + s - 8, 8);
+                if (a != b) break;
+                d -= 8; s -= 8; x += 8;
+            }
             while (d - 1 >= 0 && s - 1 >= 0 && q[d - 1] == v.ref[s - 1]) { d--; s--; x++; }
             e.posSrc -= x; e.posDest -= x; e.len += x;               // shiftStartPos(-leftExtension)
         }

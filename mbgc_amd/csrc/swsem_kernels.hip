@@ -27,6 +27,13 @@ __global__ void __launch_bounds__(256) k_load_rc(const uint8_t *__restrict__ src
 }
 
 __global__ void k_set_byte(uint8_t *p, uint8_t v) { *p = v; }
+__global__ void k_touch() {}                        // a stream's first launch (it is given its hardware queue then)
+// keeps being dispatched for as long as it runs (more workgroups than the device holds, each `ticks` of the 100 MHz clock long):
+// what a stream that shares its dispatch pipe has to wait for (swsem_runtime.hip, side_streams)
+__global__ void __launch_bounds__(256) k_hog(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 
 // The byte writes of a whole finalize call (swsem_finalize_targets): every extension copied to its place
 // in the reference buffer by one launch (block = 4096 bytes of one piece, 16 bytes per thread, any
@@ -38,22 +45,26 @@ struct BytePiece { uint64_t off, val; };
 __global__ void __launch_bounds__(256) k_copy_multi(uint8_t *__restrict__ ref, const CopyPiece *__restrict__ pieces,
                                                     const uint64_t *__restrict__ first, int np, const uint32_t *__restrict__ gate) {
     if (gate && *gate == 0) return;
-    int lo = 0, hi = np - 1;                                        // piece p with first[p] <= blockIdx.x < first[p+1]
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) / 2;
-        if (first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    // (a grid no larger than the device holds at once, walking the blocks: a launch that keeps being dispatched while it runs
+    // holds its hardware queue's pipe, and whatever shares that pipe waits for its last workgroup — profiles/queue_pipes.hip)
+    for (uint64_t blk = blockIdx.x; blk < first[np]; blk += gridDim.x) {
+        int lo = 0, hi = np - 1;                                        // piece p with first[p] <= blk < first[p+1]
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) / 2;
+            if (first[mid] <= blk) lo = mid; else hi = mid - 1;
+        }
+        const CopyPiece pc = pieces[lo];
+        const uint64_t o = (blk - first[lo]) * 4096 + 16 * (uint64_t) threadIdx.x;
+        if (o >= pc.len) continue;
+        uint8_t *d = ref + pc.dst + o;
+        const uint8_t *s = pc.src + o;
+        if (o + 16 <= pc.len) {
+            uint4 t;
+            memcpy(&t, s, 16);
+            memcpy(d, &t, 16);
+        } else
+            for (uint64_t k = 0; k < pc.len - o; k++) d[k] = s[k];
     }
-    const CopyPiece pc = pieces[lo];
-    const uint64_t o = ((uint64_t) blockIdx.x - first[lo]) * 4096 + 16 * (uint64_t) threadIdx.x;
-    if (o >= pc.len) return;
-    uint8_t *d = ref + pc.dst + o;
-    const uint8_t *s = pc.src + o;
-    if (o + 16 <= pc.len) {
-        uint4 t;
-        memcpy(&t, s, 16);
-        memcpy(d, &t, 16);
-    } else
-        for (uint64_t k = 0; k < pc.len - o; k++) d[k] = s[k];
 }
 // host tables staged in pinned memory -> device (a plain kernel: the runtime's own host-to-device copies can
 // block the calling thread for milliseconds on a side stream)
@@ -133,42 +144,48 @@ __global__ void __launch_bounds__(256) k_insert(const uint8_t *__restrict__ ref,
 // window reaches outside [lo, hi) — into the previous text, a separator — are left to a small launch over the buffer
 // once the copy has landed (the host lists them as runs of their own).
 struct InsertPiece { uint64_t S, nMain, T, nTail; uint32_t epoch, tag; const uint8_t *src; uint64_t lo, hi; };   // tag: lap_tag of the lap being loaded
+__device__ __forceinline__ bool insert_sample(const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first, int np, int k1, uint64_t g,
+                                              InsertPiece &pc, uint64_t &p, bool &tail) {
+    int lo = 0, hi = np;                               // largest p with first[p] <= g
+    while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (first[mid] <= g) lo = mid; else hi = mid; }
+    pc = pieces[lo];
+    const uint64_t t = g - first[lo];
+    tail = t >= pc.nMain;
+    p = tail ? pc.T + (t - pc.nMain) * (uint64_t) k1 : pc.S + t * (uint64_t) k1;
+    return true;
+}
 template<bool FROM_SRC>
 __global__ void __launch_bounds__(256) k_insert_multi(const uint8_t *__restrict__ ref, ht_entry *__restrict__ ht,
                                                       const InsertPiece *__restrict__ pieces, const uint64_t *__restrict__ first,
                                                       int np, int k1, int k1ord, int K, uint32_t mask, int fpBits,
                                                       const uint32_t *__restrict__ gate, uint16_t *__restrict__ tags) {
     if (gate && *gate == 0) return;
-    const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (g0 >= first[np]) return;
-    // The newest samples first: the table keeps the largest key of a bucket, a round's targets share most of their
-    // K-mers, and a sample that finds its bucket already holding a larger key (checked with a plain read below) has
-    // nothing to do — scattered atomics are what this kernel's time is made of (0.28 -> 0.23 ms).
-    const uint64_t g = first[np] - 1 - g0;
-    int lo = 0, hi = np;                               // largest p with first[p] <= g
-    while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (first[mid] <= g) lo = mid; else hi = mid; }
-    const InsertPiece pc = pieces[lo];
-    const uint64_t t = g - first[lo];
-    const bool tail = t >= pc.nMain;
-    const uint64_t p = tail ? pc.T + (t - pc.nMain) * (uint64_t) k1 : pc.S + t * (uint64_t) k1;
-    const uint8_t *s = ref + p;
-    if (FROM_SRC) {
-        if (!pc.src || p < pc.lo || p + (uint64_t) K > pc.hi) return;
-        s = pc.src + (p - pc.lo);
+    const uint64_t total = first[np];
+    // (the grid may be smaller than the samples: see k_copy_multi)
+    for (uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; g0 < total; g0 += (uint64_t) gridDim.x * blockDim.x) {
+        // The newest samples first: the table keeps the largest key of a bucket, a round's targets share most of their
+        // K-mers, and a sample that finds its bucket already holding a larger key (checked with a plain read below) has
+        // nothing to do — scattered atomics are what this kernel's time is made of (0.28 -> 0.23 ms).
+        const uint64_t g = total - 1 - g0;
+        InsertPiece pc; uint64_t p; bool tail;
+        insert_sample(pieces, first, np, k1, g, pc, p, tail);
+        const uint8_t *s = ref + p;
+        if (FROM_SRC) {
+            if (!pc.src || p < pc.lo || p + (uint64_t) K > pc.hi) continue;
+            s = pc.src + (p - pc.lo);
+        }
+        if (tags && (p & ((1ull << k1ord) - 1)) == 0) tags[p >> k1ord] = (uint16_t) pc.tag;    // sampled on the grid in this lap (lap_want)
+        uint32_t h = (uint32_t) K, f = FP_SEED;
+        const int nw = K / 4;
+        for (int j = 0; j < nw; j++) { const uint32_t w = ld_u32(s + 4 * j); h = hash_step(h, w, (uint32_t) j); f = fp_step(f, w); }
+        const uint32_t off = (uint32_t) (p & ((1ull << k1ord) - 1));
+        if (off && p >= off && (!FROM_SRC || p - off >= pc.lo)) f = fp_at(s - off, nw);   // a sample off the grid (see fp_at)
+        const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), f, fpBits);
+        const ht_entry seen = ht[h & mask];
+        if (seen >= key) continue;                         // (entries only grow: a stale read shows a smaller one at worst, then the atomic decides)
+        atomicMax(&ht[h & mask], key);
     }
-    if (tags && (p & ((1ull << k1ord) - 1)) == 0) tags[p >> k1ord] = (uint16_t) pc.tag;    // sampled on the grid in this lap (lap_want)
-    uint32_t h = (uint32_t) K, f = FP_SEED;
-    const int nw = K / 4;
-    for (int j = 0; j < nw; j++) { const uint32_t w = ld_u32(s + 4 * j); h = hash_step(h, w, (uint32_t) j); f = fp_step(f, w); }
-    const uint32_t off = (uint32_t) (p & ((1ull << k1ord) - 1));
-    if (off && p >= off && (!FROM_SRC || p - off >= pc.lo)) f = fp_at(s - off, nw);   // a sample off the grid (see fp_at)
-    const ht_entry key = ht_key(pc.epoch + (tail ? 1u : 0u), (uint32_t) (p >> k1ord), f, fpBits);
-#ifndef SWSEM_INSERT_NOREAD
-    if (ht[h & mask] >= key) return;                   // (entries only grow: a stale read shows a smaller one at worst, then the atomic decides)
-#endif
-    atomicMax(&ht[h & mask], key);
 }
-
 // The K-mer starting at p is about to lose its last byte to a separator (loadSeparator at the window's end, .cpp:439-451)
 // after it may have been hashed: if the table still holds its sample, the entry keeps its position — the reference
 // would still follow it — but its epoch becomes 0 = "do not trust the fingerprint" (ht_value).

@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +63,77 @@ struct DevBuf {
 
 struct ProfEvent { hipEvent_t a, b; int fam; };
 
+// ------------------------------------------------------------------------------------------------------------------
+// The side streams: a process-wide pool per device, dealt to a handle by MEASUREMENT.
+// A HIP stream's hardware queue is served by one of the device's four dispatch pipes (the k-th queue a process makes
+// goes to pipe k mod 4, whatever its priority: profiles/queue_pipes.hip), and a pipe works on one launch at a time: a
+// kernel with more workgroups than the device holds keeps its pipe until its last workgroup has been dispatched, and a
+// kernel queued meanwhile on another stream of the same pipe starts behind it. Which pipe the caller's stream sits on
+// depends on how many queues its framework made before — the step time of a round moved between 2.6 and 3.0 ms with
+// nothing but that (profiles/r04_stream_pipes.md). So the library makes eight candidate streams once, finds out which
+// of them get in each other's way (a long-dispatch kernel on one, a one-workgroup kernel on the other), and gives every
+// handle streams that do not share a pipe with its main stream or with each other where both are busy at once:
+//   stream2     low     the byte automata of an emission's second phase (beside the next batch's chains, then the stitch)
+//   streamAux   normal  the stitch (beside the chains' tail), later the emission's pairing kernels (beside the insertion)
+//   streamLoad  high    the finalize's copies (beside the insertion)
+//   streamUp    normal  table uploads (a few microseconds at a batch's start)
+// SWSEM_STREAM_CALIB=0: no measurement, the candidates in the order they were made.
+struct SidePool {
+    static constexpr int NC = 8;
+    bool made = false, ok = false;
+    hipStream_t cand[NC] = {};
+    int cls[NC] = {1, 1, 1, 1, 0, 0, 2, 2};     // 0 low, 1 normal, 2 high priority
+    int label[NC] = {};                          // candidates with one label get in each other's way
+    unsigned wgs = 8192;
+};
+SidePool g_pools[16];
+std::mutex g_poolMu;
+
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// does a one-workgroup kernel on b wait for a long-dispatch kernel on a?
+bool streams_collide(hipStream_t a, hipStream_t b, unsigned wgs) {
+    int hits = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        (void) hipStreamSynchronize(a); (void) hipStreamSynchronize(b);
+        const double t0 = now_us();
+        k_hog<<<dim3(wgs), dim3(256), 0, a>>>(1500);                 // 15 us per workgroup, four generations of them
+        k_touch<<<1, 1, 0, b>>>();
+        (void) hipStreamSynchronize(b);
+        const double t1 = now_us();
+        (void) hipStreamSynchronize(a);
+        const double t2 = now_us();
+        if (t1 - t0 > 0.6 * (t2 - t0)) hits++;
+    }
+    return hits == 2;
+}
+
+SidePool *side_pool(int device, int prioLow, int prioHigh) {
+    if (device < 0 || device >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_poolMu);
+    SidePool &P = g_pools[device];
+    if (P.made) return P.ok ? &P : nullptr;
+    P.made = true;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) P.wgs = (unsigned) pr.multiProcessorCount * 8u * 4u;
+    for (int i = 0; i < SidePool::NC; i++) {
+        const int pv = P.cls[i] == 0 ? prioLow : (P.cls[i] == 2 ? prioHigh : (prioLow + prioHigh) / 2);
+        if (hipStreamCreateWithPriority(&P.cand[i], hipStreamNonBlocking, pv) != hipSuccess) return nullptr;
+        k_touch<<<1, 1, 0, P.cand[i]>>>();                            // first use: the stream is given its hardware queue now
+        if (hipStreamSynchronize(P.cand[i]) != hipSuccess) return nullptr;
+    }
+    const char *e = getenv("SWSEM_STREAM_CALIB");
+    const bool measure = !(e && atoi(e) == 0);
+    for (int i = 0; i < SidePool::NC; i++) {
+        P.label[i] = i;
+        for (int j = 0; measure && j < i; j++)
+            if (P.label[j] == j && streams_collide(P.cand[j], P.cand[i], P.wgs)) { P.label[i] = j; break; }
+    }
+    (void) hipGetLastError();
+    P.ok = true;
+    return &P;
+}
+
 }  // namespace
 
 struct swsem {
@@ -107,6 +180,20 @@ struct swsem {
         uint64_t *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false;
     } hostTables[2];
     int hostTableSel = 0;
+    // what prepare_inserts has uploaded for the launches that follow (launch_insert_early / launch_inserts)
+    struct PreparedInserts {
+        size_t np = 0, nc = 0, nb = 0, ne = 0;
+        bool beside = false;
+        uint64_t nSamples = 0, nEdge = 0, copyBlocks = 0;
+        const InsertPiece *dPieces = nullptr, *dEdge = nullptr;
+        const uint64_t *dFirst = nullptr, *dCFirst = nullptr, *dEFirst = nullptr;
+        const CopyPiece *dCopies = nullptr;
+        const BytePiece *dBytes = nullptr;
+    } prep;
+    uint64_t copyWgs = 2048;               // workgroups of the copies (a grid that is resident at once: k_copy_multi)
+    hipStream_t streamUp = nullptr, streamAux = nullptr;      // (dealt from the device's pool, like stream2 and streamLoad: deal_streams) table uploads; the stitch and the pairing kernels
+    hipEvent_t evStitched = nullptr, evTables = nullptr, evRoundTop = nullptr;
+    bool roundTopFresh = false;            // evRoundTop was recorded by the batch this emission belongs to (run_batch), not an older one
     // --- per-round scratch
     DevBuf<uint8_t> stage;                 // host text / host query staging
     DevBuf<Contig> dContigs;
@@ -114,7 +201,11 @@ struct swsem {
     std::vector<uint32_t> rbOrderHost, rbOrderKey;   // the table on the device is kept while the batches keep their shape (rbOrderKey)
     bool simt = true;                      // four chains per wave (k_resolve_blocks4); SWSEM_CHAINS=1: one chain per wave (k_resolve_blocks)
     uint32_t chainsPerWave = 1;            // of the last batch
-    hipStream_t stream3 = nullptr;         // device-to-host copies of emitted streams (end_slot)
+    hipStream_t stream3 = nullptr;         // device-to-host copies of emitted streams (end_slot): made when first needed (see s3)
+    hipStream_t s3() {
+        if (!stream3 && hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking) != hipSuccess) stream3 = stream;
+        return stream3;
+    }
     hipEvent_t evMatched = nullptr;        // chains of the last batch done
     std::vector<uint32_t> rbContigHost;
     DevBuf<Match> dMatches;
@@ -150,6 +241,7 @@ struct swsem {
         std::vector<uint64_t> eloaded;
         std::vector<EmitOut> eout;
         hipEvent_t evDone = nullptr;
+        hipEvent_t evMetaDone = nullptr;     // behind the pairing kernels (the byte automata wait for it)
         bool outstanding = false, refGuarded = false;
         bool donePending = false;            // evDone has not been recorded for this emission yet (its byte automata are queued behind the speculative finalize)
         // the byte automata of the second phase wait to be queued: at the next batch's resolve launch, gated on that kernel's
@@ -188,6 +280,7 @@ struct swsem {
             if (pinE) { (void) hipHostFree(pinE); pinE = nullptr; pinECap = 0; }
             hostStreams.release();
             if (evDone) { (void) hipEventDestroy(evDone); evDone = nullptr; }
+            if (evMetaDone) { (void) hipEventDestroy(evMetaDone); evMetaDone = nullptr; }
         }
     } slot[2];
     int latest = 0;                          // slot of the last swsem_emit_batch_begin
@@ -364,6 +457,7 @@ int run_phase2b(swsem *h, swsem::EmitSlot &E, bool gated) {
         HIPCHK(hipEventRecord(h->evFin, h->stream));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->evFin, 0));
     }
+    HIPCHK(hipStreamWaitEvent(h->stream2, E.evMetaDone, 0));          // the pairing kernels' results (their own stream)
     const EmitView &v = E.v2b;
     const dim3 grid2(E.grid2b);
     const int n = E.n2b;
@@ -466,15 +560,63 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
     return SWSEM_OK;
 }
 
+// the handle's side streams out of the device's pool (see SidePool): by what shares a dispatch pipe with its main stream
+int deal_streams(swsem *h) {
+    SidePool *P = side_pool(h->device, h->prioLow, h->prioHigh);
+    if (!P) return fail(SWSEM_EHIP, "cannot make the side streams");
+    constexpr int NC = SidePool::NC;
+    const char *e = getenv("SWSEM_STREAM_CALIB");
+    const bool measure = !(e && atoi(e) == 0);
+    bool mainHits[NC] = {};
+    for (int i = 0; measure && i < NC; i++)
+        if (P->label[i] == i) mainHits[i] = streams_collide(h->stream, P->cand[i], P->wgs);
+    (void) hipGetLastError();
+    int chosen[4] = {-1, -1, -1, -1};                                // stream2, load, aux, up
+    // penalties: sharing a pipe with the main stream, with a role that is busy at the same time, being another role's stream
+    const int cls[4] = {0, 2, 1, 1};
+    const int clash[4][4] = {{0, 0, 0, 0}, {60, 0, 0, 0}, {60, 10, 0, 0}, {60, 0, 5, 0}};   // [role][earlier role]
+    const int withMain[4] = {100, 100, 100, 20};
+    for (int r = 0; r < 4; r++) {
+        int best = -1, bestCost = 1 << 30;
+        for (int i = 0; i < NC; i++) {
+            if (P->cls[i] != cls[r]) continue;
+            int cost = mainHits[P->label[i]] ? withMain[r] : 0;
+            for (int q = 0; q < r; q++) {
+                if (chosen[q] == i) cost += 1000;
+                else if (P->label[chosen[q]] == P->label[i]) cost += clash[r][q];
+            }
+            if (cost < bestCost) { bestCost = cost; best = i; }
+        }
+        if (best < 0) return fail(SWSEM_EHIP, "no side stream of the class wanted");
+        chosen[r] = best;
+    }
+    h->stream2 = P->cand[chosen[0]]; h->streamLoad = P->cand[chosen[1]]; h->streamAux = P->cand[chosen[2]]; h->streamUp = P->cand[chosen[3]];
+    if (getenv("SWSEM_STREAM_DEBUG")) {
+        fprintf(stderr, "swsem side streams: labels");
+        for (int i = 0; i < NC; i++) fprintf(stderr, " %d%s", P->label[i], mainHits[P->label[i]] ? "*" : "");
+        fprintf(stderr, " (* shares the main stream's pipe); stream2 %d, load %d, aux %d, up %d\n", chosen[0], chosen[1], chosen[2], chosen[3]);
+    }
+    return SWSEM_OK;
+}
+
 int flush_inserts(swsem *h, const uint32_t *gate = nullptr);
+int prepare_inserts(swsem *h, hipStream_t upStream);
+int launch_inserts(swsem *h, const uint32_t *gate);
 }  // namespace
 // (defined below, after run_batch's helpers)
 namespace {
-// everything collected while deferInserts was set: all copies in one launch, the separator bytes in one
-// (in program order; no copy of a round lands on a byte written by an earlier separator of the same
-// round), then every insertion phase in one launch. The tables travel in a single upload.
-int flush_inserts(swsem *h, const uint32_t *gate) {
+// Everything collected while deferInserts was set: all copies in one launch, the separator bytes in one (in program
+// order; no copy of a round lands on a byte written by an earlier separator of the same round), then every insertion
+// phase in one launch. The tables travel in a single upload. Two steps:
+//   prepare_inserts      the host tables (pinned) and their upload on `upStream` (the speculative finalize's travel with the
+//                        emission's own tables while the chains still run, not between pass 1 and the copies)
+//   launch_inserts       the launches on the main stream: copies (on their stream), separators, the insertion, the samples at
+//                        the pieces' edges
+int prepare_inserts(swsem *h, hipStream_t upStream) {
+    swsem::PreparedInserts &P = h->prep;
+    P = swsem::PreparedInserts();
     const size_t np = h->pendingPieces.size(), nc = h->pendingCopies.size(), nb = h->pendingBytes.size();
+    P.np = np; P.nc = nc; P.nb = nb;
     if (!np && !nc && !nb) return SWSEM_OK;
     // (every copy and byte collected here went through ref_write_guard when it was collected — load_pieces,
     // swsem_load_separator — with the lap count of that moment; one test of the whole span would take the two halves of a
@@ -535,8 +677,7 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
         ht.cap = want;
     }
     if (!ht.ev) HIPCHK(hipEventCreateWithFlags(&ht.ev, hipEventDisableTiming));
-    struct { uint64_t *p; uint64_t *data() { return p; } size_t n; size_t size() const { return n; } } tab = {ht.p, words};
-    uint64_t *tPieces = tab.data(), *tFirst = tPieces + wPieces, *tCopies = tFirst + np + 1, *tCFirst = tCopies + wCopies, *tBytes = tCFirst + nc + 1,
+    uint64_t *tPieces = ht.p, *tFirst = tPieces + wPieces, *tCopies = tFirst + np + 1, *tCFirst = tCopies + wCopies, *tBytes = tCFirst + nc + 1,
              *tEdge = tBytes + wBytes, *tEFirst = tEdge + wEdge;
     if (np) memcpy(tPieces, h->pendingPieces.data(), np * sizeof(InsertPiece));
     tFirst[0] = 0;
@@ -549,49 +690,63 @@ int flush_inserts(swsem *h, const uint32_t *gate) {
     tEFirst[0] = 0;
     for (size_t i = 0; i < ne; i++) tEFirst[i + 1] = tEFirst[i] + edge[i].nMain;
     int r;
-    if ((r = h->dTables.reserve(std::max<size_t>(2 * tab.size(), 1 << 16)))) return r;   // regrowing = hipFree = a device-wide wait
+    if ((r = h->dTables.reserve(std::max<size_t>(2 * words, 1 << 16)))) return r;   // regrowing = hipFree = a device-wide wait
     // (a kernel reading the pinned table: a runtime copy here costs an engine switch in the middle of the main stream)
-    k_upload<<<dim3((unsigned) ((tab.size() * 8 + 4095) / 4096)), dim3(256), 0, h->stream>>>((uint8_t *) h->dTables.p, (const uint8_t *) tab.data(), tab.size() * 8);
-    HIPCHK(hipEventRecord(ht.ev, h->stream));
+    k_upload<<<dim3((unsigned) ((words * 8 + 4095) / 4096)), dim3(256), 0, upStream>>>((uint8_t *) h->dTables.p, (const uint8_t *) ht.p, words * 8);
+    HIPCHK(hipEventRecord(ht.ev, upStream));
     ht.pending = true;
     const uint64_t *d = h->dTables.p;
-    hipStream_t cs = h->stream;                                    // the copies' stream
-    if (beside) {
+    P.beside = beside; P.ne = ne;
+    P.nSamples = tFirst[np]; P.nEdge = tEFirst[ne]; P.copyBlocks = tCFirst[nc];
+    P.dPieces = (const InsertPiece *) (d + (tPieces - ht.p)); P.dFirst = d + (tFirst - ht.p);
+    P.dCopies = (const CopyPiece *) (d + (tCopies - ht.p)); P.dCFirst = d + (tCFirst - ht.p);
+    P.dBytes = (const BytePiece *) (d + (tBytes - ht.p));
+    P.dEdge = (const InsertPiece *) (d + (tEdge - ht.p)); P.dEFirst = d + (tEFirst - ht.p);
+    h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear();
+    HIPCHK(hipGetLastError());
+    return SWSEM_OK;
+}
+
+int launch_inserts(swsem *h, const uint32_t *gate) {
+    hipStream_t sV = h->stream;
+    swsem::PreparedInserts &P = h->prep;
+    const size_t np = P.np, nc = P.nc, nb = P.nb, ne = P.ne;
+    if (!np && !nc && !nb) return SWSEM_OK;
+    hipStream_t cs = sV;                                           // the copies' stream
+    if (P.beside) {
         // (its own priority class: the runtime deals the streams of one class over a handful of hardware queues, and a copy
         // that lands on the queue of the emission's second phase runs behind 2 ms of its kernels — seen in a kernel trace)
-        if (!h->streamLoad && (hipStreamCreateWithPriority(&h->streamLoad, hipStreamNonBlocking, h->prioHigh) != hipSuccess ||
-                               hipEventCreateWithFlags(&h->evLoadFork, hipEventDisableTiming) != hipSuccess ||
-                               hipEventCreateWithFlags(&h->evLoadDone, hipEventDisableTiming) != hipSuccess))
-            return fail(SWSEM_EHIP, "hipStreamCreate failed");
         cs = h->streamLoad;
-        HIPCHK(hipEventRecord(h->evLoadFork, h->stream));            // (behind the tables, the gate and every wait the writes were given)
+        HIPCHK(hipEventRecord(h->evLoadFork, sV));                   // (behind the tables, the gate and every wait the writes were given)
         HIPCHK(hipStreamWaitEvent(cs, h->evLoadFork, 0));
     }
     if (nc) {
         h->mark(SWSEM_K_LOAD, true, cs);
-        k_copy_multi<<<dim3((unsigned) tCFirst[nc]), dim3(256), 0, cs>>>(h->ref, (const CopyPiece *) (d + (tCopies - tab.data())),
-                                                                       d + (tCFirst - tab.data()), (int) nc, gate);
+        k_copy_multi<<<dim3((unsigned) std::min<uint64_t>(P.copyBlocks, h->copyWgs)), dim3(256), 0, cs>>>(h->ref, P.dCopies, P.dCFirst, (int) nc, gate);
         h->mark(SWSEM_K_LOAD, false, cs);
     }
-    if (nb) k_set_bytes<<<1, 1, 0, cs>>>(h->ref, (const BytePiece *) (d + (tBytes - tab.data())), (int) nb, gate);
-    if (beside) HIPCHK(hipEventRecord(h->evLoadDone, cs));
-    if (np) {
+    if (nb) k_set_bytes<<<1, 1, 0, cs>>>(h->ref, P.dBytes, (int) nb, gate);
+    if (P.beside) HIPCHK(hipEventRecord(h->evLoadDone, cs));
+    if (np && P.nSamples) {
         h->mark(SWSEM_K_INSERT, true);
-        const dim3 grid((unsigned) ((tFirst[np] + 255) / 256));
-        const InsertPiece *dp = (const InsertPiece *) (d + (tPieces - tab.data()));
-        if (beside) k_insert_multi<true><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, dp, d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
-        else k_insert_multi<false><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, dp, d + (tFirst - tab.data()), (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
+        const dim3 grid((unsigned) ((P.nSamples + 255) / 256));
+        if (P.beside) k_insert_multi<true><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, P.dPieces, P.dFirst, (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
+        else k_insert_multi<false><<<grid, dim3(256), 0, h->stream>>>(h->ref, h->ht, P.dPieces, P.dFirst, (int) np, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
         h->mark(SWSEM_K_INSERT, false);
     }
-    if (beside) {
+    if (P.beside) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->evLoadDone, 0));
-        if (ne && tEFirst[ne])
-            k_insert_multi<false><<<dim3((unsigned) ((tEFirst[ne] + 255) / 256)), dim3(256), 0, h->stream>>>(
-                h->ref, h->ht, (const InsertPiece *) (d + (tEdge - tab.data())), d + (tEFirst - tab.data()), (int) ne, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
+        if (ne && P.nEdge)
+            k_insert_multi<false><<<dim3((unsigned) ((P.nEdge + 255) / 256)), dim3(256), 0, h->stream>>>(
+                h->ref, h->ht, P.dEdge, P.dEFirst, (int) ne, h->k1, h->k1ord, h->K, h->mask, h->fpBits, gate, h->tags);
     }
     HIPCHK(hipGetLastError());
-    h->pendingPieces.clear(); h->pendingCopies.clear(); h->pendingBytes.clear();
     return SWSEM_OK;
+}
+
+int flush_inserts(swsem *h, const uint32_t *gate) {
+    int r = prepare_inserts(h, h->stream);
+    return r ? r : launch_inserts(h, gate);
 }
 
 // Small copies between host and device go through pinned host memory that is mapped into the device's address
@@ -638,7 +793,9 @@ int upload(swsem *h, void *dst, const void *src, size_t bytes, hipStream_t st) {
         { int r = flush_copies(h); if (r) return r; }
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipStreamSynchronize(h->stream2));
-        HIPCHK(hipStreamSynchronize(h->stream3));
+        if (h->stream3) HIPCHK(hipStreamSynchronize(h->s3()));
+        HIPCHK(hipStreamSynchronize(h->streamUp));
+        HIPCHK(hipStreamSynchronize(h->streamAux));
         h->ringAt = 0;
     }
     uint8_t *slot = h->ring + h->ringAt;
@@ -761,11 +918,16 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
     const bool wrapped = v.fpCheck == 2;                // kernels instantiated with / without the lap epochs (ht_value)
     if (h->seqResolve || rblocks == 0)
         for (auto &E : h->slot) if ((r = run_phase2b(h, E, false))) return r;
+    // "this batch begins here": everything queued on the main stream before it has finished when this event has (the uploads
+    // of the emission that follows wait for nothing else, emit_begin_impl)
+    HIPCHK(hipEventRecord(h->evRoundTop, h->stream));
+    h->roundTopFresh = true;
     if (h->seqResolve || rblocks == 0) {
         h->mark(SWSEM_K_RESOLVE, true);
         if (wrapped) k_resolve_seq<true><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dMatches.p, h->dMatchCount.p);
         else k_resolve_seq<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dMatches.p, h->dMatchCount.p);
         h->mark(SWSEM_K_RESOLVE, false);
+        HIPCHK(hipEventRecord(h->evStitched, h->stream));
     } else {
         // rows a block chain can hold: disjoint matches, each containing the K-mer of a distinct visited hit
         const uint32_t cap = (uint32_t) ((h->rb * RBU + OVERLAP_MAX + h->K) / h->K + 8);
@@ -807,6 +969,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
                                                                           h->dKeepN.p, h->dPrev.p, h->dDstOff.p, h->dMatchCount.p, h->dStats.p);
         else k_stitch<false><<<dim3(n), dim3(WAVE), 0, h->stream>>>(v, qdev, h->dContigs.p, h->dRegions.p, h->dReplay.p, cap, h->rb, h->dRecs.p, h->dFast.p, h->dSegStart.p,
                                                                     h->dKeepN.p, h->dPrev.p, h->dDstOff.p, h->dMatchCount.p, h->dStats.p);
+        HIPCHK(hipEventRecord(h->evStitched, h->stream));             // nothing reads the table any more (the stitch's replays were the last)
         k_gather<<<dim3(rblocks), dim3(WAVE), 0, h->stream>>>(h->dContigs.p, h->dRbContig.p, h->dRegions.p, cap, h->dSegStart.p,
                                                             h->dKeepN.p, h->dDstOff.p, h->dMatches.p);
         h->mark(SWSEM_K_STITCH, false);
@@ -833,13 +996,14 @@ int pin_reserve(swsem *h, size_t bytes) {
 }
 
 // queues the copies of the match counts and statistics (no wait)
-int queue_counts(swsem *h, size_t extraBytes) {
+int queue_counts(swsem *h, size_t extraBytes, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     const size_t n = h->contigs.size();
     const size_t countsAt = 64, extraAt = (countsAt + n * sizeof(uint32_t) + 63) & ~(size_t) 63;
     int r = pin_reserve(h, extraAt + extraBytes);
     if (r) return r;
-    if ((r = download(h, h->pin, h->dStats.p, 8 * sizeof(unsigned long long), h->stream)) ||
-        (r = download(h, h->pin + countsAt, h->dMatchCount.p, n * sizeof(uint32_t), h->stream)))
+    if ((r = download(h, h->pin, h->dStats.p, 8 * sizeof(unsigned long long), st)) ||
+        (r = download(h, h->pin + countsAt, h->dMatchCount.p, n * sizeof(uint32_t), st)))
         return r;
     h->pinExtraAt = extraAt;
     return SWSEM_OK;                                   // (staged: the caller adds what it wants beside them and flushes)
@@ -893,8 +1057,8 @@ int end_slot(swsem *h, int si) {
     E.hostStreamsValid = false;
     if (h->emitHostCopy) {
         if (E.hostStreams.reserve(tot + 1)) return fail(SWSEM_ENOMEM, "cannot pin %llu B of host memory", (unsigned long long) tot);
-        if (tot) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, tot, hipMemcpyDeviceToHost, h->stream3));
-        HIPCHK(hipStreamSynchronize(h->stream3));
+        if (tot) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, tot, hipMemcpyDeviceToHost, h->s3()));
+        HIPCHK(hipStreamSynchronize(h->s3()));
         E.hostStreamsValid = true;
     }
     return SWSEM_OK;
@@ -957,12 +1121,19 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
         int least = 0, greatest = 0;                        // numerically: least >= greatest
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) { h->prioLow = least; h->prioHigh = greatest; }
     }
-    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&h->evP1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->slot[0].evDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->slot[1].evDone, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->evMatched, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
+        hipEventCreateWithFlags(&h->slot[0].evMetaDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->slot[1].evMetaDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evMatched, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evStitched, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evTables, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evRoundTop, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evLoadFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evLoadDone, hipEventDisableTiming) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipEventCreate failed"); }
+    { int d = deal_streams(h); if (d) { delete h; return d; } }
+    if (const char *e = getenv("SWSEM_COPY_WGS")) h->copyWgs = (uint64_t) std::max(1, atoi(e));
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
@@ -1004,6 +1175,8 @@ void swsem_destroy(swsem_t *h) {
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     if (h->stream2) (void) hipStreamSynchronize(h->stream2);
     if (h->stream3) (void) hipStreamSynchronize(h->stream3);
+    if (h->streamUp) (void) hipStreamSynchronize(h->streamUp);
+    if (h->streamAux) (void) hipStreamSynchronize(h->streamAux);
     h->drain_events();
     if (getenv("SWSEM_DEBUG_STATS")) {                               // diagnostics: the pairing chain's counters of this handle
         uint64_t t[8];
@@ -1021,11 +1194,12 @@ void swsem_destroy(swsem_t *h) {
     h->dPrev.release(); h->dRbContig.release(); h->dRbOrder.release(); h->dDecode.release(); h->dJobs.release(); h->dDecRecs.release(); h->dDecPlan.release(); h->dDecAux.release();
     for (auto &E : h->slot) E.release();
     h->dTables.release(); h->dGate.release(); h->dPred.release();
+    for (hipEvent_t e : {h->evStitched, h->evTables, h->evRoundTop}) if (e) (void) hipEventDestroy(e);
     if (h->pin) { (void) hipHostFree(h->pin); h->pin = nullptr; h->pinCap = 0; }
     if (h->ring) { (void) hipHostFree(h->ring); h->ring = nullptr; h->ringCap = 0; }
     for (auto &t : h->hostTables) { if (t.p) (void) hipHostFree(t.p); if (t.ev) (void) hipEventDestroy(t.ev); t = swsem::HostTab(); }
-    if (h->stream2) { (void) hipStreamSynchronize(h->stream2); (void) hipStreamDestroy(h->stream2); }
-    if (h->streamLoad) { (void) hipStreamSynchronize(h->streamLoad); (void) hipStreamDestroy(h->streamLoad); }
+    if (h->stream2) (void) hipStreamSynchronize(h->stream2);          // (the side streams are the pool's: never destroyed)
+    if (h->streamLoad) (void) hipStreamSynchronize(h->streamLoad);
     if (h->evLoadFork) (void) hipEventDestroy(h->evLoadFork);
     if (h->evLoadDone) (void) hipEventDestroy(h->evLoadDone);
     h->drain_events();
@@ -1045,7 +1219,7 @@ int swsem_set_stream(swsem_t *h, void *s) {
     if (h->ownStream) (void) hipStreamDestroy(h->stream);
     h->stream = (hipStream_t) s;
     h->ownStream = false;
-    return SWSEM_OK;
+    return deal_streams(h);                                           // (another main stream, maybe another pipe)
 }
 int swsem_synchronize(swsem_t *h) { HIPCHK(hipStreamSynchronize(h->stream)); return SWSEM_OK; }
 
@@ -1447,14 +1621,22 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
             return r;
     }
     if (!E.statZeroed) { HIPCHK(hipMemsetAsync(E.dEStat.p, 0, 8 * sizeof(unsigned long long), h->stream)); E.statZeroed = true; }
-    if ((r = upload(h, E.dEOwner.p, E.chunkOwner.data(), chunks * sizeof(uint32_t), h->stream))) return r;
-    if ((r = upload(h, E.dESpanOwner.p, E.spanOwner.data(), spans * sizeof(uint32_t), h->stream))) return r;
-    if ((r = upload(h, E.dECg.p, E.ecg.data(), n * sizeof(EmitContig), h->stream)) || (r = upload(h, E.dEWhich.p, which.data(), n * sizeof(int), h->stream))) return r;
+    // The emission's tables (and, below, the speculative finalize's) travel on a stream of their own that waits for nothing
+    // but the point where this batch began: they land while the chains are still running, and neither they nor their
+    // launch gaps sit between the stitch and the first pass. (An emission that is not the first of its batch — a retry pass
+    // over some of its contigs — has no such point: its uploads are ordered behind everything queued so far.)
+    hipStream_t up = h->streamUp;
+    if (!h->roundTopFresh) HIPCHK(hipEventRecord(h->evRoundTop, h->stream));
+    h->roundTopFresh = false;
+    HIPCHK(hipStreamWaitEvent(up, h->evRoundTop, 0));
+    if ((r = upload(h, E.dEOwner.p, E.chunkOwner.data(), chunks * sizeof(uint32_t), up))) return r;
+    if ((r = upload(h, E.dESpanOwner.p, E.spanOwner.data(), spans * sizeof(uint32_t), up))) return r;
+    if ((r = upload(h, E.dECg.p, E.ecg.data(), n * sizeof(EmitContig), up)) || (r = upload(h, E.dEWhich.p, which.data(), n * sizeof(int), up))) return r;
     E.eloaded.assign(refExtLoadedPos, refExtLoadedPos + nLoaded);
-    if ((r = upload(h, E.dELoaded.p, E.eloaded.data(), nLoaded * sizeof(uint64_t), h->stream))) return r;
+    if ((r = upload(h, E.dELoaded.p, E.eloaded.data(), nLoaded * sizeof(uint64_t), up))) return r;
     if (spec && spec->ntargets > 0) {                                // the prediction k_spec_verify checks pass 1 against
         if ((r = h->dGate.reserve(4)) || (r = h->dPred.reserve(2 * (size_t) n + 64))) return r;
-        if ((r = upload(h, h->dPred.p, spec->predExt, n, h->stream)) || (r = upload(h, h->dPred.p + n, spec->predRC, n, h->stream))) return r;
+        if ((r = upload(h, h->dPred.p, spec->predExt, n, up)) || (r = upload(h, h->dPred.p + n, spec->predRC, n, up))) return r;
     }
     if ((r = flush_copies(h))) return r;
     // no synchronisation here: the kernels below queue up behind match-finding while it is still running
@@ -1472,50 +1654,9 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
     v.chunkOwner = E.dEOwner.p; v.spanOwner = E.dESpanOwner.p;
     v.ncontigs = (uint32_t) n;
     const dim3 grid2(chunks);
-    h->mark(SWSEM_K_EMIT, true);
-    k_emit_p1_removed<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
-    k_emit_p1_scan<<<dim3(n), dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
-    k_emit_p1_compact<<<grid2, dim3(CH), 0, h->stream>>>(v, E.dECg.p, E.dEWhich.p);
-    k_emit_p1_finish<<<dim3(n), dim3(CH), 0, h->stream>>>(v, E.dECg.p);
-    h->mark(SWSEM_K_EMIT, false);
-    HIPCHK(hipGetLastError());
-    // pass-1 results (unmatchedChars, the dissimilarity verdict), match counts and statistics: one pinned block, one wait
-    const bool needCounts = h->matchCount.size() != h->contigs.size();
-    if ((r = queue_counts(h, n * sizeof(EmitOut)))) return r;
-    if ((r = download(h, h->pin + h->pinExtraAt, E.dEOut.p, n * sizeof(EmitOut), h->stream)) || (r = flush_copies(h))) return r;
-    HIPCHK(hipEventRecord(h->evP1, h->stream));
-    // the rest runs on the second stream behind pass 1
-    if (E.pinECap < n * sizeof(EmitOut)) {
-        if (E.pinE) HIPCHK(hipHostFree(E.pinE));
-        E.pinE = nullptr; E.pinECap = 0;
-        const size_t want = std::max<size_t>(2 * n * sizeof(EmitOut), 1 << 20);
-        if (hipHostMalloc((void **) &E.pinE, want, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
-        E.pinECap = want;
-    }
-    HIPCHK(hipStreamWaitEvent(h->stream2, h->evP1, 0));
-    h->mark(SWSEM_K_EMIT2, true, h->stream2);
-    k_emit_meta_regions<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
-    k_emit_meta_masks<<<dim3(spans), dim3(MLANES), 0, h->stream2>>>(v, E.dECg.p);
-    k_emit_meta_spec<<<dim3(spans), dim3(MLANES), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, h->metaWarm, E.dEStat.p);
-    // (the next batch's resolve is launched behind this kernel, run_batch: a launch of thousands of waves that is still
-    // running takes the slots the resolve's blocks are sized for, and the blocks that have to wait double its time)
-    if (!h->evMeta) HIPCHK(hipEventCreateWithFlags(&h->evMeta, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(h->evMeta, h->stream2));
-    h->metaPending = true;
-    k_emit_meta_check<<<grid2, dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
-    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->stream2>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
-    h->mark(SWSEM_K_EMIT2, false, h->stream2);
-    HIPCHK(hipGetLastError());
-    // The byte automata (sizes .. write) are queued later (run_phase2b): behind the speculative finalize, and — when the
-    // device can make a stream wait for a word in memory — not before the next batch's resolve kernel has started.
+    // the emission is on the books from here on (the plan of the speculative finalize below asks ref_write_guard about it)
     E.v2b = v; E.grid2b = chunks; E.n2b = n;
-    auto phase2b = [&](bool behindFinalize) -> int {
-        E.deferred2b = true; E.waitFin2b = behindFinalize;
-        return SWSEM_OK;
-    };
     E.donePending = true;
-    const bool specAsked = spec && spec->ntargets > 0 && h->phase2Behind;
-    if (!specAsked) { if ((r = phase2b(false))) return r; }
     h->latest = si; h->selected = -1;
     E.outstanding = true; E.refGuarded = false; E.emitN = n; E.emitPos1 = (uint64_t) h->pos1; E.qdev = h->qdev; E.params = *p;
     E.emitLaps = h->laps;
@@ -1526,18 +1667,25 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (all) E.lockMin = lm;
     }
     E.packedBytes = 0; E.hostStreamsValid = false;
+    E.deferred2b = false;
     // Speculative finalize: the round's loadRef / loadSeparator / lock releases are worked out on the host now, under
     // the caller's prediction of every contig's extension decision, and queued behind a device-side check of that
-    // prediction — so the copies and the table insertion start the moment pass 1 ends instead of after the host's
-    // round trip. The host comes to the same verdict from the values pass 1 hands back and keeps or undoes its
-    // bookkeeping accordingly; when the prediction fails nothing on the device has changed.
+    // prediction — so the copies start the moment pass 1 ends instead of after the host's round trip, and the table
+    // insertion, which can be taken back (InsertLog), the moment the stitch has ended. The host comes to the same verdict
+    // from the values pass 1 hands back and keeps or undoes its bookkeeping accordingly; when the prediction fails nothing
+    // on the device has changed.
     struct { int64_t pos1, sepEndPos; int laps, sepEndLaps, sepEndVal; uint64_t samplingPos, swEnd; uint32_t epoch, eCur, ePrev; bool pristine; std::deque<uint64_t> locks; uint64_t dropped; } snap;
-    bool queued = false, exchanged = false;
+    auto restore = [&]() {
+        h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev;
+        h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
+        h->pristine = snap.pristine; h->locks = snap.locks; h->droppedBytes = snap.dropped;
+    };
+    bool queued = false, exchanged = false, planned = false;
+    uint32_t *gate = nullptr;
     if (spec && spec->ntargets > 0) {
         snap.pos1 = h->pos1; snap.laps = h->laps; snap.samplingPos = h->samplingPos; snap.swEnd = h->swEnd; snap.epoch = h->epoch; snap.eCur = h->eCur; snap.ePrev = h->ePrev; snap.sepEndPos = h->sepEndPos; snap.sepEndLaps = h->sepEndLaps; snap.sepEndVal = h->sepEndVal;
         snap.pristine = h->pristine; snap.locks = h->locks; snap.dropped = h->droppedBytes;
-        uint32_t *gate = spec->gate_dev ? spec->gate_dev : h->dGate.p;
-        k_spec_verify<<<1, 256, 0, h->stream>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, gate);
+        gate = spec->gate_dev ? spec->gate_dev : h->dGate.p;
         // The host's half first (lock window, piece schedule, separators: load_pieces and its callees, nothing launched): it can
         // find that this finalize cannot be queued behind a gate at all (SWSEM_ESPEC: a write that would have to wait for an older
         // emission, a separator over an already hashed byte). With several replicas that has to be known BEFORE the verdicts are
@@ -1546,21 +1694,70 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         r = finalize_impl(h, spec->ntargets, spec->ext_dev, spec->ext_len, spec->addSep, spec->sep, spec->lazySeparator, spec->lockPos,
                           spec->loadedAfter, gate, true);
         h->specMode = false;
-        const bool planned = r == SWSEM_OK;
+        planned = r == SWSEM_OK;
         if (r == SWSEM_ESPEC) r = SWSEM_OK;                         // not possible this time: nothing will be queued
         else if (r) return r;
-        if (spec->veto || !planned) HIPCHK(hipMemsetAsync(gate, 0, sizeof(uint32_t), h->stream));
+        if (planned && (r = prepare_inserts(h, up))) return r;     // the finalize's tables, on the uploads' stream too
+    }
+    HIPCHK(hipEventRecord(h->evTables, up));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->evTables, 0));
+    hipStream_t sP = h->stream;
+    h->mark(SWSEM_K_EMIT, true, sP);
+    k_emit_p1_removed<<<grid2, dim3(CH), 0, sP>>>(v, E.dECg.p, E.dEWhich.p);
+    k_emit_p1_scan<<<dim3(n), dim3(CH), 0, sP>>>(v, E.dECg.p, E.dEWhich.p);
+    k_emit_p1_compact<<<grid2, dim3(CH), 0, sP>>>(v, E.dECg.p, E.dEWhich.p);
+    k_emit_p1_finish<<<dim3(n), dim3(CH), 0, sP>>>(v, E.dECg.p);
+    h->mark(SWSEM_K_EMIT, false, sP);
+    HIPCHK(hipGetLastError());
+    // pass-1 results (unmatchedChars, the dissimilarity verdict), match counts and statistics: one pinned block, one wait
+    const bool needCounts = h->matchCount.size() != h->contigs.size();
+    if ((r = queue_counts(h, n * sizeof(EmitOut), sP))) return r;
+    if ((r = download(h, h->pin + h->pinExtraAt, E.dEOut.p, n * sizeof(EmitOut), sP)) || (r = flush_copies(h))) return r;
+    HIPCHK(hipEventRecord(h->evP1, sP));
+    // the rest runs on the second stream behind pass 1
+    if (E.pinECap < n * sizeof(EmitOut)) {
+        if (E.pinE) HIPCHK(hipHostFree(E.pinE));
+        E.pinE = nullptr; E.pinECap = 0;
+        const size_t want = std::max<size_t>(2 * n * sizeof(EmitOut), 1 << 20);
+        if (hipHostMalloc((void **) &E.pinE, want, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return fail(SWSEM_ENOMEM, "cannot pin host memory");
+        E.pinECap = want;
+    }
+    HIPCHK(hipStreamWaitEvent(h->streamAux, h->evP1, 0));
+    h->mark(SWSEM_K_EMIT2, true, h->streamAux);
+    k_emit_meta_regions<<<grid2, dim3(CH), 0, h->streamAux>>>(v, E.dECg.p);
+    k_emit_meta_masks<<<dim3(spans), dim3(MLANES), 0, h->streamAux>>>(v, E.dECg.p);
+    k_emit_meta_spec<<<dim3(spans), dim3(MLANES), 0, h->streamAux>>>(v, E.dECg.p, E.dEStates.p, h->metaWarm, E.dEStat.p);
+    // (the next batch's resolve is launched behind this kernel, run_batch: a launch of thousands of waves that is still
+    // running takes the slots the resolve's blocks are sized for, and the blocks that have to wait double its time)
+    if (!h->evMeta) HIPCHK(hipEventCreateWithFlags(&h->evMeta, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->evMeta, h->streamAux));
+    h->metaPending = true;
+    k_emit_meta_check<<<grid2, dim3(WAVE), 0, h->streamAux>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
+    k_emit_meta_stitch<<<dim3(n), dim3(WAVE), 0, h->streamAux>>>(v, E.dECg.p, E.dEStates.p, E.dEStat.p);
+    h->mark(SWSEM_K_EMIT2, false, h->streamAux);
+    HIPCHK(hipEventRecord(E.evMetaDone, h->streamAux));
+    HIPCHK(hipGetLastError());
+    // The byte automata (sizes .. write) are queued later (run_phase2b): behind the speculative finalize, and — when the
+    // device can make a stream wait for a word in memory — not before the next batch's resolve kernel has started.
+    auto phase2b = [&](bool behindFinalize) -> int {
+        E.deferred2b = true; E.waitFin2b = behindFinalize;
+        return SWSEM_OK;
+    };
+    const bool specAsked = spec && spec->ntargets > 0 && h->phase2Behind;
+    if (!specAsked) { if ((r = phase2b(false))) return r; }
+    if (spec && spec->ntargets > 0) {
+        k_spec_verify<<<1, 256, 0, sP>>>(E.dEOut.p, E.dECg.p, n, h->dPred.p, h->dPred.p + n, spec->factor, spec->rcFactor, gate);
+        if (spec->veto || !planned) HIPCHK(hipMemsetAsync(gate, 0, sizeof(uint32_t), sP));
         // several replicas: the word becomes the minimum over all of them before anything gated by it is queued
         if (spec->exchange) {
             if (spec->exchange(spec->exchange_ctx, 0, gate, (void *) h->stream)) return fail(SWSEM_EHIP, "speculative finalize: the exchange between the replicas failed");
             exchanged = true;
         }
         if (planned) {
-            if ((r = flush_inserts(h, gate))) return r;
+            if ((r = launch_inserts(h, gate))) return r;
             queued = true;
         }
-        if (!queued) { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
-                       h->pristine = snap.pristine; h->locks = snap.locks; h->droppedBytes = snap.dropped; }
+        if (!queued) restore();
     }
     if (specAsked) { if ((r = phase2b(queued))) return r; }
     HIPCHK(hipEventSynchronize(h->evP1));                           // pass 1 and its copies to the host (not what was queued after them)
@@ -1575,8 +1772,7 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         }
         if (exchanged) ok = spec->exchange(spec->exchange_ctx, 1, nullptr, (void *) h->stream) == 1 && ok;   // ... and every other replica's
         if (ok) { if (applied) *applied = 1; }
-        else { h->pos1 = snap.pos1; h->laps = snap.laps; h->samplingPos = snap.samplingPos; h->swEnd = snap.swEnd; h->epoch = snap.epoch; h->eCur = snap.eCur; h->ePrev = snap.ePrev; h->sepEndPos = snap.sepEndPos; h->sepEndLaps = snap.sepEndLaps; h->sepEndVal = snap.sepEndVal;
-               h->pristine = snap.pristine; h->locks = snap.locks; h->droppedBytes = snap.dropped; }
+        else restore();
     } else if (exchanged)
         (void) spec->exchange(spec->exchange_ctx, 1, nullptr, (void *) h->stream);   // (this replica said no in the reduction: the word is 0 everywhere; taken so that the exchange's state is the same on every rank)
     return SWSEM_OK;
@@ -1636,8 +1832,8 @@ int swsem_emit_pack_dev(swsem_t *h, uint8_t *dst_dev, uint64_t cap, uint64_t *si
         if (E.packedBytes > cap) return fail(SWSEM_EINVAL, "swsem_emit_pack_dev: buffer too small");
         // on the emission's own stream, and waited for: the consumer may be on any stream, and the main stream
         // may already hold the next round's match-finding
-        HIPCHK(hipMemcpyAsync(dst_dev, E.dEArena.p, E.packedBytes, hipMemcpyDeviceToDevice, h->stream3));
-        HIPCHK(hipStreamSynchronize(h->stream3));
+        HIPCHK(hipMemcpyAsync(dst_dev, E.dEArena.p, E.packedBytes, hipMemcpyDeviceToDevice, h->s3()));
+        HIPCHK(hipStreamSynchronize(h->s3()));
     }
     if (total) *total = E.packedBytes;
     return SWSEM_OK;
@@ -1670,8 +1866,8 @@ int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
     if (k < 0 || k >= (int) E.eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
     if (!E.hostStreamsValid) {
         if (E.hostStreams.reserve(E.packedBytes + 1)) return fail(SWSEM_ENOMEM, "cannot pin %llu B of host memory", (unsigned long long) E.packedBytes);
-        if (E.packedBytes) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, E.packedBytes, hipMemcpyDeviceToHost, h->stream3));
-        HIPCHK(hipStreamSynchronize(h->stream3));
+        if (E.packedBytes) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, E.packedBytes, hipMemcpyDeviceToHost, h->s3()));
+        HIPCHK(hipStreamSynchronize(h->s3()));
         E.hostStreamsValid = true;
     }
     const EmitOut &o = E.eout[k];
@@ -1710,15 +1906,22 @@ static int decode_jobs(swsem_t *h, const swsem_emit_params_t *p, int n, const st
     std::vector<DecPlanOut> plans(n);
     HIPCHK(hipMemcpyAsync(plans.data(), h->dDecPlan.p, (size_t) n * sizeof(DecPlanOut), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    uint64_t maxRec = 0, maxLen = 0;
-    bool anyExpect = false;
-    for (int k = 0; k < n; k++) {
-        if (plans[k].unmatched < 0) continue;
-        maxRec = std::max(maxRec, plans[k].nrec); maxLen = std::max(maxLen, plans[k].destLen);
-        anyExpect |= jobs[k].expect != nullptr;
+    // grid.y holds at most 65 535 blocks: contigs go in slices of that many, each slice sized by its own longest contig
+    // (a batch of draft assemblies — tens of targets of a thousand contigs each — has more)
+    constexpr int YMAX = 65535;
+    for (int c0 = 0; c0 < n; c0 += YMAX) {
+        const int cn = std::min(YMAX, n - c0);
+        uint64_t maxRec = 0, maxLen = 0;
+        bool anyExpect = false;
+        for (int k = c0; k < c0 + cn; k++) {
+            if (plans[k].unmatched < 0) continue;
+            maxRec = std::max(maxRec, plans[k].nrec); maxLen = std::max(maxLen, plans[k].destLen);
+            anyExpect |= jobs[k].expect != nullptr;
+        }
+        if ((maxRec + 255) / 256 > 0x7FFFFFFFull || (maxLen + 4095) / 4096 > 0x7FFFFFFFull) return fail(SWSEM_EINVAL, "swsem decode: a contig too long for one launch");
+        if (maxRec) k_decode_fill<<<dim3((unsigned) ((maxRec + 255) / 256), (unsigned) cn), dim3(256), 0, h->stream>>>(h->ref, *p, h->dJobs.p, h->dDecRecs.p, dRecBase, h->dDecPlan.p, dBad, h->maxRefLength + REF_SLACK, (uint32_t) c0);
+        if (anyExpect && maxLen) k_decode_check<<<dim3((unsigned) ((maxLen + 4095) / 4096), (unsigned) cn), dim3(256), 0, h->stream>>>(h->dJobs.p, h->dDecPlan.p, dFirstDiff, (uint32_t) c0);
     }
-    if (maxRec) k_decode_fill<<<dim3((unsigned) ((maxRec + 255) / 256), (unsigned) n), dim3(256), 0, h->stream>>>(h->ref, *p, h->dJobs.p, h->dDecRecs.p, dRecBase, h->dDecPlan.p, dBad, h->maxRefLength + REF_SLACK);
-    if (anyExpect && maxLen) k_decode_check<<<dim3((unsigned) ((maxLen + 4095) / 4096), (unsigned) n), dim3(256), 0, h->stream>>>(h->dJobs.p, h->dDecPlan.p, dFirstDiff);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(aux.data(), h->dDecAux.p, aux.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -1,8 +1,10 @@
 """bench.py's host-side helpers (no GPU): what the container grants, and that the bench refuses to run without a device
 instead of measuring something else."""
+import json
 import os
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -22,4 +24,65 @@ def test_without_a_device_the_bench_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--cpu-sample", "0"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
-    assert not any(line.startswith("{") for line in r.stdout.splitlines())      # no JSON line: nothing was measured
+    lines = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert all(l["value"] is None and l["error"] for l in lines)                # nothing was measured, and the line (if any) says so
+
+
+# ---- `bench.py --gpus N` outside a launcher: the spawner must not hang on a rank that dies
+_CHILD = """
+import os, sys, time, signal
+r = int(os.environ["RANK"]); n = int(os.environ["WORLD_SIZE"])
+open(os.path.join(os.environ["MBGC_BENCH_RUNDIR"], "rank%d.up" % r), "w").close()
+mode = sys.argv[1]
+if mode == "ok":
+    time.sleep(0.3)
+    if r == 0: print('{"metric": "m", "value": 1.0, "n_gpus": %d}' % n, flush=True)
+elif mode == "kill3":
+    if r == 3:
+        time.sleep(1.0); os.kill(os.getpid(), signal.SIGKILL)
+    time.sleep(600)                       # the others sit "inside a collective"
+elif mode == "stuck":
+    time.sleep(600)
+elif mode == "exit7":
+    if r == 1: sys.exit(7)
+    time.sleep(600)
+"""
+
+
+def _spawn(mode, n, limit=None, grace=1.0):
+    code = ("import sys; sys.path.insert(0, %r); import bench; bench.spawn_ranks(%d, argv=[sys.executable, '-c', %r, %r], grace=%r, limit=%r)"
+            % (ROOT, n, _CHILD, mode, grace, limit))
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    return r, time.monotonic() - t0
+
+
+def test_spawner_relays_rank_0s_line():
+    r, dt = _spawn("ok", 4)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["value"] == 1.0 and lines[0]["n_gpus"] == 4
+
+
+def test_spawner_ends_the_run_when_a_rank_is_killed():
+    """8 ranks, rank 3 dies on SIGKILL a second in, the others would wait ten minutes: the spawner returns within seconds,
+    non-zero, with a line that says value null, which rank, and how many ranks had come up"""
+    r, dt = _spawn("kill3", 8)
+    assert r.returncode != 0 and dt < 30, (r.returncode, dt)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["value"] is None and "rank 3" in lines[0]["error"] and "signal 9" in lines[0]["error"]
+    assert lines[0]["rccl_ranks_seen"] == 8 and lines[0]["n_gpus"] == 8
+
+
+def test_spawner_ends_the_run_when_a_rank_exits_with_an_error():
+    r, dt = _spawn("exit7", 2)
+    assert r.returncode == 7 and dt < 30
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines[0]["value"] is None and "rank 1" in lines[0]["error"] and "exit code 7" in lines[0]["error"]
+
+
+def test_spawner_bounds_the_whole_run():
+    r, dt = _spawn("stuck", 2, limit=2.0)
+    assert r.returncode != 0 and dt < 30
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines[0]["value"] is None and "limit" in lines[0]["error"]

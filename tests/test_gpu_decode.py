@@ -183,3 +183,29 @@ def test_long_gaps_long_matches_and_long_literal_runs_decode_back(binding, mode,
     # the oracle's decoder on the same streams (the CPU restatement of MBGC_Decoder.cpp:319-523)
     back, un2 = _orc.decode_contig(h.ref(h.max_ref_length()), _orc.emit_params(mode, lazyDecompressionSupport=lazy), streams, _orc.NO_LOCK, t.size + 16)
     assert un2 == un and np.array_equal(back, t)
+
+
+def test_more_contigs_than_one_grid_dimension_holds(binding):
+    """70 000 contigs in one batch (draft assemblies: tens of targets of a thousand contigs each): the decoder's fill and
+    check passes index contigs through grid.y, which holds 65 535 — they go in slices; every contig is given back, and a
+    byte changed in one beyond the first slice is reported with its contig and position"""
+    import torch
+    n, step = 70_000, 64
+    base = synth.genome(synth.base_codes(200_000, 5), 0, 0.0)
+    h = binding.SlidingWindowSparseEMMatcher(8_000_000)
+    h.load_ref(base, load_rc=False)
+    rng = np.random.default_rng(11)
+    starts = rng.integers(0, base.size - step, n)
+    q = np.concatenate([base[s: s + step] for s in starts])
+    q[rng.integers(0, q.size, q.size // 100)] = ord("A")           # some mismatches, so that extensions and literals occur
+    buf = torch.from_numpy(q).to("cuda:0")
+    torch.cuda.synchronize()
+    offs = np.arange(n + 1, dtype=np.uint64) * step
+    h.match_batch_dev(buf.data_ptr(), offs, 32, None)
+    h.emit_set_host_copy(False)
+    h.emit_batch(binding.emit_params(1), None, None, None, None, None, [h.loaded_ref_length()], n=n)
+    assert h.emit_verify() == (0, -1, 2 ** 64 - 1)
+    buf[69_000 * step + 5] = ord("N") if q[69_000 * step + 5] != ord("N") else ord("C")
+    torch.cuda.synchronize()
+    assert h.emit_verify() == (1, 69_000, 5)
+    h.close()
