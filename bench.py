@@ -8,21 +8,29 @@ reverse complement preloaded; 2.56e9 bytes and a 2^28-entry table for 1001 files
 own rules let targets be in flight — what they load must fit the sliding window (1/16 of the buffer = 160 MB = 31
 targets; SlidingWindowSparseEMMatcher.cpp:361-378,412-417,433: what goes beyond the window is dropped) and at most 64
 (MGMP.cpp:374-375,532) — and NO extension byte is dropped (`extension_bytes_dropped_per_step` must be 0, or the line says
-INVALID). Every GPU matches its share of the round (31 // N targets, file-per-GPU) against its frozen replica —
-matchTexts + processMatches, six streams — then every replica loads the round's extensions in target order (loadRef,
-hash insertion included). The run goes THROUGH the wrap of the circular buffer (near target 510); step times before and
-after it are reported separately. With N > 1 the total work per step is fixed (strong scaling: the in-flight bound is
-the collection's, not a GPU's), the extension bytes are exchanged over RCCL and the streams gathered to rank 0. Inputs are
-resident in HBM before the timed region. One JSON line is printed by rank 0.
+INVALID). One GPU: rounds of 31. Several GPUs: the total work of a step is the same at every N (strong scaling) — 24
+targets, the largest multiple of 8 the window allows, dealt 12 / 6 / 3 per GPU (file-per-GPU) at N = 2 / 4 / 8; the one-GPU
+run times that step too, beside its headline (`scaling_reference`), so the curve has its N = 1 point at the same step. Every
+GPU matches its share of the round against its frozen replica — matchTexts + processMatches, six streams — then every
+replica loads the round's extensions in target order (loadRef, hash insertion included). The run goes THROUGH the wrap of
+the circular buffer (near target 510); step times before and after it are reported separately. With N > 1 the extension
+bytes are exchanged over RCCL and the streams gathered to rank 0. Inputs are resident in HBM before the timed region. One
+JSON line is printed by rank 0.
 
-`python bench.py --gpus N` starts its own N ranks (children, before anything in this process touches a GPU);
-under `python -m torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
+`python bench.py --gpus N` starts its own N ranks (children, before anything in this process touches a GPU) and watches
+them: a rank that dies ends the run within seconds with a line that says `"value": null` and why (spawn_ranks); under
+`python -m torch.distributed.run` (WORLD_SIZE set) it is one of the ranks, with a 120 s process-group timeout.
+
+Beside the headline, N = 1 only and never inside its timed region (`--no-extras` skips them): `cpp_host` — the product's C++
+host (`mbgc-hip c --bench`) on the same collection from FASTA files; `configs` — BASELINE configs[1] (128 genomes, matcher
+only) and the configs[4] data class and sizing (mixed-species genomes, `-m 3`, 4.5e9-byte reference with 40-bit offsets)
+through the C++ host, each with its match-finding kernel's roofline; `cpu_baseline` — the reference's own OpenMP path.
 
 Diagnostics (never the headline): --no-emit (matcher only), --from-host (queries cross PCIe inside the timed region),
 --check (first round against the oracle); environment: MBGC_BENCH_MAX_REF (another buffer size), MBGC_BENCH_BLOCK_STATS
 / MBGC_BENCH_BLOCK_DUMP (per-block clocks of the last resolve launch), MBGC_BENCH_ONE_DEVICE + MBGC_BENCH_BACKEND=gloo
-(several ranks on one GPU, a rehearsal of the N > 1 protocol), and the library's own switches (SWSEM_CHAINS,
-SWSEM_RB, SWSEM_RESOLVE, SWSEM_PROF_FAMS; see mbgc_amd/csrc/swsem_runtime.hip: swsem_create)."""
+(several ranks on one GPU, a rehearsal of the N > 1 protocol), MBGC_BENCH_TIMEOUT / MBGC_BENCH_PG_TIMEOUT (seconds), and the
+library's own switches (SWSEM_CHAINS, SWSEM_RB, SWSEM_RESOLVE, SWSEM_PROF_FAMS; see mbgc_amd/csrc/swsem_runtime.hip: swsem_create)."""
 import argparse
 import json
 import os
@@ -78,6 +86,145 @@ KERNEL_OF = {"resolve": "k_resolve_blocks4", "stitch": "k_stitch_pre + k_stitch 
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
+MIXED_GENOMES = 200                  # configs[4]'s kind of data, as many genomes as a bench line can afford (the full 10 000: profiles/configs4_run.py)
+TOOL = os.path.join(ROOT, "mbgc_amd", "mbgc-hip")
+
+
+def resolve_alg_bytes(bases, matched, matches):
+    """SURVEY.md §8(d) for the match-finding kernel on ANY data: the query scan (1 B per base), the table probes the sequential
+    loop performs (4 B each: it visits what no match lets it jump over — the unmatched positions, and per match about 8 in front
+    of the hit and the 16 of the skip margin behind it: 0.31 per base on the 99 %-identity collection, where the oracle counts
+    0.29), the reference bytes it compares (the matched length) and the 24-byte rows it writes."""
+    probes = bases - matched + 24 * matches
+    return bases + 4 * probes + matched + 24 * matches
+
+
+def _mixed_one(args):
+    d, i = args
+    from mbgc_amd import synth
+    coll = synth.MixedSpecies()
+    with open(os.path.join(d, "m%05d.fa" % i), "wb") as f:
+        f.write(coll.fasta(i))
+    return sum(int(c.size) for c in coll.contigs(i))
+
+
+def write_mixed_species(n):
+    """n genomes of synth.MixedSpecies (8 unrelated species x 4 strains, 0.2-10 % divergence, 1-4 contigs, reverse-complemented
+    contigs, N runs) as FASTA files, by forked workers — before this process touches the GPU"""
+    import multiprocessing as mp
+    import tempfile
+    d = tempfile.mkdtemp(prefix="mbgc_bench_mix_", dir=os.environ.get("TMPDIR", "/tmp"))
+    with mp.get_context("fork").Pool(min(16, os.cpu_count() or 1)) as p:
+        sizes = p.map(_mixed_one, [(d, i) for i in range(n)], chunksize=2)
+    with open(os.path.join(d, "list.txt"), "w") as f:
+        f.write("".join(os.path.join(d, "m%05d.fa" % i) + "\n" for i in range(n)))
+    with open(os.path.join(d, "meta.json"), "w") as f:
+        json.dump({"genomes": n, "bases": sum(sizes), "g0_bases": sizes[0]}, f)
+    return d
+
+
+def _tool_profile(stderr):
+    import re
+    m = re.search(r"kernel profile: (\{.*\})", stderr)
+    return json.loads(m.group(1)) if m else None
+
+
+def cpp_host_line(fasta_dir, n_targets, warm, py_value):
+    """the product's host — C++ classes over the C ABI, `mbgc-hip c --bench` — on the headline's collection (the same genomes as
+    FASTA files: read, uploaded and parsed on the device before the clock starts; rounds sized by the window; timed behind
+    `warm` warm-up rounds like the line above it)"""
+    try:
+        lst = os.path.join(fasta_dir, "list.txt")
+        with open(lst, "w") as f:
+            f.write("".join(synth_path(fasta_dir, i) + "\n" for i in range(n_targets + 1)))
+        t0 = time.perf_counter()
+        r = subprocess.run([TOOL, "c", "--bench", "--warmup", str(warm), lst, os.path.join(fasta_dir, "out")], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, MBGC_HIP_PROFILE="1"))
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "mbgc-hip exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        out = {"command": "mbgc-hip c --bench --warmup %d <list of the same %d files>" % (warm, n_targets + 1), "value": d["value"], "unit": "Gbases/s",
+               "ms_per_round": d["ms_per_round"], "rounds": d["rounds"], "targets_per_round": d["targets_per_round"],
+               "extension_bytes_dropped": d.get("extension_bytes_dropped"), "max_ref_len": d.get("max_ref_len"),
+               "over_the_python_line": round(d["value"] / py_value, 4) if py_value else None, "wall_seconds_of_the_tool": round(wall, 2)}
+        prof = _tool_profile(r.stderr)
+        if prof and prof["resolve"]["launches"]:
+            ms = prof["resolve"]["ms"] / prof["resolve"]["launches"]
+            ach = ALG_BYTES["resolve"] * d["targets_per_round"] * GENOME_LEN / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": KERNEL_OF["resolve"], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(ms, 4), "alg_bytes_per_base": round(ALG_BYTES["resolve"], 3)}
+            out["kernel_ms_per_launch"] = {k: round(v["ms"] / v["launches"], 4) for k, v in prof.items() if v["launches"]}
+        return out
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def synth_path(fasta_dir, i):
+    from mbgc_amd import synth
+    return synth.fasta_path(fasta_dir, i)
+
+
+def config1_line():
+    """BASELINE configs[1]: 128 synthetic 5 Mbp genomes, SlidingWindowSparseEMMatcher only (matchTexts + loadRef, no emission),
+    against the 1.28e9-byte buffer `mbgc c` gives 129 files — this script again, as a child, in rounds of 16"""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-emit", "--round", "16", "--steps", "7", "--warmup", "1", "--cpu-sample", "0",
+                            "--no-extras"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, MBGC_BENCH_MAX_REF=str(ref_length_limit(129, GENOME_LEN))))
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"config": "configs[1]", "error": "child bench exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+        d = json.loads(lines[-1])
+        return {"config": "configs[1]", "workload": "configs[1]: 128 synthetic 5 Mbp genomes @99% identity, SlidingWindowSparseEMMatcher only (matchTexts + loadRef per round, no "
+                                                    "emission), %.4g-byte circular reference (the buffer `mbgc c` gives 129 files), rounds of 16; timed: targets 17..128" % d["config"]["max_ref_len"],
+                "metric": d["metric"], "value": d["value"], "unit": d["unit"], "extension_bytes_dropped_per_step": d.get("extension_bytes_dropped_per_step"),
+                "ms_per_step": d["ms_per_step"], "targets_per_step": d["config"]["targets_per_step"], "max_ref_len": d["config"]["max_ref_len"],
+                "roofline": d["roofline"], "kernel_ms_per_launch": d["kernel_ms_per_launch"]}
+    except Exception as e:
+        return {"config": "configs[1]", "error": "%s: %s" % (type(e).__name__, e)}
+
+
+def config4_line(mixed_dir):
+    """BASELINE configs[4]'s data class and sizing on what a bench line can afford: MIXED_GENOMES mixed-species genomes through the C++
+    host in the `-m 3` presets (sequential schedule, skip margin 24, reverse-complement pass) against the 4.5e9-byte buffer with
+    40-bit offsets and 2^29 buckets that `mbgc c -m3` gives 10 001 files (--ref-factor 512) — files from the page cache, the tool's
+    own clock over its matching phase (reading, upload, device parse, matchTexts, processMatches, loadRef)"""
+    import re
+    if not mixed_dir:
+        return {"config": "configs[4]", "error": "no mixed-species files"}
+    try:
+        meta = json.load(open(os.path.join(mixed_dir, "meta.json")))
+        r = subprocess.run([TOOL, "c", "-m", "3", "--ref-factor", "512", os.path.join(mixed_dir, "list.txt"), os.path.join(mixed_dir, "out")],
+                           capture_output=True, text=True, timeout=300, env=dict(os.environ, MBGC_HIP_PROFILE="1"))
+        if r.returncode != 0:
+            return {"config": "configs[4]", "error": "mbgc-hip exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+        ms = int(re.search(r"matching finished - (\d+) \[ms\]", r.stderr).group(1))
+        matches = int(re.search(r"exact matches total: (\d+)", r.stdout).group(1))
+        unmatched = int(re.search(r"swsMEM unmatched chars: (\d+)", r.stdout).group(1))
+        ref_len = int(re.search(r"final reference length: (\d+)", r.stdout).group(1))
+        bases = meta["bases"] - meta["g0_bases"]                      # the targets (the first file is the reference)
+        out = {"config": "configs[4]", "workload": "%d mixed-species synthetic genomes (8 species x 4 strains, 0.2-10 %% divergence, 1-4 contigs), `mbgc-hip c -m 3 "
+                                                   "--ref-factor 512`: sequential schedule, 4.5e9-byte reference with 40-bit offsets, 2^29 buckets; C++ host, files "
+                                                   "from the page cache" % meta["genomes"],
+               "metric": "input Gbases/s (compress path of the C++ host, -m3: file reading + device parse + match-finding + stream emission)",
+               "value": round(bases / (ms * 1e-3) / 1e9, 4), "unit": "Gbases/s", "matching_ms": ms, "target_bases": bases, "exact_matches": matches,
+               "unmatched_chars_before_extensions": unmatched, "final_reference_length": ref_len}
+        prof = _tool_profile(r.stderr)
+        if prof and prof["resolve"]["ms"] > 0:
+            alg = resolve_alg_bytes(bases, bases - unmatched, matches)
+            ach = alg / (prof["resolve"]["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": KERNEL_OF["resolve"], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "launches": prof["resolve"]["launches"],
+                               "avg_launch_ms": round(prof["resolve"]["ms"] / prof["resolve"]["launches"], 4),
+                               "alg_bytes_per_base": round(alg / bases, 3),
+                               "share_of_the_matching_phase": round(prof["resolve"]["ms"] / ms, 3)}
+            out["kernel_ms_total"] = {k: round(v["ms"], 2) for k, v in prof.items() if v["launches"]}
+        return out
+    except Exception as e:
+        return {"config": "configs[4]", "error": "%s: %s" % (type(e).__name__, e)}
+
+
 def kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
@@ -86,9 +233,11 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel_prefix, targets_per_launch):
+def measured_traffic(kernel_prefix, targets_per_launch, n_gpus=1):
     """(bytes per launch, where the figure comes from): the PMC passes are a rocprofv3 run of their own over this command, so
-    the line says which commit's kernels they saw and whether the kernel sources have changed since (then: re-take them)"""
+    the line says which commit's kernels they saw and whether the kernel sources have changed since (then: re-take them).
+    The counters were taken on ONE GPU with `targets_per_launch` targets in a launch: another launch size, or a rank of a
+    sharded run, has no measured figure (null, and the source says why)."""
     try:
         with open(TRAFFIC_FILE) as f:
             t = json.load(f)
@@ -97,7 +246,11 @@ def measured_traffic(kernel_prefix, targets_per_launch):
                "kernel_sources_changed_since": t.get("kernel_source_sha16") != kernel_source_sha()}
         if src["kernel_sources_changed_since"]:
             print("bench.py: %s was taken from other kernel sources than the ones built now: roofline.traffic is stale" % src["file"], file=sys.stderr)
+        if n_gpus != t.get("n_gpus", 1):
+            src["not_used"] = "counters were taken on %d GPU(s), this run has %d" % (t.get("n_gpus", 1), n_gpus)
+            return None, src
         if t.get("targets_per_launch") != targets_per_launch:
+            src["not_used"] = "counters were taken with %s targets per launch, this run has %d" % (t.get("targets_per_launch"), targets_per_launch)
             return None, src
         return int(k["bytes_per_launch"]), src
     except Exception:
@@ -363,6 +516,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128, help="targets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--check", action="store_true", help="compare the first step's matches with the oracle")
     ap.add_argument("--no-emit", action="store_true", help="matcher only (no stream emission) inside the step")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1 only: skip what is measured beside the headline (the constant-step line for the scaling curve, the C++ host "
+                         "on the same collection, the other configs' lines)")
     ap.add_argument("--from-host", action="store_true",
                     help="diagnostic, not the headline: every timed round's queries start in pinned host memory and cross PCIe "
                          "inside the timed region (double-buffered on a copy stream); reported under its own metric name")
@@ -384,26 +540,53 @@ def main():
     coll = COLLECTION
     max_ref = int(float(os.environ["MBGC_BENCH_MAX_REF"])) if "MBGC_BENCH_MAX_REF" in os.environ else ref_length_limit(1 + coll, args.length)
     cap = targets_in_flight(max_ref, args.length)
-    R = args.round if args.round > 0 else max(1, min(cap, COLLECTION // (steps + warm)) // world)
+    # targets per step. One GPU: what the window lets be in flight (31). Several: the SAME step at every N, so that the curve
+    # can be read — the largest multiple of 8 the window allows (24), dealt 12 / 6 / 3 per GPU at N = 2 / 4 / 8; the one-GPU run
+    # times that step too, beside its headline ("scaling_reference").
+    SCALE_STEP = max(8, cap // 8 * 8)
+    if args.round > 0:
+        R = args.round
+    elif world == 1:
+        R = max(1, min(cap, COLLECTION // (steps + warm)))
+    else:
+        R = max(1, min(SCALE_STEP, COLLECTION // (steps + warm)) // world)
     n_targets = (steps + warm) * R * world
+    extras = (world == 1 and rank == 0 and not args.no_extras and not args.from_host and not args.no_emit and args.round <= 0 and
+              args.length == GENOME_LEN and "MBGC_BENCH_MAX_REF" not in os.environ and not os.environ.get("MBGC_BENCH_SERIAL"))
+    REF_WARM, REF_STEPS = 2, 6
+    ref_R = min(SCALE_STEP, R)
+    n_ref = (REF_WARM + REF_STEPS) * ref_R if extras and n_targets + (REF_WARM + REF_STEPS) * ref_R <= COLLECTION else 0
     # synthetic collection (SURVEY.md §8d recipe), generated by forked workers BEFORE this process touches the GPU:
     # this rank's targets of every round, one host array per round
     base = synth.base_codes(args.length)
     sched = round_schedule(n_targets, R, world)
-    mine_all = [1 + t for rnd in sched for t in rnd[rank]]
+    sched_ref = [[[n_targets + r0 + t for t in range(ref_R)]] for r0 in range(0, n_ref, ref_R)]
+    mine_all = [1 + t for rnd in sched + sched_ref for t in rnd[rank]]
     if os.environ.get("MBGC_BENCH_SAME"):               # experiment: every target of a round is the same genome (perfect inter-target locality)
         mine_all = [1 + rnd[rank][0] for rnd in sched for t in rnd[rank]]
+    fasta_dir = mixed_dir = None
+    if extras:
+        import tempfile
+        fasta_dir = tempfile.mkdtemp(prefix="mbgc_bench_fa_", dir=os.environ.get("TMPDIR", "/tmp"))   # the same genomes as files, for the C++ host
     t_gen = time.perf_counter()
     gens = synth.genomes(base, mine_all, workers=max(1, min(16, (os.cpu_count() or 1) // world)),
-                         fork=os.environ.get("MBGC_BENCH_GEN", "fork") != "thread")   # (threads under a profiler that has already opened the GPU)
+                         fork=os.environ.get("MBGC_BENCH_GEN", "fork") != "thread",   # (threads under a profiler that has already opened the GPU)
+                         fasta_dir=fasta_dir)
     host_rounds, k = [], 0
-    for rnd in sched:
+    for rnd in sched + sched_ref:
         cnt = len(rnd[rank])
         host_rounds.append(np.concatenate(gens[k: k + cnt]))
         for j in range(k, k + cnt):
             gens[j] = None
         k += cnt
     del gens
+    if extras:
+        with open(synth.fasta_path(fasta_dir, 0), "wb") as f:
+            f.write(synth.fasta_bytes(synth.genome(base, 0), 0))
+        try:
+            mixed_dir = write_mixed_species(MIXED_GENOMES)
+        except Exception as e:
+            print("bench.py: no mixed-species files (%s)" % e, file=sys.stderr)
     t_gen = time.perf_counter() - t_gen
 
     import torch
@@ -450,7 +633,7 @@ def main():
 
     # resident in HBM before the clock starts
     bufs = []
-    for ri, rnd in enumerate(sched):
+    for ri, rnd in enumerate(sched + sched_ref):
         offs = np.arange(len(rnd[rank]) + 1, dtype=np.uint64) * args.length
         bufs.append((torch.from_numpy(host_rounds[ri]).to(dev), offs))
         host_rounds[ri] = None
@@ -523,6 +706,26 @@ def main():
     m.profile_enable(False)
     dropped = m.dropped_bytes() - dropped0
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    # the step of the scaling curve (SCALE_STEP targets whatever N is) on this one GPU: the collection's next rounds, timed the same way
+    scaling_ref = None
+    if sched_ref:
+        first = len(sched)
+        d0 = m.dropped_bytes()
+        for s_ in range(first, first + REF_WARM):
+            runner.run_round(*bufs[s_], next_batch=bufs[s_ + 1])
+        runner.flush()
+        barrier()
+        t1 = time.perf_counter()
+        for s_ in range(first + REF_WARM, first + REF_WARM + REF_STEPS):
+            runner.run_round(*bufs[s_], next_batch=bufs[s_ + 1] if s_ + 1 < len(bufs) else None)
+        runner.flush()
+        barrier()
+        dt1 = time.perf_counter() - t1
+        scaling_ref = {"targets_per_step": ref_R, "steps": REF_STEPS, "warmup": REF_WARM, "ms_per_step": round(dt1 / REF_STEPS * 1e3, 3),
+                       "value": round(ref_R * args.length * REF_STEPS / dt1 / 1e9, 4), "unit": "Gbases/s",
+                       "extension_bytes_dropped": m.dropped_bytes() - d0,
+                       "what": "the step bench.py --gpus N times at every N > 1 (%d targets: the largest multiple of 8 the window allows), on one GPU; "
+                               "targets %d..%d of the same collection" % (ref_R, n_targets + 1, n_targets + n_ref)}
     if os.environ.get("MBGC_BENCH_BLOCK_STATS"):          # diagnostics of the last round's resolve blocks, to stderr
         import ctypes as C
         from mbgc_amd import binding as _b
@@ -560,7 +763,7 @@ def main():
         launch_bases = R * args.length                     # bases one launch of a family processes (this rank's round)
         alg = dict(ALG_BYTES)
         ach = alg[dom] * launch_bases / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
-        traffic, traffic_source = measured_traffic(KERNEL_OF[dom].split()[0], R * world)
+        traffic, traffic_source = measured_traffic(KERNEL_OF[dom].split()[0], R, world)
         pre = [t for t, w in zip(step_ms, laps_at) if not w]
         post = [t for t, w in zip(step_ms, laps_at) if w]
         first_coll = 1 + warm * R * world
@@ -601,7 +804,9 @@ def main():
             "matches_per_step": tot_matches // steps, "replayed_resolve_blocks_per_step": replayed / steps,
             "stream_bytes_per_step": runner.stream_bytes // max(1, steps + warm),
             "round_finalizes_queued_behind_pass1": {"tried": runner.spec_local[0], "applied": runner.spec_local[1], "not_applied_at_try": runner.spec_local[2][:16]},
+            "step_ms_min_median_max": [round(float(np.min(step_ms)), 3), round(float(np.median(step_ms)), 3), round(float(np.max(step_ms)), 3)],
             **({"step_ms": [round(t, 3) for t in step_ms]} if os.environ.get("MBGC_BENCH_STEP_MS") else {}),
+            **({"scaling_reference": scaling_ref} if scaling_ref else {}),
             **({"INVALID": "MBGC_BENCH_SERIAL: the device was drained after every step (diagnostics)"} if os.environ.get("MBGC_BENCH_SERIAL") else {}),
         }
         if os.environ.get("MBGC_BENCH_BLOCK_TIMES"):                  # diagnostics: how even the last launch's resolve blocks were
@@ -630,6 +835,20 @@ def main():
                                                                    "bytes_of_those_rounds": runner.head_gathers[2]}
         if runner.trace is not None:
             out["host_ms_per_round"] = {k: round(v * 1e3 / (steps + warm), 3) for k, v in runner.trace.items()}
+        if extras:
+            # beside the headline, never inside its timed region: the product's C++ host on the same collection, the other configs
+            runner = None
+            m.close()
+            del bufs
+            torch.cuda.empty_cache()
+            try:
+                out["cpp_host"] = cpp_host_line(fasta_dir, n_targets, warm, value)
+                out["configs"] = [config1_line(), config4_line(mixed_dir)]
+            finally:
+                import shutil
+                for d_ in (fasta_dir, mixed_dir):
+                    if d_:
+                        shutil.rmtree(d_, ignore_errors=True)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.length, emit, max_ref)
         if dropped and not os.environ.get("MBGC_BENCH_ALLOW_DROPS"):

@@ -193,10 +193,11 @@ int main(int argc, char **argv) {
         // the C++ host's own measurement of the hot path (BASELINE.json metric): inputs resident in HBM, rounds of -R targets
         printf("{\"metric\": \"input Gbases/s (compress hot path, C++ host)\", \"value\": %.4f, \"unit\": \"Gbases/s\", \"rounds\": %d, "
                "\"warmup_rounds\": %d, \"targets_per_round\": %d, \"bases\": %llu, \"seconds\": %.6f, \"ms_per_round\": %.4f, "
-               "\"n_gpus\": %d, \"exchange\": \"%s\", \"rounds_finalized_on_device_verdicts\": %d}\n",
+               "\"n_gpus\": %d, \"exchange\": \"%s\", \"rounds_finalized_on_device_verdicts\": %d, \"extension_bytes_dropped\": %zu, "
+               "\"max_ref_len\": %zu}\n",
                params.benchBases / params.benchSeconds / 1e9, params.benchRounds, params.benchWarmup, params.roundSize * gpus,
                (unsigned long long) params.benchBases, params.benchSeconds, params.benchSeconds * 1e3 / std::max(1, params.benchRounds),
-               gpus, params.exchange ? transport.c_str() : "none", params.specRounds);
+               gpus, params.exchange ? transport.c_str() : "none", params.specRounds, enc.droppedExtensionBytes(), enc.maxReferenceLength());
         return finish(0);
     }
     dump(pos[1], "literals", enc.literals);

@@ -736,6 +736,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
         } else if ((int) r == params->benchWarmup) {
             if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); prev.valid = false; }
             matcher->synchronize();
+            if (getenv("MBGC_HIP_PROFILE")) swsem_profile_enable(matcher->handle(), 1);   // (the kernel profile covers what the clock covers)
             tStart = now();
         }
         const size_t ncont = B.targetOf.size();
@@ -856,6 +857,10 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
 
 void MultipleGenomeMatchingProcessor::performMatching() {
     const double t0 = nowSeconds();
+    // MBGC_HIP_PROFILE=1: the library's per-family kernel times (HIP events on the streams the kernels run on) over the matching
+    // phase, one JSON line on stderr — what bench.py prices its C++-host lines' rooflines with
+    const bool profile = getenv("MBGC_HIP_PROFILE") != nullptr;
+    if (profile) swsem_profile_enable(matcher->handle(), 1);
     if (params->sequentialMatching) processTargetsWithParallelIO();
     else if (targetsCount && params->exchange) processTargetsRoundsSharded();
     else if (targetsCount) processTargetsRounds();
@@ -869,6 +874,15 @@ void MultipleGenomeMatchingProcessor::performMatching() {
     // and parsing the target files, match-finding, processMatches, loadRef)
     if (!params->benchMode && (!params->exchange || mbgc_xchg_rank(params->exchange) == 0))
         fprintf(stderr, "matching finished - %.0f [ms]\n", (nowSeconds() - t0) * 1e3);
+    if (profile) {
+        static const char *fam[SWSEM_K_COUNT] = {"load", "insert", "probe", "emit2", "resolve", "stitch", "emit"};
+        double ms[SWSEM_K_COUNT]; uint64_t nl[SWSEM_K_COUNT];
+        swsem_profile_get(matcher->handle(), ms, nl);
+        swsem_profile_enable(matcher->handle(), 0);
+        fprintf(stderr, "kernel profile: {");
+        for (int k = 0; k < SWSEM_K_COUNT; k++) fprintf(stderr, "%s\"%s\": {\"ms\": %.3f, \"launches\": %llu}", k ? ", " : "", fam[k], ms[k], (unsigned long long) nl[k]);
+        fprintf(stderr, "}\n");
+    }
     if (getenv("MBGC_HIP_TIMES"))
         fprintf(stderr, "  reader threads: reading files %.0f ms; input thread: waiting for them %.0f ms, upload + parse %.0f ms; main thread: waiting for it %.0f ms, taking the streams over %.0f ms"
                         " (%.0f of them waiting for the bytes; appends on their thread %.0f ms, waited for %.0f ms); rounds prepared by the main thread itself %.0f ms; match-finding calls %.0f ms, processMatches calls %.0f ms, loadRef calls %.0f ms; rounds cut at a dissimilar contig: %llu passes over %llu contigs\n",

@@ -217,5 +217,6 @@ public:
     size_t exactMatches() const { return resCount; }
     size_t finalReferenceLength() const { return refFinalTotalLength; }          // writeStats' refFinalTotalLength, ENC.cpp:734-743
     size_t droppedExtensionBytes() const { return matcher ? matcher->getDroppedBytes() : 0; }
+    size_t maxReferenceLength() const { return matcher ? matcher->getMaxRefLength() : 0; }
     size_t unmatchedChars() const { return unmatchedCharsAll; }
 };

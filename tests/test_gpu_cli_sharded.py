@@ -136,3 +136,94 @@ def test_a_wrapping_buffer_and_the_head_of_the_round(tmp_path):
     for k in STREAMS:
         assert a[k] == c[k], k
     assert "rounds whose extension exchange carried only the loadable head: 0" in whole
+
+
+# ---- as many ranks as a one-GPU box lets share its card (five beside this process): the shape of BASELINE configs[3] — file per
+# rank, replicated index, extensions exchanged in target order, streams to rank 0 — rehearsed over host shared memory. Eight ranks
+# run over gloo on the CPU (tests/test_rounds_cpu.py::test_eight_ranks_gloo).
+@pytest.mark.parametrize("gpus,r,n,div,contigs,factor", [(5, 1, 21, 0.003, 1, None), (5, 2, 26, 0.015, "ragged", None), (5, 1, 31, 0.003, 1, "1"),
+                                                         (4, 1, 17, 0.06, 2, None)])
+def test_five_ranks_on_one_gpu_equal_the_single_gpu_rounds(tmp_path, gpus, r, n, div, contigs, factor):
+    """five (four) ranks: similar genomes (finalize on the ranks' verdicts), reverse-complement extensions with ragged contig
+    layouts, a buffer that wraps several times (--ref-factor 1: the head-only exchange), dissimilar contigs that cut rounds
+    between ranks — every stream equal to the single GPU's rounds of gpus x r"""
+    write_collection(tmp_path, n, 300_000 if factor else 70_000, div, contigs)
+    extra = ["--ref-factor", factor] if factor else []
+    one = run_tool(["c"] + extra + ["-R", str(gpus * r), "list.txt", "one"], str(tmp_path))
+    many = run_tool(["c"] + extra + ["--gpus", str(gpus), "--exchange", "hostmem", "--shm-mb", "2", "-R", str(r), "list.txt", "many"], str(tmp_path))
+    a, b = dumps(tmp_path, "one"), dumps(tmp_path, "many")
+    for k in STREAMS:
+        assert a[k] == b[k], k
+    for line in ("exact matches total", "final unmatched chars"):
+        assert [x for x in one.splitlines() if x.startswith(line)] == [x for x in many.splitlines() if x.startswith(line)], line
+    if factor:
+        heads = int([x for x in many.splitlines() if x.startswith("rounds whose extension exchange carried only the loadable head")][0].split(":")[1])
+        assert heads >= 1, many
+
+
+def test_five_ranks_with_a_record_less_file(tmp_path):
+    write_collection(tmp_path, 22, 70_000, 0.003, 1)
+    for i in (4, 9, 13):
+        (tmp_path / ("g%02d.fa" % i)).write_bytes(b"")
+    one = run_tool(["c", "-R", "5", "list.txt", "one"], str(tmp_path))
+    many = run_tool(["c", "--gpus", "5", "--exchange", "hostmem", "--shm-mb", "1", "-R", "1", "list.txt", "many"], str(tmp_path))
+    a, b = dumps(tmp_path, "one"), dumps(tmp_path, "many")
+    for k in STREAMS:
+        assert a[k] == b[k], k
+
+
+def _children(pid):
+    out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(pid)], capture_output=True, text=True).stdout.split()
+    return [int(x) for x in out]
+
+
+def test_a_killed_rank_ends_the_run_within_seconds(tmp_path):
+    """kill -9 on one of four ranks in the middle of a run: the others must not sit in an exchange forever — rank 0 notices the
+    child's abnormal end, raises the shared failure flag, every rank leaves, and the tool exits non-zero well within 30 s"""
+    import signal
+    import time
+    write_collection(tmp_path, 61, 1_500_000, 0.003, 1)
+    p = subprocess.Popen(["timeout", "-k", "10", "120", TOOL, "c", "--gpus", "4", "--exchange", "hostmem", "--shm-mb", "4", "-R", "1", "list.txt", "x"],
+                         cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.monotonic()
+    kids = []
+    while time.monotonic() - t0 < 20 and len(kids) < 3:                # the tool (child of `timeout`) forks ranks 1..3
+        tool = _children(p.pid)
+        kids = _children(tool[0]) if tool else []
+        time.sleep(0.05)
+    assert len(kids) == 3, kids
+    time.sleep(0.7)                                                     # into the rounds
+    assert p.poll() is None, "the run ended before a rank could be killed: make it longer"
+    os.kill(kids[1], signal.SIGKILL)
+    t1 = time.monotonic()
+    out, err = p.communicate(timeout=60)
+    assert p.returncode != 0 and time.monotonic() - t1 < 30, (p.returncode, time.monotonic() - t1, err[-500:])
+
+
+def test_bench_py_reports_a_killed_rank(tmp_path):
+    """`python bench.py --gpus 4` (its own spawner; the four ranks on this one device over gloo): rank 3 killed in the middle —
+    the run ends within 30 s, non-zero, and rank 0's place is taken by a line with "value": null, the rank, and how many ranks
+    had come up"""
+    import glob
+    import signal
+    import sys
+    import time
+    env = dict(os.environ, MBGC_BENCH_ONE_DEVICE="1", MBGC_BENCH_BACKEND="gloo", TMPDIR=str(tmp_path), MBGC_BENCH_PG_TIMEOUT="60")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "150", "--warmup", "2", "--round", "1",
+                          "--length", "1000000", "--cpu-sample", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.monotonic()
+    ups = []
+    while time.monotonic() - t0 < 150 and len(ups) < 4 and p.poll() is None:
+        ups = glob.glob(str(tmp_path / "mbgc_bench_*" / "rank*.up"))
+        time.sleep(0.2)
+    assert len(ups) == 4, (ups, p.poll())
+    pids = [int(x) for x in open(glob.glob(str(tmp_path / "mbgc_bench_*" / "pids"))[0]).read().split()]
+    time.sleep(1.0)                                                     # into the rounds
+    assert p.poll() is None, "the run ended before a rank could be killed: make it longer"
+    os.kill(pids[3], signal.SIGKILL)
+    t1 = time.monotonic()
+    out, err = p.communicate(timeout=90)
+    dt = time.monotonic() - t1
+    assert p.returncode != 0 and dt < 30, (p.returncode, dt, err[-800:])
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert lines and lines[-1]["value"] is None and "rank 3" in lines[-1]["error"] and lines[-1]["rccl_ranks_seen"] == 4, lines

@@ -208,3 +208,32 @@ def test_after_the_wrap_only_the_loadable_head_of_a_round_travels(tmp_path, worl
     assert len(set(hd)) == 1
     k, asked, whole = (int(x) for x in hd[0].split())
     assert k >= 1 and asked < whole, hd
+
+
+@pytest.mark.parametrize("per_rank,n,div,announce,lim", [(1, 25, 0.002, 1, LIM), (1, 25, 0.06, 0, LIM), (1, 33, 0.002, 1, 700_000)])
+def test_eight_ranks_gloo(tmp_path, per_rank, n, div, announce, lim):
+    """BASELINE configs[3]'s shape — eight ranks, file-per-rank, rounds of eight targets — as far as a CPU goes: == one
+    process with rounds of 8 in every stream, lock positions, refExtSize and on every replica's table; with the finalize queued
+    on all eight verdicts (similar collection), with dissimilar-contig retries that cut a round between ranks (6 %), and on a
+    buffer that wraps several times, where only the loadable head of a round travels"""
+    import torch.multiprocessing as mp
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_n, args=(world, port, str(tmp_path), div, per_rank, announce, n, lim), nprocs=world, join=True)
+    gs = collection(n, 60_000, div, seed=17)
+    res, ht, _ = reference_result(gs, world * per_rank, 1, lim)
+    for k, v in res["streams"].items():
+        assert (tmp_path / k).read_bytes() == v, k
+    assert (tmp_path / "locks").read_bytes() == res["locks"]
+    assert (tmp_path / "refext").read_bytes() == res["refExtSize"]
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("ht%d.npy" % r)), ht), r
+    sp = [(tmp_path / ("spec%d" % r)).read_text() for r in range(world)]
+    assert len(set(sp)) == 1
+    if div == 0.002 and lim == LIM:
+        assert int(sp[0].split()[1]) >= 1, sp                        # rounds finalized on the eight ranks' device-side verdicts
+    if lim < LIM:
+        hd = [(tmp_path / ("head%d" % r)).read_text() for r in range(world)]
+        assert len(set(hd)) == 1 and int(hd[0].split()[0]) >= 1 and int(hd[0].split()[1]) < int(hd[0].split()[2]), hd
