@@ -496,10 +496,26 @@ def spawn_ranks(n, argv=None, grace=5.0, limit=None):
         failed = "a rank ended with exit code %d" % rc
     seen = len([f for f in os.listdir(rundir) if f.endswith(".up")])
     shutil.rmtree(rundir, ignore_errors=True)
-    has_line = any(l.startswith("{") and '"metric"' in l for l in out.splitlines())
-    sys.stdout.write(out)
-    if failed is not None and not has_line:
-        print(error_line(n, 0, 0, failed, ranks_seen=seen))
+    # rank 0's own line stands when it carries a value; an error line of its own (it noticed a dead peer inside a collective) gives
+    # way to the spawner's, which knows WHICH rank ended first and how — rank 0's message rides along
+    kept, rank0_error, has_value = [], None, False
+    for l in out.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            try:
+                d = json.loads(l)
+                if d.get("value") is None and d.get("error"):
+                    rank0_error = d["error"]
+                    continue
+                has_value = True
+            except ValueError:
+                pass
+        kept.append(l)
+    if kept:
+        sys.stdout.write("\n".join(kept) + "\n")
+    if failed is not None and not has_value:
+        print(error_line(n, 0, 0, failed, ranks_seen=seen, extra={"rank0_error": rank0_error} if rank0_error else None))
+    elif failed is None and rank0_error and not has_value:
+        print(error_line(n, 0, 0, rank0_error, ranks_seen=seen))
     if failed is not None:
         print("bench.py: " + failed, file=sys.stderr)
     sys.stdout.flush()

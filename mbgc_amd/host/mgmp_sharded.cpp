@@ -285,6 +285,11 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
             applied = matcher->emitRoundBegin(emitParams(), locks, factors, processed, tidx, loadedPositions(),
                                               canSpec ? &spec : nullptr, un, counts);           // :381
         }
+        if (getenv("MBGC_HIP_SHARD_DEBUG")) {
+            fprintf(stderr, "[rank %u round %u] canSpec %d applied %d veto %d targets %u..%u un:", g, q, (int) canSpec, (int) applied, (int) veto, B.t0, B.t1);
+            for (size_t c = 0; c < ncont && c < un.size(); c++) fprintf(stderr, " %llu/%llu", (unsigned long long) un[c], (unsigned long long) (B.offsets[c + 1] - B.offsets[c]));
+            fprintf(stderr, " loaded %zu\n", matcher->getLoadedRefLength());
+        }
         if (applied) {
             for (size_t c = 0; c < ncont; c++) resCount += counts[c];
             size_t startPos = before;
@@ -394,8 +399,13 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
                         at += len;
                     }
                 }
-                matcher->synchronize();                     // the strings are in place (and nothing reads the other buffer any more)
-                DevBuf &dst = extAll[(q & 1) ^ 1];
+                matcher->synchronize();                     // the strings are in place (and nothing reads this round's buffer any more)
+                // THIS round's buffer — the one its own speculative all-gather may have used (not applied: its gated launches
+                // have found their gate shut) — never the other one: the finalize queued below reads the buffer while the
+                // NEXT round's all-gather, which starts at that round's top on a stream of its own, writes the other. (With the
+                // other one here, a replica that ran late loaded the next round's targets in place of this round's — and
+                // then found one of them in its reference, whole: four and five ranks on one GPU showed it, round 4.)
+                DevBuf &dst = extAll[q & 1];
                 ensure(dst, (size_t) N * most);
                 xc(mbgc_xchg_allgather_bytes_begin(X, extTmp.p, most, dst.p));
                 xc(mbgc_xchg_wait_bytes(X));

@@ -22,7 +22,7 @@ def collection(n, length, div, seed):
     return [synth.genome(base, i, div) for i in range(n)]
 
 
-def _worker(rank, world, port, outdir, div, n, announce):
+def _worker(rank, world, port, outdir, div, n, announce, per_rank=2):
     import torch
     import torch.distributed as dist
     from mbgc_amd import binding
@@ -36,7 +36,7 @@ def _worker(rank, world, port, outdir, div, n, announce):
     runner = RoundRunner(h, rank, world, None, "cuda:0", lazy=True, emit_params=binding.emit_params(1))
     runner.start()
     rounds = []
-    for rnd in round_schedule(len(gs) - 1, 2, world):
+    for rnd in round_schedule(len(gs) - 1, per_rank, world):
         mine = [gs[1 + t] for t in rnd[rank]]
         buf = torch.from_numpy(np.concatenate(mine)).to("cuda:0")
         offs = np.zeros(len(mine) + 1, dtype=np.uint64)
@@ -86,4 +86,29 @@ def test_two_replicas_on_one_gpu_equal_the_reference_loop(tmp_path, div, n, anno
     assert sp[0] == sp[1]
     if announce and div < 0.005:
         assert int(sp[0].split()[1]) >= 1, sp          # ... and a whole round's finalize ran on the two ranks' device-side verdicts
+    o.close()
+
+
+@pytest.mark.parametrize("world,per_rank,div,n,announce", [(5, 1, 0.002, 21, 1), (5, 1, 0.012, 16, 0), (4, 1, 0.002, 21, 1), (5, 2, 0.002, 31, 1)])
+def test_five_replicas_on_one_gpu_equal_the_reference_loop(tmp_path, world, per_rank, div, n, announce):
+    """as many replicas as a one-GPU box lets share its card beside this process (five): rank-major target order, the finalize
+    queued on five device-side verdicts, retries at 1.2 % — against the oracle's rounds of world x per_rank"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, str(tmp_path), div, n, announce, per_rank), nprocs=world, join=True)
+    gs = collection(n, 80_000, div, seed=23)
+    o = _orc.OracleMatcher(LIM)
+    res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [[g] for g in gs[1:]], world * per_rank)
+    for k, v in res["streams"].items():
+        assert (tmp_path / k).read_bytes() == v, k
+    assert (tmp_path / "locks").read_bytes() == res["locks"]
+    assert (tmp_path / "refext").read_bytes() == res["refExtSize"]
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("ht%d.npy" % r)), o.ht()), r
+    sp = [(tmp_path / ("spec%d" % r)).read_text() for r in range(world)]
+    assert len(set(sp)) == 1
+    if announce and div < 0.005:
+        assert int(sp[0].split()[1]) >= 1, sp
     o.close()
