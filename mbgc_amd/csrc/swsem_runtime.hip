@@ -1097,7 +1097,7 @@ int swsem_device_numa_node(int device) {
 
 int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, int skipMargin, int device) {
     *out = nullptr;
-    if (k1 <= 0 || (k1 % 2)) return fail(SWSEM_EINVAL, "Error initializing ExpSparseMEM: incorrect k1 (%d)", k1);
+    if (k1 <= 0) return fail(SWSEM_EINVAL, "s - reference sampling step - should be a positive integer.");   // MBGC_Params.h:593-597
     if (k2 != 1) return fail(SWSEM_EINVAL, "k2 = %d unsupported (MBGC always uses k2 = 1, MGMP_Params.h:202)", k2);
     if (L < 16) return fail(SWSEM_EINVAL, "Error: Minimal matching length too short!");
     if (maxRefLength < 64 || (maxRefLength >> __builtin_ctz((unsigned) k1)) >= (1ull << 32))
@@ -1114,7 +1114,11 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     h->swEnd = maxRefLength;
     h->swSize = maxRefLength / SW_WIDTH_FACTOR;
     init_params(h);
-    h->samplingPos = (uint64_t) k1;
+    // an even k1: SlidingWindowExpSparseEMMatcher — entries hold position >> ctz(k1), sampling starts at k1 (.cpp:494-503); an odd
+    // one: the base class (MGMP.cpp:170-176) — htEncodePos / htDecodePos are the identity (.h:74-76: k1ord = 0 here), sampling
+    // starts at REF_SHIFT (.h:78), which is also where a wrap puts it back, so the off-grid samples of the Exp variant do not occur
+    h->samplingPos = (k1 % 2) ? REF_SHIFT : (uint64_t) k1;
+    if (h->k1ord == 0) h->useTags = false;                  // (a lap tag per sampling slot would be two bytes per reference byte: stale entries are visited instead, same results)
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(SWSEM_EHIP, "hipStreamCreate failed"); }
     h->ownStream = true;
     {
@@ -1137,15 +1141,15 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_RESOLVE")) h->seqResolve = strcmp(e, "seq") == 0;
     if (const char *e = getenv("SWSEM_PROF_FAMS")) h->profMask = (uint32_t) strtoul(e, nullptr, 0);
     if (const char *e = getenv("SWSEM_CHAINS")) h->simt = atoi(e) != 1;
-    if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_INSERT_BESIDE")) h->insertBeside = atoi(e) != 0;
     if (const char *e = getenv("SWSEM_META_WARM")) h->metaWarm = std::min(swk::MWARM, std::max(0, atoi(e)));
     if (const char *e = getenv("SWSEM_OVERLAP")) { int x = atoi(e); if (x >= 0 && x <= OVERLAP_MAX) h->overlap = h->overlapFixed = (uint32_t) std::max(1, x); }
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x * (1024 / RBU); }   // (in units of 1024 positions)
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
+    if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = h->useTags && atoi(e) != 0;
     if (hipMalloc((void **) &h->ref, maxRefLength + REF_SLACK) != hipSuccess ||
-        hipMalloc((void **) &h->tags, nSlots * sizeof(uint16_t)) != hipSuccess ||
+        (h->useTags && hipMalloc((void **) &h->tags, nSlots * sizeof(uint16_t)) != hipSuccess) ||
         hipMalloc((void **) &h->ht, (size_t) h->hash_size * sizeof(ht_entry)) != hipSuccess ||
         hipMalloc((void **) &h->lut, 256) != hipSuccess) {
         swsem_destroy(h);
@@ -1156,7 +1160,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     build_lut(lut);
     HIPCHK(hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(h->ht, 0, (size_t) h->hash_size * sizeof(ht_entry), h->stream));
-    HIPCHK(hipMemsetAsync(h->tags, 0, nSlots * sizeof(uint16_t), h->stream));
+    if (h->tags) HIPCHK(hipMemsetAsync(h->tags, 0, nSlots * sizeof(uint16_t), h->stream));
     // start1[0] = 0 (.cpp:335); the rest of the buffer is written before it is ever read, the slack
     // past the end is zeroed because the reference's own reads run a few bytes over (:224, ENC:337)
     // the whole buffer starts out as zeros (the reference reads — harmlessly — bytes it has not loaded yet, e.g. the one at the

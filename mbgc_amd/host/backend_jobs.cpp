@@ -198,7 +198,7 @@ bool compress(const Ctx &x, Job &j, bool inBlocks) {
 
 
 // ---- the incremental form: blocks of the split streams are coded while the streams still grow ---------------------------
-struct Piece { std::string raw; Job job; };
+struct Piece { std::string raw; Job job; bool freed = false; };
 
 }  // namespace
 
@@ -224,6 +224,15 @@ struct mbgc_backend_stream {
             running++;
             lk.unlock();
             const bool ok = compress(x, pc->job, true);                // (a block is coded by the stream's coder itself, CodersLib.cpp:300-306)
+            // A block that shrank is written from its packed bytes: its raw bytes go now, not when the section is written (a stream
+            // of gigabytes would otherwise stand in memory three times: with the caller, in the pieces, in the raw fallback's copy).
+            // "Shrank" with the container's own bytes to spare (17 of header per block, 4 for the count), so that a stream whose
+            // blocks all went this way is certain to be smaller as a container than raw — the one case that needs the raw bytes back.
+            if (ok && pc->job.packed.size() + 32 <= pc->raw.size()) {
+                std::string().swap(pc->raw);
+                pc->job.src = nullptr;
+                pc->freed = true;
+            }
             lk.lock();
             running--;
             if (!ok) failed = true;
@@ -298,14 +307,20 @@ int mbgc_backend_stream_feed(mbgc_backend_stream_t *s, int st, const uint8_t *da
     auto &t = s->st[st];
     std::lock_guard<std::mutex> lk(s->mu);
     if (s->finishing) return fail("mbgc_backend_stream_feed: the section is being written");
-    t.pending.append((const char *) data, n);
     t.total += n;
-    // a split stream gives up a block as soon as more than a block is waiting (the rest stays: the last block is what is left)
-    if (t.coder.blocks && t.pending.size() > s->blockBytes) {
-        size_t at = 0;
-        for (; t.pending.size() - at > s->blockBytes; at += s->blockBytes) s->enqueue(t, t.pending.substr(at, s->blockBytes));
-        t.pending.erase(0, at);
+    if (!t.coder.blocks) { t.pending.append((const char *) data, n); return 0; }
+    // a split stream gives up a block as soon as more than a block is waiting (the rest stays: the last block is what is left);
+    // every byte is copied once, into the block it will be coded from
+    while (t.pending.size() + n > s->blockBytes) {
+        const size_t take = s->blockBytes - t.pending.size();
+        t.pending.append((const char *) data, take);
+        data += take; n -= take;
+        std::string blk;
+        blk.swap(t.pending);
+        s->enqueue(t, std::move(blk));
+        t.pending.reserve((size_t) std::min<uint64_t>(s->blockBytes, 1u << 26));
     }
+    t.pending.append((const char *) data, n);
     return 0;
 }
 
@@ -336,9 +351,19 @@ int mbgc_backend_stream_finish(mbgc_backend_stream_t *s, uint64_t refFinalTotalL
         // block's length from the block's own header (parallelBlocksDecompress, :316-345)
         Sink blocks;
         blocks.put<int32_t>((int32_t) t.pieces.size());
+        bool anyFreed = false;
+        for (auto &pc : t.pieces) anyFreed |= pc->freed;
+        // (the raw fallback of the whole stream — a container that is no smaller than the bytes, CodersLib.cpp:202-218 — needs them
+        // all: only a stream none of whose blocks shrank can get there, and then every block still has its bytes)
         std::string whole;
-        for (auto &pc : t.pieces) { whole += pc->raw; writeJob(blocks, pc->job); }
-        Job outer{(const uint8_t *) whole.data(), whole.size(), t.coder};
+        if (!anyFreed) for (auto &pc : t.pieces) whole += pc->raw;
+        for (auto &pc : t.pieces) { writeJob(blocks, pc->job); std::string().swap(pc->raw); }
+        if (anyFreed && blocks.s.size() >= t.total) {                  // (cannot happen when every block was freed; blocks that did not shrink beside ones that did)
+            sec.put<uint64_t>(t.total); sec.put<uint64_t>(blocks.s.size()); sec.put<uint8_t>((uint8_t) MBGC_PARALLEL_BLOCKS_CODER);
+            sec.put((const uint8_t *) blocks.s.data(), blocks.s.size());
+            continue;
+        }
+        Job outer{(const uint8_t *) whole.data(), (size_t) t.total, t.coder};
         outer.packed = std::move(blocks.s);
         writeJob(sec, outer);
     }

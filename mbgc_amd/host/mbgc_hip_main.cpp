@@ -78,6 +78,10 @@ int main(int argc, char **argv) {
         if (a == "-t1") params.sequentialMatching = true;                        // like `mbgc c -t1` (MBGC_Params.h:867-869)
         else if (a == "-m" && i + 1 < argc) params.setCompressionMode(atoi(argv[++i]));
         else if (a == "-R" && i + 1 < argc) params.roundSize = atoi(argv[++i]);
+        else if (a == "-s" && i + 1 < argc) {                                    // reference sampling step (MBGC_Params.h:593-600); an odd one: identity-encoded table entries
+            params.k1 = atoi(argv[++i]);
+            if (params.k1 <= 0) { fprintf(stderr, "s - reference sampling step - should be a positive integer.\n\n"); return EXIT_FAILURE; }
+        }
         else if (a == "-d" && i + 1 < argc) params.device = atoi(argv[++i]);
         else if (a == "-L") params.lazyDecompressionSupport = false;             // disable lazy decompression support
         else if (a == "-U") params.uppercaseDNA = true;                          // MBGC_Params.h: converts bases to uppercase
@@ -97,7 +101,7 @@ int main(int argc, char **argv) {
         else pos.push_back(a);
     }
     if (pos.size() != 2) {
-        fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-R targetsPerRound] [-d device] [-U] [--verify | --verify-every K] [--ref-factor F] [--bench [--warmup rounds]] "
+        fprintf(stderr, "usage: mbgc-hip c [-t1] [-m mode] [-s samplingStep] [-R targetsPerRound] [-d device] [-U] [--verify | --verify-every K] [--ref-factor F] [--bench [--warmup rounds]] "
                         "[--gpus N [--exchange rccl|hostmem] [--shm-mb M]] [--backend coders.so [--backend-threads T] [--backend-blocks K | --backend-overlap MiB] [--coder-threads t]] <sequencesListFile> <outputPrefix>\n"
                         "  --backend writes <outputPrefix>.collective: the collective section of the matcher-side streams (the header-side streams are the CLI's and\n"
                         "  go in empty); --coder-threads = the reference's -t as its coders see it (LZMA runs two threads when it is > 1)\n");
@@ -105,6 +109,12 @@ int main(int argc, char **argv) {
     }
     if (gpus < 1 || (transport != "rccl" && transport != "hostmem") || (gpus > 1 && params.sequentialMatching)) {
         fprintf(stderr, "--gpus needs a positive count, --exchange rccl or hostmem, and the round mode (not -t1 / -m 3: those match sequentially)\n");
+        return EXIT_FAILURE;
+    }
+    if (gpus > 1 && params.verifyEmissions) {
+        // (the sharded round loop has no verification step: every rank would have to decode its own emissions before the round's
+        // finalize — accepted silently before, the run then ended with "verified on the device: 0 contigs" and exit code 0)
+        fprintf(stderr, "--verify / --verify-every check the emissions of the one-GPU schedules; with --gpus N verify a single-GPU run of the same rounds (-R N x r writes the same streams)\n");
         return EXIT_FAILURE;
     }
     std::vector<std::string> files;
@@ -231,8 +241,14 @@ int main(int argc, char **argv) {
             printf("backend: %zu stream bytes to %zu in %.0f ms (%d threads, %d x the reference's blocks)\n", raw, section.size(), ms, backendThreads,
                    std::max(1, backendBlocksScale));
     }
-    if (params.verifyEmissions) printf("verified on the device: %llu contigs, %llu bases decoded back to their bytes\n",
-                                       (unsigned long long) params.verifiedContigs, (unsigned long long) params.verifiedBases);
+    if (params.verifyEmissions) {
+        printf("verified on the device: %llu contigs, %llu bases decoded back to their bytes\n",
+               (unsigned long long) params.verifiedContigs, (unsigned long long) params.verifiedBases);
+        if (params.verifiedContigs == 0 && files.size() > 1) {
+            fprintf(stderr, "--verify was asked for and no emission was verified\n");
+            return finish(EXIT_FAILURE);
+        }
+    }
     if (!params.sequentialMatching)
         printf("rounds of %d targets%s; reference extension bytes dropped at the sliding window's end: %zu\n", params.roundSize,
                gpus > 1 ? " per GPU" : "", enc.droppedExtensionBytes());

@@ -62,6 +62,8 @@ extern "C" {
 // ---------------------------------------------------------------- matcher
 void *refm_create(uint64_t maxRefLen, int L, int k1, int k2, int skipMargin) {
     quiet();
+    if (__builtin_ctz((uint32_t) k1) == 0)                                   // MGMP.cpp:170-176: an odd k1 takes the base class
+        return new SlidingWindowSparseEMMatcher(maxRefLen, L, k1, k2, skipMargin);
     return new SlidingWindowExpSparseEMMatcher(maxRefLen, L, k1, k2, skipMargin);
 }
 void refm_destroy(void *h) { delete (SlidingWindowSparseEMMatcher *) h; }

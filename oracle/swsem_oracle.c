@@ -73,11 +73,11 @@ static void init_params(orc_matcher *m) {
 }
 
 orc_matcher *orc_matcher_create(uint64_t maxRefLength, int L, int k1, int k2, int skipMargin) {
-    if (k1 % 2 || k1 <= 0 || L < 16) return NULL;            /* .cpp:499-502, :82-85 */
+    if (k1 <= 0 || L < 16) return NULL;                       /* :82-85; an odd k1 is the base class (identity encoding), MGMP.cpp:170-176 */
     orc_matcher *m = (orc_matcher *) calloc(1, sizeof(*m));
     m->maxRefLength = maxRefLength;
     m->L = L; m->k1 = k1; m->k2 = k2; m->skipMargin = skipMargin;
-    m->k1ord = __builtin_ctz((unsigned) k1);                  /* .cpp:498 */
+    m->k1ord = __builtin_ctz((unsigned) k1);                  /* .cpp:498; 0 for an odd k1 = htEncodePos / htDecodePos the identity, .h:74-76 */
     m->ref = (uint8_t *) calloc(maxRefLength + REF_SLACK, 1);
     m->ref[0] = 0;                                            /* .cpp:335 */
     m->pos1 = REF_SHIFT;                                      /* .cpp:337 */
@@ -85,7 +85,7 @@ orc_matcher *orc_matcher_create(uint64_t maxRefLength, int L, int k1, int k2, in
     m->swSize = maxRefLength / SW_WIDTH_FACTOR;               /* .cpp:339 */
     m->circular = 1;
     init_params(m);
-    m->samplingPos = (uint64_t) k1;                           /* .cpp:503 */
+    m->samplingPos = (k1 % 2) ? REF_SHIFT : (uint64_t) k1;    /* .cpp:503 (Exp variant); the base class keeps its initialiser, .h:78 */
     m->ht = (uint32_t *) calloc(m->hash_size, sizeof(uint32_t));
     m->prefilter = 1;
     return m;

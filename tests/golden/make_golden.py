@@ -32,6 +32,11 @@ CASES = {
     # lie beyond it — their matches carry a fifth offset byte (mapOff5th). Two more fields: start position, 40-bit flag.
     "seq_bit40": (6, 200_000, 0.012, 105, (1 << 32) + 6_000_000, 2, 0, 1, (1 << 32) - 500_000, 1),
     "rounds3_bit40": (8, 150_000, 0.012, 106, (1 << 32) + 6_000_000, 1, 3, 1, (1 << 32) - 400_000, 1),
+    # an ODD sampling step (`mbgc -s 15`): MGMP.cpp:170-176 then builds the base class SlidingWindowSparseEMMatcher, whose table
+    # entries hold positions as they are (htEncodePos / htDecodePos the identity, .h:74-76) and whose sampling starts at
+    # REF_SHIFT. One more field: k1. Sequential, and rounds on a buffer that wraps several times.
+    "seq_k15": (6, 60_000, 0.012, 107, 0, 2, 0, 1, 0, 0, 15),
+    "rounds3_wrap_k9": (12, 50_000, 0.015, 108, 380_000, 2, 3, 1, 0, 0, 9),
 }
 
 
@@ -54,6 +59,11 @@ def extras(case):
     return (int(c[8]), bool(c[9])) if len(c) > 8 else (0, False)
 
 
+def k1_of(case):
+    c = CASES[case]
+    return int(c[10]) if len(c) > 10 else 16
+
+
 def ht_digest(ht):
     nz = np.nonzero(ht)[0].astype(np.uint64)
     h = hashlib.sha256()
@@ -65,7 +75,7 @@ def ht_digest(ht):
 def run_reference(case):
     gs, lim, cpt, rs, mode = inputs(case)
     margin = 24 if mode >= 2 else 16
-    r = _refh.RefMatcher(lim, skip_margin=margin)
+    r = _refh.RefMatcher(lim, k1=k1_of(case), skip_margin=margin)
     start, bit40 = extras(case)
     if start:
         r.set_position(start, 0)

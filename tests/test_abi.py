@@ -64,8 +64,8 @@ def test_parameter_validation_needs_no_device():
     from mbgc_amd import binding
     L = binding.lib()
     h = ctypes.c_void_p()
-    assert L.swsem_create(ctypes.byref(h), 1 << 20, 32, 7, 1, 16, 0) == -1       # odd k1
-    assert b"incorrect k1" in L.swsem_last_error()
+    assert L.swsem_create(ctypes.byref(h), 1 << 20, 32, 0, 1, 16, 0) == -1       # k1 must be positive (an odd one is the identity-encoding variant)
+    assert b"sampling step" in L.swsem_last_error()
     assert L.swsem_create(ctypes.byref(h), 1 << 20, 32, 16, 2, 16, 0) == -1      # k2 != 1
     assert L.swsem_create(ctypes.byref(h), 1 << 20, 8, 16, 1, 16, 0) == -1       # L too short
     p = binding.emit_params(0)

@@ -10,7 +10,7 @@ import _driver
 import _orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["seq_m1", "seq_m2", "rounds3_wrap", "rounds4_divergent", "seq_bit40", "rounds3_bit40"]
+CASES = ["seq_m1", "seq_m2", "rounds3_wrap", "rounds4_divergent", "seq_bit40", "rounds3_bit40", "seq_k15", "rounds3_wrap_k9"]
 
 
 def load(case):
@@ -32,6 +32,12 @@ def extras(d):
     """(loader position to start from, 40-bit offsets) of the cases that have them"""
     c = d["case"]
     return (int(c[8]), bool(c[9])) if len(c) > 8 else (0, False)
+
+
+def k1_of(case):
+    """the sampling step of the case (an odd one: the reference's base matcher class with identity-encoded table entries)"""
+    c = np.load(os.path.join(GOLDEN, case + ".npz"))["case"]
+    return int(c[10]) if len(c) > 10 else 16
 
 
 def split(g, k):
@@ -78,7 +84,7 @@ def margin(case):
 @pytest.mark.parametrize("case", CASES)
 def test_oracle_reproduces_reference_fixtures(case):
     d, gs, lim, cpt, rs, mode = load(case)
-    o = _orc.OracleMatcher(lim, skip_margin=margin(case))
+    o = _orc.OracleMatcher(lim, k1=k1_of(case), skip_margin=margin(case))
     run_case(case, o, lambda: _orc.OracleEmitter(o, _orc.emit_params(mode, enable40bitReference=int(extras(d)[1]))))
 
 
@@ -88,7 +94,7 @@ def test_hip_reproduces_reference_fixtures(case):
     from mbgc_amd import binding
     from test_gpu_emit import HipEmitter
     d, gs, lim, cpt, rs, mode = load(case)
-    h = binding.SlidingWindowSparseEMMatcher(lim, skip_margin=margin(case))
+    h = binding.SlidingWindowSparseEMMatcher(lim, k1=k1_of(case), skip_margin=margin(case))
     run_case(case, h, lambda: HipEmitter(binding, h, binding.emit_params(mode, enable40bitReference=int(extras(d)[1]))))
 
 

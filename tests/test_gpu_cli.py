@@ -373,3 +373,36 @@ def test_repeated_runs_write_the_same_bytes(tmp_path):
             h.update((tmp_path / ("o." + k)).read_bytes())
         digests.add(h.hexdigest())
     assert len(digests) == 1
+
+
+@pytest.mark.parametrize("k1,args,rs", [(15, ["-t1"], 0), (9, ["-R", "3"], 3), (7, ["-R", "2"], 2)])
+def test_an_odd_sampling_step_through_the_cpp_host(tmp_path, k1, args, rs):
+    """`mbgc -s <odd k1>` (MGMP.cpp:170-176: the base matcher class, identity-encoded table entries): the C++ host with `-s k1` writes
+    the streams the oracle, driven through the reference's target loop with the same sampling step, writes"""
+    base = synth.base_codes(90_000, 77)
+    files = [split(synth.genome(base, i, 0.012), 2) for i in range(8)]
+    paths = []
+    for i, contigs in enumerate(files):
+        p = tmp_path / ("g%d.fa" % i)
+        p.write_bytes(b"".join(synth.fasta_bytes(c, i * 10 + j) for j, c in enumerate(contigs)))
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    run_tool(["c", "-s", str(k1)] + args + ["list.txt", "out"], str(tmp_path))
+    if rs == 0:
+        lim, _ = _driver.ref_length_limit(len(files), os.path.getsize(paths[0]))
+        o = _orc.OracleMatcher(lim, k1=k1)
+        oe = _orc.OracleEmitter(o)
+        res = _driver.encode_sequential(o, oe, files)
+        streams = oe.streams()
+        g0lit = files[0][0].tobytes() + b"\xa2"
+    else:
+        lim, _ = _driver.ref_length_limit(len(files), sum(c.size for c in files[0]))
+        o = _orc.OracleMatcher(lim, k1=k1)
+        res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), files[0], files[1:], rs)
+        streams = res["streams"]
+        g0lit = b"".join(c.tobytes() + b"\xa2" for c in files[0])
+    got = {k: (tmp_path / ("out." + k)).read_bytes() for k in ("literals", "mapOff", "mapLen", "gapDelta", "flags", "locksPos", "refExtSize")}
+    assert got["literals"] == g0lit + streams["literals"]
+    for k in ("mapOff", "mapLen", "gapDelta", "flags"):
+        assert got[k] == streams[k], k
+    assert got["locksPos"] == res["locks"] and got["refExtSize"] == res["refExtSize"]

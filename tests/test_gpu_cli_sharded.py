@@ -227,3 +227,11 @@ def test_bench_py_reports_a_killed_rank(tmp_path):
     assert p.returncode != 0 and dt < 30, (p.returncode, dt, err[-800:])
     lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
     assert lines and lines[-1]["value"] is None and "rank 3" in lines[-1]["error"] and lines[-1]["rccl_ranks_seen"] == 4, lines
+
+
+def test_verify_is_refused_with_several_ranks(tmp_path):
+    """--verify with --gpus N used to be accepted and silently skipped (the run ended with "verified on the device: 0 contigs" and
+    exit code 0): it is refused now, with the way to get the check"""
+    write_collection(tmp_path, 5, 70_000, 0.003, 1)
+    r = subprocess.run([TOOL, "c", "--verify", "--gpus", "2", "--exchange", "hostmem", "-R", "1", "list.txt", "x"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--verify" in r.stderr and "single-GPU" in r.stderr, (r.returncode, r.stderr[-300:])

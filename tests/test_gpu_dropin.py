@@ -58,6 +58,20 @@ def test_the_patched_reference_cli_writes_the_stock_archive(tmp_path):
     assert (tmp_path / "hip3.mbgc").read_bytes() == (tmp_path / "ref3.mbgc").read_bytes()
 
 
+@needs_ref
+@pytest.mark.skipif(not os.access(DROPIN, os.X_OK), reason="oracle/_ref/mbgc-dropin not built (make -C oracle dropin)")
+def test_the_patched_cli_refuses_the_parallel_schedule(tmp_path):
+    """the reference's default schedule calls matchTexts / processMatches from several worker threads on the one matcher
+    (MGMP.cpp:520-555); the device handle serves one such pair at a time — the patched binary says so and exits instead of
+    writing an archive whose streams its threads mixed up (advisor, round 3)"""
+    exp = __import__("json").load(open(os.path.join(LIST, "expected_t1.json")))
+    for f in exp["files"]:
+        (tmp_path / f).write_bytes(lzma.open(os.path.join(LIST, f + ".xz")).read())
+    (tmp_path / "seqlist.txt").write_text("\n".join(exp["files"]) + "\n")
+    r = subprocess.run([DROPIN, "c", "seqlist.txt", "hip.mbgc"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one matchTexts/processMatches pair at a time" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
 def split(g, k):
     cuts = [0] + [g.size * i // k + (7 * i) % 13 for i in range(1, k)] + [g.size]
     return [g[cuts[i]:cuts[i + 1]] for i in range(k)]

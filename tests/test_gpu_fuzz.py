@@ -177,15 +177,29 @@ def genomes_with_runs(rng, length, nfiles):
     return [cut(rng, mutate(rng, base, 0.004 * (1 + i % 4)), int(rng.integers(1, 5))) for i in range(nfiles)]
 
 
+FUZZ_ROUND = 4        # the build round these seeds belong to: every round fuzzes cases no round before it has seen
+
+
 def _extra():
     import os
-    return int(os.environ.get("MBGC_FUZZ_EXTRA", "24"))
+    return int(os.environ.get("MBGC_FUZZ_EXTRA", "100"))
+
+
+def _seeds(first):
+    """MBGC_FUZZ_EXTRA seeds (default 100) from `first` on, moved by the round number (MBGC_FUZZ_ROUND overrides it: any earlier
+    round's cases can be run again); printed, so that a failure names its case"""
+    import os
+    rnd = int(os.environ.get("MBGC_FUZZ_ROUND", FUZZ_ROUND))
+    lo = first + 100_000 * rnd
+    print("fuzz seeds %d..%d (round %d)" % (lo, lo + _extra() - 1, rnd))
+    return range(lo, lo + _extra())
 
 
 def test_fuzz_small_buffers_and_runs_of_one_letter(binding):
-    """MBGC_FUZZ_EXTRA cases (default 24; 1000 ran clean at the end of round 2): buffers of 1.5 to 20 genome lengths — most
-    wrap several times, inside rounds with retries too —, runs of one letter, both target loops of the plain API"""
-    for seed in range(5000, 5000 + _extra()):
+    """MBGC_FUZZ_EXTRA cases (default 100, seeds of their own every round; 1000 ran clean at the end of round 2): buffers of 1.5 to
+    20 genome lengths — most wrap several times, inside rounds with retries too —, runs of one letter, both target loops of the
+    plain API"""
+    for seed in _seeds(5000):
         rng = np.random.default_rng(seed)
         length = int(rng.choice([30_000, 50_000, 80_000]))
         gs = genomes_with_runs(rng, length, int(rng.integers(6, 14)))
@@ -213,7 +227,7 @@ def test_fuzz_the_pipelined_round_runner(binding):
     resolve launch), targets of several contigs"""
     import torch
     from mbgc_amd.rounds import RoundRunner, round_schedule
-    for seed in range(7000, 7000 + _extra()):
+    for seed in _seeds(7000):
         rng = np.random.default_rng(seed)
         length = int(rng.choice([30_000, 60_000]))
         gs = genomes_with_runs(rng, length, int(rng.integers(8, 20)))

@@ -145,7 +145,7 @@ def test_wrap_quirk_and_locks(binding, sequential):
 
 def test_other_kmer_parameters(binding):
     gs = small_collection(3, 80_000, 0.02, seed=9)
-    for L, k1, margin in ((32, 16, 24), (24, 8, 16), (40, 6, 16), (48, 16, 16)):
+    for L, k1, margin in ((32, 16, 24), (24, 8, 16), (40, 6, 16), (48, 16, 16), (32, 15, 16), (32, 7, 16), (40, 5, 24)):   # odd k1: identity-encoded entries (.h:74-76)
         h, o = pair(binding, 4_000_000, L=L, k1=k1, skip_margin=margin)
         assert h.K() == o.K() and h.hash_size() == o.hash_size()
         for m in (h, o):
@@ -160,7 +160,7 @@ def test_other_kmer_parameters(binding):
 
 def test_error_paths(binding):
     with pytest.raises(binding.SwsemError):
-        binding.SlidingWindowSparseEMMatcher(1 << 20, k1=7)          # odd k1: ExpSparseMEM init error
+        binding.SlidingWindowSparseEMMatcher(1 << 20, k1=0)          # the sampling step is a positive integer (MBGC_Params.h:593-597)
     h = binding.SlidingWindowSparseEMMatcher(1 << 20)
     with pytest.raises(binding.SwsemError):
         h.match(np.zeros(100, dtype=np.uint8), min_len=16)           # minMatchLength < K

@@ -339,3 +339,39 @@ def test_the_fuzz_case_with_an_n_run_behind_a_wrap(refh):
         assert a["streams"][k] == b["streams"][k], k
     assert_same_state(r, o)
     assert any(len(m) and (np.asarray(m)[:, 0] == 8276).any() for m in b["matches"])      # the matches in question
+
+
+@pytest.mark.parametrize("k1,L,sequential", [(15, 32, True), (7, 32, False), (9, 40, False), (5, 32, True)])
+def test_an_odd_sampling_step_takes_the_identity_encoded_matcher(refh, k1, L, sequential):
+    """`mbgc -s <odd k1>`: MGMP.cpp:170-176 builds the base class SlidingWindowSparseEMMatcher — table entries are positions as they
+    are (htEncodePos / htDecodePos the identity, .h:74-76), sampling starts at REF_SHIFT (.h:78). The restatement follows (k1ord =
+    0): match rows, table image and loader state equal the reference's through several wraps, with locks, separators and
+    reverse-complement loads (the reference side is built by refm_create as MGMP builds it)"""
+    rng = np.random.default_rng(50 + k1)
+    base = rng.integers(0, 4, 50_000)
+    r, o = refh.RefMatcher(90_000, L=L, k1=k1), _orc.OracleMatcher(90_000, L=L, k1=k1)
+    assert r.K() == o.K() and r.hash_size() == o.hash_size()
+    if sequential:
+        r.disable_sliding_window(); o.disable_sliding_window()
+    nm = 0
+    for step in range(12):
+        g = base.copy()
+        mask = rng.random(g.size) < 0.02
+        g[mask] = (g[mask] + 1) & 3
+        g = synth.ACGT[g][: int(rng.integers(15_000, 50_000))]
+        lock = NO_LOCK
+        if not sequential:
+            lr, lo = r.acquire_lock(), o.acquire_lock()
+            assert lr == lo
+            lock = lo
+        mr, mo = r.match(g, L, lock), o.match(g, L, lock)
+        assert np.array_equal(mr, mo), step
+        nm += len(mo)
+        for m in (r, o):
+            m.load_ref(g, load_rc=bool(step % 4 == 0), add_sep=True)
+            if step % 2:
+                m.load_separator(0)
+        if not sequential:
+            r.release_lock(lock); assert o.release_lock(lock) == 0
+        assert_same_state(r, o)
+    assert o.loaded_ref_length() > 89_999 + 40_000 and nm > 500      # wrapped (with locks the window clips what a round loads)
