@@ -550,109 +550,21 @@ void MultipleGenomeMatchingProcessor::extensionStrings(const RoundBatch &B, cons
     }
 }
 
-// A round whose first pass gave up a contig as dissimilar (MGMP.cpp:382-388: "discard, wait until the earlier targets
-// are loaded, retry"): the deterministic form of that wait, with blocking calls — match + emit what is pending, load
-// the targets in front of the first given-up contig, redo everything from that contig on. Locks are held by the caller.
-void MultipleGenomeMatchingProcessor::processRoundWithRetries(RoundBatch &B, size_t expectTaken) {
-    const std::vector<uint64_t> &offsets = B.offsets;
-    const size_t ncont = B.targetOf.size();
-    const uint32_t r0 = B.t0, r1 = B.t1;
-    auto targetOf = [&](size_t c) { return B.t0 + B.targetOf[c]; };
-    uint8_t *dev = B.seqDev;
-    size_t p0 = 0;                                                                              // contigs [p0, ncont) are pending
-    std::vector<uint64_t> unmatched(ncont, SIZE_MAX);
-    std::vector<EmittedStreams> emitted(ncont);
-    uint32_t finalized = r0;                                                                    // == processedTargetsCount
-    // The pending contigs are matched against the reference as it stands, and the ones in front of the first given-up
-    // contig are taken. They are tried a stretch at a time — as many as twice what the last pass took, then twice that —
-    // and the pass stops at the first stretch that holds a given-up contig: what lies behind it would be matched again
-    // anyway (the first round of a collection of similar genomes takes one target per pass until the reference holds
-    // enough of them; matching all of the round's remaining targets in every pass would be 800 target scans for 40).
-    size_t took = std::min(ncont, expectTaken);                                                 // (the caller's first pass has seen where the first one is)
-    while (true) {
-        int cut = (int) ncont;                                                                  // first contig that has to be retried
-        size_t stretch = std::max<size_t>(2, 2 * took), at = p0;
-        took = 0;
-        while (at < ncont && cut == (int) ncont) {
-            const size_t n = std::min(stretch, ncont - at);
-            std::vector<uint64_t> offs, locks, counts;
-            std::vector<int> factors;
-            std::vector<int64_t> processed, tidx;
-            for (size_t c = at; c < at + n; c++) {
-                offs.push_back(offsets[c] - offsets[at]);
-                locks.push_back(matchingLocksPos[targetOf(c)]);
-                factors.push_back(unmatchedFractionFactors[2 * targetOf(c)]);
-                processed.push_back(processedTargetsCount);
-                tidx.push_back(targetOf(c));
-            }
-            offs.push_back(offsets[at + n] - offsets[at]);
-            const double tm0 = nowSeconds();
-            matcher->matchRound(dev + offsets[at], offs, params->k, locks, counts);            // :379
-            const double te0 = nowSeconds();
-            g_tMatch += te0 - tm0;
-            std::vector<EmittedStreams> out;
-            matcher->emitRound(emitParams(), locks, factors, processed, tidx, loadedPositions(), out);   // :381
-            g_tEmit += nowSeconds() - te0;
-            g_retryPasses++; g_retryContigs += n;
-            if (params->verifyEmissions) verifyEmission(n, offs[n]);
-            for (size_t k = 0; k < n; k++) {
-                const int c = (int) (at + k);
-                if (out[k].unmatchedChars == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) {   // :382-388
-                    cut = std::min(cut, c);
-                    continue;
-                }
-                if (c < cut) {
-                    unmatched[c] = out[k].unmatchedChars;
-                    resCount += counts[k];
-                    emitted[c] = std::move(out[k]);
-                    took++;
-                }
-            }
-            at += n;
-            stretch *= 2;
+// streams the host holds already, target by target (targets of a round that kept what its first pass found while others
+// were matched again, processTargetsRounds): contig by contig, then the target separator — the targets arrive in order, so the
+// bytes go straight to where appendTargetStreams (ENC.cpp:543-556) would put them
+void MultipleGenomeMatchingProcessor::appendHeldTargets(std::vector<std::vector<EmittedStreams>> &targets) {
+    for (auto &contigs : targets) {
+        for (EmittedStreams &e : contigs) {
+            swsem_streams_t view = {};
+            for (int i = 0; i < SWSEM_NSTREAMS; i++) { view.data[i] = (const uint8_t *) e.s[i].data(); view.size[i] = e.s[i].size(); }
+            view.unmatchedChars = e.unmatchedChars; view.extensionsMatchedChars = e.extensionsMatchedChars;
+            view.extensionsMismatches = e.extensionsMismatches; view.totalMatched = e.totalMatched;
+            view.removedGapBreakingMatches = e.removedGapBreakingMatches; view.nmatches = e.nmatches;
+            appendContigInOrder(view);
+            e = EmittedStreams();
         }
-        // targets before the one holding the cut are complete: load their extensions in order (:433-468), all in one call
-        const uint32_t upto = cut < (int) ncont ? targetOf(cut) : r1;
-        if (upto > finalized) {
-            std::vector<char> ext(ncont, 0), rc(ncont, 0);
-            for (size_t c = 0; c < ncont; c++) {
-                const uint32_t t = targetOf(c);
-                if (t < finalized || t >= upto) continue;
-                const size_t len = offsets[c + 1] - offsets[c];
-                ext[c] = params->isContigProperForRefExtension(len, unmatched[c], unmatchedFractionFactors[2 * t]);                 // :389-392
-                rc[c] = params->rcInReference && params->isContigProperForRefRCExtension(len, unmatched[c], params->unmatchedFractionRCFactor);
-            }
-            std::vector<const uint8_t *> extDev;
-            std::vector<uint64_t> extLen, loadedAfter, tlocks;
-            extensionStrings(B, ext, rc, finalized - r0, upto - r0, extDev, extLen);
-            for (uint32_t t = finalized; t < upto; t++) tlocks.push_back(matchingLocksPos[t]);
-            size_t startPos = matcher->getLoadedRefLength();
-            const double tf0 = nowSeconds();
-            matcher->finalizeTargets(extDev, extLen, params->refRegionSeparators, REF_REGION_SEPARATOR, lazyMode(), tlocks, loadedAfter);   // :440-457
-            g_tFinalize += nowSeconds() - tf0;
-            for (uint32_t t = finalized; t < upto; t++) {
-                // the target's streams: contig by contig, then the target separator — the targets arrive in order here, so the
-                // bytes go straight to where appendTargetStreams (ENC.cpp:543-556) would put them (divergent collections, which
-                // take this path, have the large streams: 0.4 bytes per base)
-                for (size_t c = 0; c < ncont; c++)
-                    if (targetOf(c) == t) {
-                        swsem_streams_t view = {};
-                        for (int i = 0; i < SWSEM_NSTREAMS; i++) { view.data[i] = (const uint8_t *) emitted[c].s[i].data(); view.size[i] = emitted[c].s[i].size(); }
-                        view.unmatchedChars = emitted[c].unmatchedChars; view.extensionsMatchedChars = emitted[c].extensionsMatchedChars;
-                        view.extensionsMismatches = emitted[c].extensionsMismatches; view.totalMatched = emitted[c].totalMatched;
-                        view.removedGapBreakingMatches = emitted[c].removedGapBreakingMatches; view.nmatches = emitted[c].nmatches;
-                        appendContigInOrder(view);
-                        emitted[c] = EmittedStreams();
-                    }
-                endTargetInOrder();
-                noteTargetLoaded(t, startPos, loadedAfter[t - finalized]);                      // :557-563
-                startPos = loadedAfter[t - finalized];
-                processedTargetsCount = t + 1;
-            }
-        }
-        finalized = upto;
-        if (cut >= (int) ncont) break;
-        p0 = (size_t) cut;
+        endTargetInOrder();
     }
 }
 
@@ -678,42 +590,49 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             loadRound(1 + slots[r].t0, 1 + slots[r].t1, slots[r], 1 + std::min(targetsCount, (r + 1) * R), 1 + std::min(targetsCount, (r + 2) * R),
                       r + 1 < nRounds ? &slots[r + 1] : nullptr);
         }
-    struct Deferred { bool valid = false; RoundBatch *B = nullptr; } prev;   // emission whose streams have not been taken yet
+    // an emission whose streams have not been taken yet: targets [u0, u1) of batch B, its contigs [c0, c1). `tail`: targets that
+    // follow it and whose streams the host holds already (they kept what the batch's first pass found, see below) — appended
+    // behind the unit's, target by target
+    typedef std::vector<std::vector<EmittedStreams>> HeldTargets;
+    struct Deferred { bool valid = false; RoundBatch *B = nullptr; uint32_t u0 = 0, u1 = 0; size_t c0 = 0, c1 = 0; std::shared_ptr<HeldTargets> tail; } prev;
     int predicted = -1;                                                     // what every contig of the last round decided (-1: no prediction)
     // per-target stream merge, ENC.cpp:542-556: the views of a round's streams (page-locked memory of the emission slot)
     // are appended to the collection's strings by a thread of its own, while the next round is matched — the slot's
     // memory belongs to the emission after the next one, so the appends are waited for before that one begins
     std::future<void> appending;
     auto appendsDone = [&] { if (appending.valid()) appending.get(); };
-    auto collect = [&](RoundBatch &B, bool newerBegun) {
+    auto collect = [&](const Deferred &D, bool newerBegun) {
+        RoundBatch &B = *D.B;
         const double tc0 = nowSeconds();
         appendsDone();
         if (newerBegun) matcher->emitSelect(true);
-        if (!bench && !B.targetOf.empty()) { swsem_streams_t st = {}; matcher->emitView(0, st); }   // (waits for the emission and its copy)
+        if (!bench && D.c1 > D.c0) { swsem_streams_t st = {}; matcher->emitView(0, st); }   // (waits for the emission and its copy)
         g_tCollectWait += nowSeconds() - tc0;
         auto views = std::make_shared<std::vector<swsem_streams_t>>();
         auto perTarget = std::make_shared<std::vector<uint32_t>>();
-        size_t c = 0;                                                       // (the contigs of a round are in target order)
-        for (uint32_t t = B.t0; t < B.t1; t++) {
+        size_t c = D.c0;                                                    // (the contigs of a round are in target order)
+        for (uint32_t u = D.u0; u < D.u1; u++) {
             uint32_t k = 0;
-            for (; c < B.targetOf.size() && B.t0 + B.targetOf[c] == t; c++) {
+            for (; c < D.c1 && B.targetOf[c] == u; c++) {
                 if (bench) continue;                                        // bench: the bytes stay packed in HBM, as in bench.py
                 swsem_streams_t st = {};
-                matcher->emitView((int) c, st);
+                matcher->emitView((int) (c - D.c0), st);
                 views->push_back(st);
                 k++;
             }
             perTarget->push_back(k);
         }
         if (newerBegun) matcher->emitSelect(false);
+        std::shared_ptr<HeldTargets> tail = D.tail;
         if (!bench)
-            appending = std::async(std::launch::async, [this, views, perTarget] {
+            appending = std::async(std::launch::async, [this, views, perTarget, tail] {
                 const double ta0 = nowSeconds();
                 size_t v = 0;
                 for (uint32_t k : *perTarget) {
                     for (uint32_t i = 0; i < k; i++) appendContigInOrder((*views)[v++]);
                     endTargetInOrder();
                 }
+                if (tail) appendHeldTargets(*tail);
                 g_tAppend += nowSeconds() - ta0;
             });
         g_tCollect += nowSeconds() - tc0;
@@ -734,7 +653,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             loadRound(1 + B.t0, 1 + B.t1, B, 1 + std::min(targetsCount, (r + 1) * R), 1 + std::min(targetsCount, (r + 2) * R),
                       r + 1 < nRounds ? &slots[(r + 1) % 3] : nullptr);
         } else if ((int) r == params->benchWarmup) {
-            if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); prev.valid = false; }
+            if (prev.valid) { matcher->emitEnd(); collect(prev, false); prev.valid = false; }
             matcher->synchronize();
             if (getenv("MBGC_HIP_PROFILE")) swsem_profile_enable(matcher->handle(), 1);   // (the kernel profile covers what the clock covers)
             tStart = now();
@@ -747,7 +666,7 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             matchingLocksPos[t] = matcher->acquireWorkerMatchingLockPos();                      // :353-358
         }
         if (ncont == 0) {                                                                       // files without a record
-            if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); prev.valid = false; }
+            if (prev.valid) { matcher->emitEnd(); collect(prev, false); prev.valid = false; }
             appendsDone();
             for (uint32_t t = B.t0; t < B.t1; t++) {
                 const size_t startPos = matcher->getLoadedRefLength();
@@ -758,91 +677,166 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
             }
             continue;
         }
-        std::vector<uint64_t> locks(ncont), tlocks(T), un, counts;
-        std::vector<int> factors(ncont);
-        std::vector<int64_t> processed(ncont, processedTargetsCount), tidx(ncont);
+        // The batch as one unit first — every target's worker against the reference as the round found it. If that first pass
+        // gives contigs up as dissimilar (:382-388), the targets that hold one are void, whole (a worker that starts its target
+        // again when its turn has come); the others keep what was found. The finalizer then takes the targets in order: a run of
+        // kept targets is loaded from what the first pass found; the stopped targets that follow each other — at most
+        // allowedTargetsOutrunForDissimilarContigs + 1 of them, a unit — are matched again with every target in front of the unit
+        // loaded (processMatches then gives nothing up, ENC.cpp:203) — and a unit is a round of the pipeline below like any
+        // other: its loads queued behind its first pass, its streams taken while the next unit is matched. (Until round 4 a
+        // stopped target was matched again in blocking calls, and every later target with it: tests/_driver.py tells that story.)
+        const uint32_t unitTargets = (uint32_t) std::max(0, emitParams().allowedTargetsOutrunForDissimilarContigs) + 1;
+        std::vector<uint64_t> un, counts;
+        // targets [u0, u1) of the batch as one round of the pipeline; false: its first pass gave a contig up (nothing was loaded)
+        auto runUnit = [&](uint32_t u0, uint32_t u1) -> bool {
+            const uint32_t Tu = u1 - u0;
+            size_t c0 = 0, c1;
+            while (c0 < ncont && B.targetOf[c0] < u0) c0++;
+            for (c1 = c0; c1 < ncont && B.targetOf[c1] < u1; c1++) {}
+            const size_t nc = c1 - c0;
+            std::vector<uint64_t> locks(nc), tlocks(Tu), offs(nc + 1);
+            std::vector<int> factors(nc);
+            std::vector<int64_t> processed(nc, processedTargetsCount), tidx(nc);
+            for (size_t c = c0; c < c1; c++) {
+                const uint32_t t = B.t0 + B.targetOf[c];
+                locks[c - c0] = matchingLocksPos[t]; factors[c - c0] = unmatchedFractionFactors[2 * t]; tidx[c - c0] = t;
+                offs[c - c0] = B.offsets[c] - B.offsets[c0];
+            }
+            offs[nc] = B.offsets[c1] - B.offsets[c0];
+            for (uint32_t t = 0; t < Tu; t++) tlocks[t] = matchingLocksPos[B.t0 + u0 + t];
+            // span of every target's contigs in the buffer (they follow each other)
+            std::vector<uint64_t> tBeg(Tu, 0), tEnd(Tu, 0);
+            std::vector<char> tHas(Tu, 0);
+            for (size_t c = c0; c < c1; c++) {
+                const uint32_t lt = B.targetOf[c] - u0;
+                if (!tHas[lt]) { tBeg[lt] = B.offsets[c]; tHas[lt] = 1; }
+                tEnd[lt] = B.offsets[c + 1];
+            }
+            const double tm0 = nowSeconds();
+            matcher->matchRoundBegin(B.seqDev + B.offsets[c0], offs, params->k, locks);         // :379
+            g_tMatch += nowSeconds() - tm0;
+            // the unit's finalize under the prediction "every contig decides as the last round's did"
+            std::vector<const uint8_t *> extDev(Tu, nullptr);
+            std::vector<uint64_t> extLen(Tu, 0), loadedAfter(Tu, 0);
+            std::vector<uint8_t> predExt(nc, predicted == 1), predRC(nc, 0);
+            swsem_spec_finalize_t spec = {};
+            const bool useSpec = predicted >= 0 && !params->verifyEmissions;   // (verifying: the round's loads wait for the check)
+            if (useSpec) {
+                if (predicted == 1)
+                    for (uint32_t t = 0; t < Tu; t++)
+                        if (tHas[t] && tEnd[t] > tBeg[t]) { extDev[t] = B.seqDev + tBeg[t]; extLen[t] = tEnd[t] - tBeg[t]; }
+                spec.ntargets = (int) Tu; spec.ext_dev = extDev.data(); spec.ext_len = extLen.data();
+                spec.addSep = params->refRegionSeparators; spec.sep = REF_REGION_SEPARATOR; spec.lazySeparator = lazyMode();
+                spec.lockPos = tlocks.data(); spec.loadedAfter = loadedAfter.data();
+                spec.predExt = predExt.data(); spec.predRC = predRC.data();
+                spec.factor = params->currentUnmatchedFractionFactor; spec.rcFactor = params->rcInReference ? params->unmatchedFractionRCFactor : 0;
+            }
+            const size_t before = matcher->getLoadedRefLength();
+            const double ta0 = nowSeconds();
+            appendsDone();                                                  // (this emission's slot is the one those views point into)
+            const double te0 = nowSeconds();
+            g_tAppendWait += te0 - ta0;
+            const bool applied = matcher->emitRoundBegin(emitParams(), locks, factors, processed, tidx, loadedPositions(),
+                                                         useSpec ? &spec : nullptr, un, counts);   // :381
+            g_tEmit += nowSeconds() - te0;
+            for (size_t c = 0; c < nc; c++)
+                if (un[c] == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) return false;   // (nothing was applied: the library checks the same condition)
+            for (size_t c = 0; c < nc; c++) resCount += counts[c];
+            if (params->verifyEmissions && (Tu != T || (B.t0 / std::max<uint32_t>(1, T)) % (uint32_t) std::max(1, params->verifyEvery) == 0))
+                verifyEmission(nc, offs[nc]);
+            // extension policy, :389-398
+            std::vector<char> ext(ncont, 0), rc(ncont, 0);
+            bool allExt = true, noneExt = true, anyRC = false;
+            for (size_t c = c0; c < c1; c++) {
+                const uint32_t t = B.t0 + B.targetOf[c];
+                const size_t len = B.offsets[c + 1] - B.offsets[c];
+                ext[c] = params->isContigProperForRefExtension(len, un[c - c0], unmatchedFractionFactors[2 * t]);
+                rc[c] = params->rcInReference && params->isContigProperForRefRCExtension(len, un[c - c0], params->unmatchedFractionRCFactor);
+                allExt &= (bool) ext[c]; noneExt &= !ext[c]; anyRC |= (bool) rc[c];
+            }
+            if (!applied) {
+                extensionStrings(B, ext, rc, u0, u1, extDev, extLen);
+                const double tf0 = nowSeconds();
+                matcher->finalizeTargets(extDev, extLen, params->refRegionSeparators, REF_REGION_SEPARATOR, lazyMode(), tlocks, loadedAfter);   // :440-457
+                g_tFinalize += nowSeconds() - tf0;
+            }
+            size_t startPos = before;
+            for (uint32_t t = 0; t < Tu; t++) {
+                noteTargetLoaded(B.t0 + u0 + t, startPos, loadedAfter[t]);                      // ENC.cpp:557-563
+                startPos = loadedAfter[t];
+            }
+            processedTargetsCount = B.t0 + u1;
+            // the previous unit's streams: its second phase ran beside everything above
+            if (prev.valid) collect(prev, true);
+            prev = Deferred();
+            prev.valid = true; prev.B = &B; prev.u0 = u0; prev.u1 = u1; prev.c0 = c0; prev.c1 = c1;
+            predicted = (!anyRC && (allExt || noneExt)) ? (allExt ? 1 : 0) : -1;
+            return true;
+        };
+        if (runUnit(0, T)) continue;
+        // ---- the first pass gave contigs up
+        std::vector<char> stopped(T, 0);
+        for (size_t c = 0; c < ncont; c++)
+            if (un[c] == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) stopped[B.targetOf[c]] = 1;
+        if (prev.valid) { collect(prev, true); prev.valid = false; }
+        appendsDone();
+        matcher->emitEnd();
+        predicted = -1;
+        if (params->verifyEmissions) verifyEmission(ncont, B.offsets[ncont] - B.offsets[0]);
+        // what the kept targets' workers found: decisions now, streams to the host (the units take the emission's buffers over)
+        const std::vector<uint64_t> un1 = un, counts1 = counts;
+        std::vector<EmittedStreams> held(ncont);
+        g_retryPasses++;
         for (size_t c = 0; c < ncont; c++) {
-            const uint32_t t = B.t0 + B.targetOf[c];
-            locks[c] = matchingLocksPos[t]; factors[c] = unmatchedFractionFactors[2 * t]; tidx[c] = t;
+            if (stopped[B.targetOf[c]]) { g_retryContigs++; continue; }
+            resCount += counts1[c];
+            if (!bench) matcher->emitTake((int) c, held[c]);
         }
-        for (uint32_t t = 0; t < T; t++) tlocks[t] = matchingLocksPos[B.t0 + t];
-        // span of every target's contigs in the buffer (they follow each other)
-        std::vector<uint64_t> tBeg(T, 0), tEnd(T, 0);
-        std::vector<char> tHas(T, 0);
-        for (size_t c = 0; c < ncont; c++) {
-            const uint32_t lt = B.targetOf[c];
-            if (!tHas[lt]) { tBeg[lt] = B.offsets[c]; tHas[lt] = 1; }
-            tEnd[lt] = B.offsets[c + 1];
-        }
-        const double tm0 = nowSeconds();
-        matcher->matchRoundBegin(B.seqDev, B.offsets, params->k, locks);                        // :379
-        g_tMatch += nowSeconds() - tm0;
-        // the round's finalize under the prediction "every contig decides as the last round's did"
-        std::vector<const uint8_t *> extDev(T, nullptr);
-        std::vector<uint64_t> extLen(T, 0), loadedAfter(T, 0);
-        std::vector<uint8_t> predExt(ncont, predicted == 1), predRC(ncont, 0);
-        swsem_spec_finalize_t spec = {};
-        const bool useSpec = predicted >= 0 && !params->verifyEmissions;       // (verifying: the round's loads wait for the check)
-        if (useSpec) {
-            if (predicted == 1)
-                for (uint32_t t = 0; t < T; t++)
-                    if (tHas[t] && tEnd[t] > tBeg[t]) { extDev[t] = B.seqDev + tBeg[t]; extLen[t] = tEnd[t] - tBeg[t]; }
-            spec.ntargets = (int) T; spec.ext_dev = extDev.data(); spec.ext_len = extLen.data();
-            spec.addSep = params->refRegionSeparators; spec.sep = REF_REGION_SEPARATOR; spec.lazySeparator = lazyMode();
-            spec.lockPos = tlocks.data(); spec.loadedAfter = loadedAfter.data();
-            spec.predExt = predExt.data(); spec.predRC = predRC.data();
-            spec.factor = params->currentUnmatchedFractionFactor; spec.rcFactor = params->rcInReference ? params->unmatchedFractionRCFactor : 0;
-        }
-        const size_t before = matcher->getLoadedRefLength();
-        const double ta0 = nowSeconds();
-        appendsDone();                                                      // (this emission's slot is the one those views point into)
-        const double te0 = nowSeconds();
-        g_tAppendWait += te0 - ta0;
-        const bool applied = matcher->emitRoundBegin(emitParams(), locks, factors, processed, tidx, loadedPositions(),
-                                                     useSpec ? &spec : nullptr, un, counts);   // :381
-        g_tEmit += nowSeconds() - te0;
-        bool skipped = false;
-        for (size_t c = 0; c < ncont; c++) skipped |= un[c] == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY;
-        if (skipped) {                                                      // (nothing was applied: the library checks the same condition)
-            if (prev.valid) { collect(*prev.B, true); prev.valid = false; }
-            appendsDone();
-            matcher->emitEnd();
-            predicted = -1;
-            size_t firstGivenUp = 0;
-            while (firstGivenUp < ncont && un[firstGivenUp] != PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) firstGivenUp++;
-            processRoundWithRetries(B, firstGivenUp);
-            continue;
-        }
-        for (size_t c = 0; c < ncont; c++) resCount += counts[c];
-        if (params->verifyEmissions && (B.t0 / std::max<uint32_t>(1, T)) % (uint32_t) std::max(1, params->verifyEvery) == 0) verifyEmission(ncont, B.offsets[ncont] - B.offsets[0]);
-        // extension policy, :389-398
-        std::vector<char> ext(ncont), rc(ncont);
-        bool allExt = true, noneExt = true, anyRC = false;
-        for (size_t c = 0; c < ncont; c++) {
-            const uint32_t t = B.t0 + B.targetOf[c];
-            const size_t len = B.offsets[c + 1] - B.offsets[c];
-            ext[c] = params->isContigProperForRefExtension(len, un[c], unmatchedFractionFactors[2 * t]);
-            rc[c] = params->rcInReference && params->isContigProperForRefRCExtension(len, un[c], params->unmatchedFractionRCFactor);
-            allExt &= (bool) ext[c]; noneExt &= !ext[c]; anyRC |= (bool) rc[c];
-        }
-        if (!applied) {
-            extensionStrings(B, ext, rc, 0, T, extDev, extLen);
+        uint32_t t = 0;
+        while (t < T) {
+            if (stopped[t]) {
+                uint32_t u1 = t + 1;
+                while (u1 < T && u1 - t < unitTargets && stopped[u1]) u1++;
+                if (!runUnit(t, u1)) {
+                    fprintf(stderr, "internal error: a contig was given up although every target in front of its unit had been loaded\n");
+                    exit(EXIT_FAILURE);
+                }
+                t = u1;
+                continue;
+            }
+            uint32_t t2 = t + 1;
+            while (t2 < T && !stopped[t2]) t2++;
+            // targets [t, t2) keep the first pass: their extensions in one call (:433-468), their streams behind the unit in flight
+            std::vector<char> ext(ncont, 0), rc(ncont, 0);
+            auto tail = std::make_shared<HeldTargets>(t2 - t);
+            for (size_t c = 0; c < ncont; c++) {
+                const uint32_t lt = B.targetOf[c];
+                if (lt < t || lt >= t2) continue;
+                const size_t len = B.offsets[c + 1] - B.offsets[c];
+                ext[c] = params->isContigProperForRefExtension(len, un1[c], unmatchedFractionFactors[2 * (B.t0 + lt)]);         // :389-392
+                rc[c] = params->rcInReference && params->isContigProperForRefRCExtension(len, un1[c], params->unmatchedFractionRCFactor);
+                (*tail)[lt - t].push_back(std::move(held[c]));
+            }
+            std::vector<const uint8_t *> extDev;
+            std::vector<uint64_t> extLen, loadedAfter, tlocks;
+            extensionStrings(B, ext, rc, t, t2, extDev, extLen);
+            for (uint32_t x = t; x < t2; x++) tlocks.push_back(matchingLocksPos[B.t0 + x]);
+            size_t startPos = matcher->getLoadedRefLength();
             const double tf0 = nowSeconds();
             matcher->finalizeTargets(extDev, extLen, params->refRegionSeparators, REF_REGION_SEPARATOR, lazyMode(), tlocks, loadedAfter);   // :440-457
             g_tFinalize += nowSeconds() - tf0;
+            for (uint32_t x = t; x < t2; x++) {
+                noteTargetLoaded(B.t0 + x, startPos, loadedAfter[x - t]);                       // ENC.cpp:557-563
+                startPos = loadedAfter[x - t];
+            }
+            processedTargetsCount = B.t0 + t2;
+            if (bench) {}                                                   // (bench: nobody takes the bytes)
+            else if (prev.valid) prev.tail = tail;                          // (a unit is never followed by two kept runs)
+            else { appendsDone(); appendHeldTargets(*tail); }
+            t = t2;
         }
-        size_t startPos = before;
-        for (uint32_t t = 0; t < T; t++) {
-            noteTargetLoaded(B.t0 + t, startPos, loadedAfter[t]);                               // ENC.cpp:557-563
-            startPos = loadedAfter[t];
-        }
-        processedTargetsCount = B.t1;
-        // the previous round's streams: its second phase ran beside everything above
-        if (prev.valid) collect(*prev.B, true);
-        prev.valid = true; prev.B = &B;
-        predicted = (!anyRC && (allExt || noneExt)) ? (allExt ? 1 : 0) : -1;
     }
-    if (prev.valid) { matcher->emitEnd(); collect(*prev.B, false); }
+    if (prev.valid) { matcher->emitEnd(); collect(prev, false); }
     appendsDone();
     matcher->synchronize();
     if (bench) {

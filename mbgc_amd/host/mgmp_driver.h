@@ -104,7 +104,7 @@ protected:
     void processTargetsWithParallelIO();                                                // :232-313  (-t1)
     void processTargetsRounds();                                                        // :340-468 as deterministic rounds
     void verifyEmission(size_t contigs, size_t bases);                                  // --verify: the selected emission through the device decoder, exit on a contig that does not come back
-    void processRoundWithRetries(RoundBatch &B, size_t expectTaken = SIZE_MAX);                                        // a round holding a dissimilar contig (:382-388), blocking calls
+    void appendHeldTargets(std::vector<std::vector<EmittedStreams>> &targets);       // streams of targets that kept a round's first pass (:382-388), in target order
     void processTargetsRoundsSharded();                                                 // the rounds with their targets sharded over the ranks of params->exchange (mgmp_sharded.cpp)
     // input stage (MGMP.cpp:7-35,349-372 on the device parser)
     mbgc_fasta_t *fasta = nullptr;

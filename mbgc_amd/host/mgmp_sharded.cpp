@@ -12,13 +12,15 @@
 // of ALL the round's targets. No host round trip between pass 1 and the finalize. The streams of a round are gathered
 // one round later, like the single-GPU loop collects them. Otherwise (first rounds, reverse-complement extensions,
 // contigs given up as dissimilar): the decisions are exchanged after pass 1, the extension strings after that, and a
-// round with a given-up contig is redone from that contig on, on every rank, as processRoundWithRetries does.
+// round whose first pass gave a contig up goes on, from the first such target, in units of
+// allowedTargetsOutrunForDissimilarContigs + 1 targets matched with every earlier target loaded — as processTargetsRounds does.
 #include "mgmp_driver.h"
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <time.h>
 
 namespace {
@@ -314,12 +316,13 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
         auto J = [&](size_t c) { return (uint32_t) (B.t0 - base) + B.targetOf[c]; };       // position of contig c's target in the round
         uint32_t finalized = 0;
         bool firstPass = true, onDevice = ncont > 0, everyWhole = true, retried = false;
+        std::map<uint32_t, int> cutOf;                      // local targets still to be matched again (-> their first contig)
+        std::vector<char> stoppedAll;                       // the round's targets that gave a contig up in the first pass
         while (true) {
-            int cut = (int) ncont;                          // first contig of this rank that was given up
             if (!pending.empty()) {
                 std::vector<EmittedStreams> out;
                 if (!firstPass) {
-                    const int c0 = pending.front();         // (contigs from the first pending one on are consecutive in the buffer)
+                    const int c0 = pending.front();         // (the rest of one target: consecutive in the buffer)
                     std::vector<uint64_t> offs, lk;
                     std::vector<int> fa;
                     std::vector<int64_t> pr, ti;
@@ -333,17 +336,43 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
                     un.assign(pending.size(), 0);
                     for (size_t k = 0; k < pending.size(); k++) un[k] = out[k].unmatchedChars;
                 }
+                // contigs given up as dissimilar (:382-388): only the first pass over the whole round meets them
+                std::map<uint32_t, int> fresh;
+                for (size_t k = 0; k < pending.size(); k++)
+                    if (un[k] == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) fresh.emplace(B.targetOf[pending[k]], pending[k]);
+                if (!firstPass && !fresh.empty()) { fprintf(stderr, "internal error: a contig was given up although every target in front of its unit had been loaded\n"); exit(EXIT_FAILURE); }
                 for (size_t k = 0; k < pending.size(); k++) {
                     const int c = pending[k];
-                    if (un[k] == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) { cut = std::min(cut, c); continue; }   // :382-388
+                    if (un[k] == PROCESSING_MATCHES_SKIPPED_DUE_TO_CONTIG_DISSIMILARITY) continue;
                     unmatched[c] = un[k]; cnt[c] = counts[k];
                     if (!firstPass) hostStreams[c] = std::move(out[k]);
                 }
+                cutOf.insert(fresh.begin(), fresh.end());
             }
-            std::vector<int64_t> all;
-            gatherInts({cut < (int) ncont ? (int64_t) J(cut) : (int64_t) ntot}, all);
-            uint32_t firstSkip = ntot;                      // the first target (in target order) holding a given-up contig cuts the round
-            for (uint32_t r = 0; r < N; r++) firstSkip = std::min<uint32_t>(firstSkip, (uint32_t) all[r]);
+            // the first target (in target order) still to be matched (again): the finalizer gets that far. (The first pass also
+            // tells which of the round's targets gave a contig up: R flags per rank.)
+            int64_t mineSkip = ntot;
+            for (const auto &kv : cutOf) mineSkip = std::min<int64_t>(mineSkip, (int64_t) (B.t0 - base) + kv.first);
+            std::vector<int64_t> mine(1, mineSkip), all;
+            if (firstPass)
+                for (uint32_t lt = 0; lt < R; lt++) mine.push_back(cutOf.count(lt) ? 1 : 0);
+            gatherInts(mine, all);
+            const size_t per = mine.size();
+            uint32_t firstSkip = ntot;
+            for (uint32_t r = 0; r < N; r++) firstSkip = std::min<uint32_t>(firstSkip, (uint32_t) all[r * per]);
+            if (firstPass && firstSkip < ntot) {
+                // the first pass met dissimilar contigs: the targets that hold one are void, whole (a worker that starts its target
+                // again when its turn has come); the others keep what was found. The finalizer takes the targets in order; the
+                // stopped targets that follow each other — at most allowedTargetsOutrunForDissimilarContigs + 1, a unit — are
+                // matched again with every target in front of the unit loaded (processMatches then gives nothing up, ENC.cpp:203)
+                // and loaded before the finalizer goes on: the schedule of processTargetsRounds and tests/_driver.py, so that N
+                // ranks write what one GPU writes.
+                stoppedAll.assign(ntot, 0);
+                for (uint32_t j = 0; j < ntot; j++) stoppedAll[j] = all[(j / R) * per + 1 + j % R] != 0;
+                cutOf.clear();
+                for (size_t c = 0; c < ncont; c++)
+                    if (stoppedAll[J(c)]) { unmatched[c] = SIZE_MAX; cnt[c] = 0; cutOf.emplace(B.targetOf[c], (int) c); }
+            }
             if (firstSkip < ntot && !retried) {
                 // a retry follows: its emissions take over the buffers — the streams still on the device are taken now, and
                 // the round before this one is collected first (by every rank: it holds collectives)
@@ -356,12 +385,19 @@ void MultipleGenomeMatchingProcessor::processTargetsRoundsSharded() {
                     onDevice = false;
                 }
             }
-            // everything the sequential schedule would do after the given-up contig is redone against the extended
-            // reference: the rest of its target and every later target of the round
-            const int cutAt = (cut < (int) ncont && J(cut) == firstSkip) ? cut : (int) ncont;
+            // the next unit: this rank's share of it
             std::vector<int> redo;
-            for (size_t c = 0; c < ncont; c++)
-                if (J(c) > firstSkip || (J(c) == firstSkip && (int) c >= cutAt)) redo.push_back((int) c);
+            if (firstSkip < ntot) {
+                const uint32_t unit = (uint32_t) std::max(0, emitParams().allowedTargetsOutrunForDissimilarContigs) + 1;
+                uint32_t end = firstSkip + 1;
+                while (end < ntot && end - firstSkip < unit && stoppedAll[end]) end++;
+                for (uint32_t j = firstSkip; j < end; j++) {
+                    if (j / R != g || !cutOf.count(j % R)) continue;
+                    for (size_t c = 0; c < ncont; c++)
+                        if (B.targetOf[c] == j % R) redo.push_back((int) c);
+                    cutOf.erase(j % R);
+                }
+            }
             // targets [finalized, firstSkip) are complete on every rank: their extension strings (contig, then its reverse
             // complement, :389-398) are exchanged and loaded in target order by every replica (:433-468)
             if (firstSkip > finalized) {

@@ -1,5 +1,8 @@
 #include "sw_matcher.h"
 
+#include <atomic>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -58,12 +61,23 @@ void SlidingWindowSparseEMMatcher::matchTexts(std::vector<TextMatch> &res, const
         fprintf(stderr, "Source as destination and reverse-complement matching modes unsupported\n\n");
         exit(EXIT_FAILURE);
     }
+    // The handle serves one matchTexts / processMatches pair at a time (the rows stay on it between the two calls). A second
+    // thread inside matchTexts — the reference's default schedule on this class (MGMP.cpp:520-555) — would launch on the same
+    // buffers: refused before it touches the device, without the exit handlers (the first thread is inside the HIP runtime).
+    static std::atomic<int> inside(0);
+    if (inside.fetch_add(1) != 0) {
+        fprintf(stderr, "mbgc (HIP matcher): the device matcher serves one matchTexts/processMatches pair at a time: run the sequential "
+                        "schedule (-t1), or the round schedule of mbgc-hip\n");
+        fflush(stderr);
+        _exit(EXIT_FAILURE);
+    }
     res.clear();                                // .cpp:484
     const swsem_match_t *m = nullptr;
     uint64_t n = 0;
     check(swsem_match(h, (const uint8_t *) destText, destLen, minMatchLength, matchingLockPos, &m, &n), "matchTexts");
     res.reserve(n);
     for (uint64_t i = 0; i < n; i++) res.emplace_back(m[i].posSrcText, m[i].length, m[i].posDestText);
+    inside.fetch_sub(1);
 }
 
 static void take(const swsem_streams_t &st, EmittedStreams &out) {

@@ -354,7 +354,11 @@ class RoundRunner:
         emitted_here = False                        # an emission of THIS round has been begun (the deferred one is then "previous")
         ext_done = {}
         first_pass = True                           # rank-invariant: every rank is in its first pass over the whole round
+        first_pass_local = True
         spec_applied = False
+        cuts = {}                                   # local targets still to be matched again (-> their first contig)
+        stopped_all = set()                         # the round's targets (global index) that gave a contig up in the first pass
+        any_cut = False
         while True:
             if pending:
                 t0 = time.perf_counter() if tr is not None else 0
@@ -410,52 +414,85 @@ class RoundRunner:
                 self._keep.clear()              # the waits above cover every copy queued by earlier finalize calls
                 for k, c in enumerate(pending):
                     counts[c] = cnt[k]
-                skipped_local = [c for k, c in enumerate(pending) if int(un[k]) == SKIPPED]
-                good = [(k, c) for k, c in enumerate(pending) if int(un[k]) != SKIPPED]
-                for k, c in good:
-                    unmatched[c] = int(un[k])
-                last = ([k for k, _ in good], [c for _, c in good], len(pending)) if self.p is not None and good else None
+                # contigs given up as dissimilar (MGMP.cpp:382-388): only the first pass over the whole round meets them — the
+                # round then goes on in units whose workers start with every earlier target loaded (see below)
+                new_cuts = {}
+                for k, c in enumerate(pending):
+                    if int(un[k]) == SKIPPED:
+                        new_cuts.setdefault(targets[c], c)
+                assert first_pass_local or not new_cuts, "a contig was given up although every target in front of its unit had been loaded"
+                for k, c in enumerate(pending):
+                    if int(un[k]) != SKIPPED:
+                        unmatched[c] = int(un[k])
+                cuts.update(new_cuts)
+                any_cut = any_cut or bool(new_cuts)
+                emitted_now = (list(pending), len(pending)) if self.p is not None else None
             else:
-                skipped_local = []
-                last = None
-            # the first target (global order) holding a dissimilar contig cuts the round (MGMP.cpp:382-388:
-            # "discard, wait until the earlier targets are loaded, retry")
-            first_skip_local = min([self.rank * T + targets[c] for c in skipped_local], default=ntot)
+                emitted_now = None
+            # the first target (global order) still to be matched (again): the finalizer gets that far
+            first_skip_local = min([self.rank * T + lt for lt in cuts], default=ntot)
             merged = None
             if self.multi and first_pass and spec_applied:
                 first_skip = ntot                   # every rank's pass 1 came out as predicted: there is nothing to tell
             elif self.multi and first_pass:
                 # first pass over the whole round: the skip index travels together with what this rank would load if
                 # nobody skips (one exchange instead of two on the path between pass 1 and the round's finalize)
-                if skipped_local:
+                if cuts:
                     pieces, whole = None, False
                 else:
                     pieces, whole = self._build_pieces(qbuf, offsets, targets, T, unmatched, 0, ntot)
                 got = self._allgather_ints([first_skip_local] + ([x[1] for x in pieces] if pieces is not None else [0] * T) +
-                                           [1 if whole else 0], fixed=True)
+                                           [1 if whole else 0] + [1 if lt in cuts else 0 for lt in range(T)], fixed=True)
                 first_skip = min(v[0] for v in got)
+                stopped_all = {r * T + lt for r, v in enumerate(got) for lt in range(T) if v[2 + T + lt]}
                 if first_skip == ntot:
-                    merged = (pieces, [v[1: 1 + T] for v in got], [v[-1] for v in got])
+                    merged = (pieces, [v[1: 1 + T] for v in got], [v[1 + T] for v in got])
             elif self.multi:
                 first_skip = min(x[0] for x in self._allgather_ints([first_skip_local], fixed=True))
             else:
                 first_skip = first_skip_local
+                if first_pass_local:
+                    stopped_all = set(cuts)
+            if first_pass_local and first_skip < ntot:
+                # the first pass met dissimilar contigs: the targets that hold one are void, whole (a worker that starts its
+                # target again when its turn has come); the others keep what was found. The finalizer takes the targets in order;
+                # the stopped targets that follow each other — at most allowedTargetsOutrunForDissimilarContigs + 1, a unit — are
+                # matched again with every target in front of the unit loaded (processMatches then gives nothing up,
+                # MBGC_Encoder.cpp:203) and loaded before the finalizer goes on.
+                cuts = {}
+                for c in range(ncont):
+                    if self.rank * T + targets[c] in stopped_all:
+                        unmatched[c] = None
+                        counts[c] = 0
+                        cuts.setdefault(targets[c], c)
+            first_pass_local = False
             first_pass = False
             upto = first_skip                       # targets [finalized, upto) are complete on every rank
+            last = None
+            if emitted_now is not None:
+                kept = [(k, c) for k, c in enumerate(emitted_now[0]) if unmatched[c] is not None]
+                if kept:
+                    last = ([k for k, _ in kept], [c for _, c in kept], emitted_now[1])
             if last is not None and first_skip < ntot:
-                packs.append(self._pack(*last))     # a retry follows: it reuses the emission's buffers, take the streams now
+                packs.append(self._pack(*last))     # another pass follows: it reuses the emission's buffers, take the streams now
                 last = None
-            # everything the sequential schedule would do AFTER the skipping contig is redone against the
-            # extended reference: the rest of that target and all later targets of the round
-            cut = min([c for c in skipped_local if self.rank * T + targets[c] == first_skip], default=ncont)
-            redo = [c for c in range(ncont) if self.rank * T + targets[c] > first_skip or
-                    (self.rank * T + targets[c] == first_skip and c >= cut)]
+            redo = []
+            if first_skip < ntot:
+                unit = (self.p.allowedTargetsOutrunForDissimilarContigs if self.p is not None else 0) + 1
+                run = [first_skip]
+                while len(run) < unit and run[-1] + 1 in stopped_all:
+                    run.append(run[-1] + 1)
+                for j in run:
+                    lt = j - self.rank * T
+                    if j // T == self.rank and lt in cuts:
+                        redo += [c for c in range(ncont) if targets[c] == lt]
+                        del cuts[lt]
             if pending and spec_applied:            # (implies: no skip, the whole round) only the bookkeeping is left
                 self._note_finalized(locks, after, before)
             else:
                 self._finalize_range(qbuf, offsets, targets, T, locks, unmatched, finalized, upto, ext_done, merged=merged)
             finalized = upto
-            self._learn(offsets, unmatched, skipped_local)
+            self._learn(offsets, unmatched, any_cut)
             # the previous round's streams: the second phase of its emission ran beside everything above (two
             # emissions may be in flight) and is collected only now, with this round's finalize already queued
             if self._deferred is not None:
@@ -465,7 +502,7 @@ class RoundRunner:
                     tr["flush"] = tr.get("flush", 0) + time.perf_counter() - t0
             if finalized >= ntot:
                 break
-            # retry: the skipping contig itself, and every contig of the targets after it
+            # the next unit
             pending = sorted(redo)
             for c in pending:
                 unmatched[c] = None

@@ -23,5 +23,6 @@ lines[first - 1: last] = new
 # the C ABI's declarations for the replacement body
 inc = next(i for i, l in enumerate(lines) if l.startswith("#include"))
 lines.insert(inc, '#include "mbgc_swsem.h"')
+lines.insert(inc, '#include <unistd.h>')                       # (_exit in the refusal of the parallel schedule)
 open(enc, "w").write("\n".join(lines))
 print("applied: matcher header replaced, MBGC_Encoder.cpp:%d-%d -> %d lines" % (first, last, len(new)))

@@ -28,7 +28,10 @@ for i in range(n):
 with open(os.path.join(d, "list.txt"), "w") as f:
     f.write("\n".join(paths) + "\n")
 out = {}
-for name, args in (("m3", ["-m", "3"]), ("m1_rounds", []), ("m1_t1", ["-t1"])):
+runs = [("m3", ["-m", "3"]), ("m1_rounds", []), ("m1_t1", ["-t1"])]
+if os.environ.get("MBGC_MIX_RUNS"):                  # e.g. "R2:-R 2,R4:-R 4": other command lines instead of the three above
+    runs = [(x.split(":")[0], x.split(":")[1].split()) for x in os.environ["MBGC_MIX_RUNS"].split(",")]
+for name, args in runs:
     t0 = time.time()
     r = subprocess.run([os.path.join(ROOT, "mbgc_amd", "mbgc-hip"), "c"] + args + [os.path.join(d, "list.txt"), os.path.join(d, "out")],
                        capture_output=True, text=True, env=dict(os.environ, MBGC_HIP_TIMES="1"))

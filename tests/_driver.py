@@ -53,6 +53,7 @@ class Policy:
     def __init__(self, mode=1):
         self.factor = 128
         self.rc_factor = 128 if mode >= 2 else 8
+        self.outrun = {0: 4, 2: 0}.get(mode, 1)                        # allowedTargetsOutrunForDissimilarContigs, MGMP_Params.h:58-62
         self.lazy = True
 
     def proper_for_ext(self, n, unmatched): return unmatched * self.factor > n
@@ -91,10 +92,20 @@ def encode_rounds(matcher, make_emitter, g0, targets, round_size, policy=None, l
                   keep_matches=True):
     """g0: list of contigs of the first file (reference only). targets: list of lists of contigs.
     make_emitter() -> fresh per-target emitter. Returns per-target streams merged in target order.
-    threads > 1: the targets of a round are matched + emitted by a thread pool first (the reference is frozen during a
-    round and the backends release the GIL: same results, the wall time of a full-size run divided by the cores); a
-    round in which some contig is skipped as dissimilar is redone by the sequential loop below, which alone defines
-    the schedule. keep_matches=False drops the match rows of finished targets (a 1000-genome run holds 48 M of them)."""
+
+    The schedule (one admissible run of the reference's parallel mode, MGMP.cpp:340-468, made deterministic): the targets of a
+    round take their lock positions together (:353-358); every target's worker then runs against the reference as the round
+    found it — contig after contig, until it meets a contig that processMatches gives up as dissimilar (:382-388), where it
+    stops. The finalizer then takes the targets in order (:433-468): a target whose worker got through keeps what it found; the
+    stopped targets that follow each other — at most allowedTargetsOutrunForDissimilarContigs + 1 of them, a UNIT — are matched
+    again, whole, when every target in front of the unit is loaded (processMatches then gives nothing up, MBGC_Encoder.cpp:203),
+    and loaded before the finalizer goes on. (The reference's stopped workers wait for exactly that, :385-386; that they start
+    their target again instead of going on behind the given-up contig is the run in which they had started late. Rounds 1-3 of
+    this repo re-matched every LATER target of the round as well, stopped or not: on collections of unrelated species, where
+    most targets hold a dissimilar contig, a pass over the rest of the round per stopped target.)
+    threads > 1: the run-ahead part of a round goes to a thread pool (the reference is frozen meanwhile and the backends
+    release the GIL: same results). keep_matches=False drops the match rows of finished targets (a 1000-genome run holds
+    48 M of them)."""
     pol = policy or Policy()
     matcher.set_sliding_window_size(sw_factor)                         # MGMP.cpp:179-180
     g0cat = np.concatenate(g0)
@@ -127,52 +138,61 @@ def encode_rounds(matcher, make_emitter, g0, targets, round_size, policy=None, l
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(threads)
 
-    def ahead(t, processed, loaded_now):                               # one target against the frozen reference
-        em, out = make_emitter(), []
-        for contig in targets[t]:
+    def worker(t, em, processed, loaded_now):                          # target t's contigs, until one is given up
+        out = []
+        for ci in range(len(targets[t])):
+            contig = targets[t][ci]
             m = matcher.match(contig, 32, lock[t])
-            out.append((m, em.process(m, contig, lock[t], pol.factor, processed, t, loaded_now)))
-            em.put(0, bytes([SEQ_SEPARATOR]))
-        em.put(5, bytes([FILE_SEPARATOR]))
-        return em, out
+            unmatched = em.process(m, contig, lock[t], pol.factor, processed, t, loaded_now)
+            if unmatched == SKIPPED:
+                return out, ci
+            out.append((m, unmatched))
+            em.put(0, bytes([SEQ_SEPARATOR]))                          # processAfterSequence
+        em.put(5, bytes([FILE_SEPARATOR]))                             # processAfterTarget
+        return out, None
 
+    def run_workers(ts):                                               # against the reference as it is now
+        p0, l0 = state["processed"], list(loaded)
+        run = (lambda t: worker(t, ems[t], p0, l0))
+        return dict(zip(ts, pool.map(run, ts) if pool is not None else map(run, ts)))
+
+    def decide(t, out):                                                # the extension policy, :389-398
+        for (m, unmatched), contig in zip(out, targets[t]):
+            all_matches.append(m if keep_matches else len(m))
+            unm.append(unmatched)
+            if pol.proper_for_ext(contig.size, unmatched):
+                exts[t].append(("fw", contig))
+            if pol.proper_for_rc_ext(contig.size, unmatched):
+                exts[t].append(("rc", contig))
+
+    unit = getattr(pol, "outrun", 1) + 1
     for r0 in range(0, len(targets), round_size):
         rnd = list(range(r0, min(r0 + round_size, len(targets))))
         for t in rnd:
             lock[t] = matcher.acquire_lock()                           # :353-358, same pos1 for the round
-        pre = None
-        if pool is not None:
-            got = list(pool.map(lambda t: ahead(t, state["processed"], list(loaded)), rnd))
-            if all(u != SKIPPED for _, out in got for _, u in out):
-                pre = dict(zip(rnd, got))
-        for t in rnd:
-            ems[t], exts[t] = (pre[t][0] if pre else make_emitter()), []
-            for ci, contig in enumerate(targets[t]):
-                while True:
-                    if pre:
-                        m, unmatched = pre[t][1][ci]
-                        break
-                    m = matcher.match(contig, 32, lock[t])
-                    unmatched = ems[t].process(m, contig, lock[t], pol.factor, state["processed"], t, loaded)
-                    if unmatched != SKIPPED:
-                        break
-                    # :382-388 "dissimilar contig: discard, wait for the earlier targets, retry" —
-                    # the deterministic form: load every earlier target's extension now, then retry
-                    # with the lock position this target already holds.
-                    while state["processed"] < t:
-                        finalize(state["processed"])
-                all_matches.append(m if keep_matches else len(m))
-                unm.append(unmatched)
-                if pol.proper_for_ext(contig.size, unmatched):
-                    exts[t].append(("fw", contig))
-                if pol.proper_for_rc_ext(contig.size, unmatched):
-                    exts[t].append(("rc", contig))
-                if not pre:
-                    ems[t].put(0, bytes([SEQ_SEPARATOR]))
-            if not pre:
-                ems[t].put(5, bytes([FILE_SEPARATOR]))
-        while state["processed"] <= rnd[-1]:
-            finalize(state["processed"])
+            ems[t], exts[t] = make_emitter(), []
+        got = run_workers(rnd)
+        stopped = {t for t in rnd if got[t][1] is not None}
+        t = rnd[0]
+        while t <= rnd[-1]:
+            if t not in stopped:
+                decide(t, got[t][0])
+                finalize(t)
+                t += 1
+                continue
+            ts = [t]
+            while len(ts) < unit and ts[-1] + 1 in stopped:
+                ts.append(ts[-1] + 1)
+            for u in ts:
+                # (what the first pass put there is void; an emitter bound to its target — the reference's — is reset)
+                ems[u], exts[u] = (ems[u].reset() if hasattr(ems[u], "reset") else make_emitter()), []
+            again = run_workers(ts)
+            for u in ts:
+                assert again[u][1] is None, "a contig was given up although every target in front of its unit had been loaded"
+                decide(u, again[u][0])
+            for u in ts:
+                finalize(u)
+            t = ts[-1] + 1
         if not keep_matches:
             for t in rnd:
                 ems.pop(t, None), exts.pop(t, None)

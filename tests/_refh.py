@@ -57,6 +57,7 @@ def lib():
         L.refe_process_matches.argtypes = [vp, vp, u64, vp, u64, ci, u64]
         L.refe_after_sequence.argtypes = [vp, ci]
         L.refe_after_target.argtypes = [vp, ci]
+        L.refe_reset_target.argtypes = [vp, ci]
         L.refe_stream.restype = u64
         L.refe_stream.argtypes = [vp, ci, ci, vp, u64]
         _lib = L
@@ -137,6 +138,7 @@ class RefEmitter:
 
     def after_sequence(self, t=0): lib().refe_after_sequence(self.h, t)
     def after_target(self, t=0): lib().refe_after_target(self.h, t)
+    def reset_target(self, t=0): lib().refe_reset_target(self.h, t)
 
     def stream(self, which, target=0):
         n = lib().refe_stream(self.h, target, which, None, 0)

@@ -37,6 +37,9 @@ CASES = {
     # REF_SHIFT. One more field: k1. Sequential, and rounds on a buffer that wraps several times.
     "seq_k15": (6, 60_000, 0.012, 107, 0, 2, 0, 1, 0, 0, 15),
     "rounds3_wrap_k9": (12, 50_000, 0.015, 108, 380_000, 2, 3, 1, 0, 0, 9),
+    # divergence -1: every third genome 7 % from the rest, the others 0.4 % — rounds of 6 in which the fifth target gives a contig
+    # up as dissimilar (MGMP.cpp:382-388) and the sixth, behind it, does not (it keeps what its worker found running ahead)
+    "rounds6_mixed": (13, 40_000, -1, 109, 2_000_000, 2, 6, 1),
 }
 
 
@@ -48,7 +51,7 @@ def split(g, k):
 def inputs(case):
     n, length, div, seed, lim, cpt, rs, mode = CASES[case][:8]
     base = synth.base_codes(length, seed)
-    gs = [synth.genome(base, i, div) for i in range(n)]
+    gs = [synth.genome(base, i, div if div >= 0 else (0.07 if i % 3 == 2 else 0.004)) for i in range(n)]
     if not lim:
         lim, _ = _driver.ref_length_limit(n, length)
     return gs, lim, cpt, rs, mode
@@ -102,6 +105,7 @@ def run_reference(case):
                 def process(s, *a): return s.v.process(*a)
                 def put(s, which, data): ad.e.after_sequence(s.t) if which == 0 else ad.e.after_target(s.t)
                 def streams(s): return ad.e.streams(s.t)
+                def reset(s): ad.e.reset_target(s.t); return s
             return E()
         res = _driver.encode_rounds(r, make, split(gs[0], cpt), targets, rs, pol)
         streams = res["streams"]

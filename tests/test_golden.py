@@ -10,7 +10,7 @@ import _driver
 import _orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["seq_m1", "seq_m2", "rounds3_wrap", "rounds4_divergent", "seq_bit40", "rounds3_bit40", "seq_k15", "rounds3_wrap_k9"]
+CASES = ["seq_m1", "seq_m2", "rounds3_wrap", "rounds4_divergent", "seq_bit40", "rounds3_bit40", "seq_k15", "rounds3_wrap_k9", "rounds6_mixed"]
 
 
 def load(case):
@@ -22,7 +22,8 @@ def load(case):
     n, length, div, seed, lim, cpt, rs, mode = d["case"][:8]
     n, length, seed, lim, cpt, rs, mode = int(n), int(length), int(seed), int(lim), int(cpt), int(rs), int(mode)
     base = synth.base_codes(length, seed)
-    gs = [synth.genome(base, i, float(div)) for i in range(n)]
+    # (divergence -1: every third genome 7 % from the rest, the others 0.4 % — make_golden.py's rounds6_mixed)
+    gs = [synth.genome(base, i, float(div) if div >= 0 else (0.07 if i % 3 == 2 else 0.004)) for i in range(n)]
     if not lim:
         lim, _ = _driver.ref_length_limit(n, length)
     return d, gs, lim, cpt, rs, mode

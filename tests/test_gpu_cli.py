@@ -95,14 +95,19 @@ def crlf(c):
 
 
 # divergence 1.5 %: every contig extends the reference (the speculative finalize applies from the second round on);
-# 0.1 %: none does; 6 %: dissimilar contigs are given up and retried (the blocking path); "crlf": CRLF line ends; "gz": gzip files
+# 0.1 %: none does; 6 %: dissimilar contigs are given up and their targets matched again in units; "mixed": every third genome 7 %
+# from the rest, the others 0.4 % — rounds of 6 and 7 with kept targets in front of, between and behind stopped ones (units of
+# one and two targets); "crlf": CRLF line ends; "gz": gzip files
 @pytest.mark.parametrize("args,rs,div", [(["-t1"], 0, 0.015), (["-R", "3"], 3, 0.015), (["-R", "8"], 8, 0.015), (["-R", "2"], 2, 0.001),
-                                         (["-R", "3"], 3, 0.06), (["-R", "3"], 3, "crlf"), (["-t1"], 0, "crlf"), (["-R", "3"], 3, "gz"),
-                                         (["-t1"], 0, "gz")])
+                                         (["-R", "3"], 3, 0.06), (["-R", "6"], 6, "mixed"), (["-R", "7"], 7, "mixed"), (["-R", "5"], 5, 0.06),
+                                         (["-R", "3"], 3, "crlf"), (["-t1"], 0, "crlf"), (["-R", "3"], 3, "gz"), (["-t1"], 0, "gz")])
 def test_synthetic_files_equal_oracle_driver(tmp_path, args, rs, div):
     base = synth.base_codes(70_000, 55)
     cr, gz = div == "crlf", div == "gz"
-    gs = [synth.genome(base, i, 0.015 if cr or gz else div) for i in range(8)]
+    if div == "mixed":
+        gs = [synth.genome(base, i, 0.07 if i % 3 == 2 else 0.004) for i in range(16)]
+    else:
+        gs = [synth.genome(base, i, 0.015 if cr or gz else div) for i in range(8)]
     files = [split(g, 2) for g in gs]
     paths = []
     for i, contigs in enumerate(files):

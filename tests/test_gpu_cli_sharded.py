@@ -35,7 +35,8 @@ def write_collection(tmp_path, n, length, div, contigs=2, seed=61):
     for i in range(n):
         p = tmp_path / ("g%02d.fa" % i)
         with open(p, "wb") as f:
-            for j, c in enumerate(split(synth.genome(base, i, div), (1, 2, 3)[i % 3] if contigs == "ragged" else contigs)):
+            d = (0.07 if i % 3 == 2 else 0.004) if div == "mixed" else div      # "mixed": kept targets between and behind stopped ones
+            for j, c in enumerate(split(synth.genome(base, i, d), (1, 2, 3)[i % 3] if contigs == "ragged" else contigs)):
                 f.write(synth.fasta_bytes(c, i * 10 + j))
         paths.append(str(p))
     (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
@@ -49,7 +50,7 @@ def dumps(tmp_path, prefix):
 # verdicts); 1.5 %: with reverse complements; 0.1 %: none does; 6 %: contigs are given up as dissimilar and the round is redone from there on every rank;
 # 11 / 12 files: the last round is short (a rank without targets) / full
 @pytest.mark.parametrize("gpus,r,n,div,contigs", [(2, 2, 17, 0.003, 2), (2, 2, 11, 0.015, "ragged"), (2, 2, 12, 0.06, 2), (2, 3, 11, 0.001, 1),
-                                                  (3, 1, 12, 0.015, "ragged"), (3, 2, 15, 0.06, "ragged")])
+                                                  (3, 1, 12, 0.015, "ragged"), (3, 2, 15, 0.06, "ragged"), (2, 3, 14, "mixed", 2), (3, 2, 17, "mixed", "ragged")])
 def test_ranks_on_one_gpu_equal_the_single_gpu_rounds(tmp_path, gpus, r, n, div, contigs):
     write_collection(tmp_path, n, 70_000, div, contigs)
     one = run_tool(["c", "-R", str(gpus * r), "list.txt", "one"], str(tmp_path))

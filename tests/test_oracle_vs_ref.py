@@ -217,6 +217,7 @@ def test_emission_rounds_with_locks_and_wrap(refh, round_size):
             def process(s, *a): return s.v.process(*a)
             def put(s, which, data): ad.e.after_sequence(s.t) if which == 0 else ad.e.after_target(s.t)
             def streams(s): return ad.e.streams(s.t)
+            def reset(s): ad.e.reset_target(s.t); return s
         return E()
 
     a = _driver.encode_rounds(r, make_ref, g0, targets, round_size)
@@ -249,6 +250,7 @@ def test_five_laps_of_the_buffer(refh, round_size, laps):
             def process(s, *a): return s.v.process(*a)
             def put(s, which, data): ad.e.after_sequence(s.t) if which == 0 else ad.e.after_target(s.t)
             def streams(s): return ad.e.streams(s.t)
+            def reset(s): ad.e.reset_target(s.t); return s
         return E()
 
     a = _driver.encode_rounds(r, make_ref, [gs[0]], targets, round_size)
@@ -328,6 +330,7 @@ def test_the_fuzz_case_with_an_n_run_behind_a_wrap(refh):
             def process(s, *a): return s.v.process(*a)
             def put(s, which, data): ad.e.after_sequence(s.t) if which == 0 else ad.e.after_target(s.t)
             def streams(s): return ad.e.streams(s.t)
+            def reset(s): ad.e.reset_target(s.t); return s
         return E()
 
     a = _driver.encode_rounds(r, make_ref, gs[0], gs[1:], round_size)

@@ -20,6 +20,8 @@ LIM = 3_000_000
 
 def collection(n, length, div, seed):
     base = synth.base_codes(length, seed)
+    if div == "mixed":      # every third genome far from the rest: rounds of 6 hold a stopped target with kept ones behind it
+        return [synth.genome(base, i, 0.07 if i % 3 == 2 else 0.004) for i in range(n)]
     return [synth.genome(base, i, div) for i in range(n)]
 
 
@@ -80,6 +82,28 @@ def test_single_process_runner_equals_reference_loop(div, cpt):
     assert bytes(runner.locks_stream) == res["locks"]
     assert bytes(runner.ref_ext_sizes) == res["refExtSize"]
     assert m.loaded_ref_length() == loaded and np.array_equal(m.ht(), ht)
+
+
+@pytest.mark.parametrize("cpt", [1, "ragged"])
+def test_kept_targets_behind_a_stopped_one(cpt):
+    """rounds of 6 in which the fifth target gives a contig up and the sixth does not: the sixth keeps what the first pass found
+    (the reference's workers do not wait for each other's dissimilar contigs), the fifth is matched again by itself"""
+    gs = collection(13, 60_000, "mixed", seed=17)
+    runner, m = run_rank(0, 1, gs, 6, cpt)
+    res, ht, loaded = reference_result(gs, 6, cpt)
+    for k, v in res["streams"].items():
+        assert bytes(runner.streams[k]) == v, k
+    assert bytes(runner.locks_stream) == res["locks"]
+    assert bytes(runner.ref_ext_sizes) == res["refExtSize"]
+    assert m.loaded_ref_length() == loaded and np.array_equal(m.ht(), ht)
+    # (the drive itself: some target was matched twice, and some target behind it was not)
+    o = _orc.OracleMatcher(LIM)
+    calls = []
+    real = o.match
+    o.match = lambda contig, *a: (calls.append(contig.size), real(contig, *a))[1]
+    _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), [gs[0]], [split(g, _cpt(cpt, t)) for t, g in enumerate(gs[1:])], 6)
+    total = sum(len(split(g, _cpt(cpt, t))) for t, g in enumerate(gs[1:]))
+    assert total < len(calls) < 2 * total - 4, (total, len(calls))
 
 
 def _worker_n(rank, world, port, outdir, div, per_rank, announce, n, lim=LIM):
@@ -162,7 +186,8 @@ def test_world_size_2_gloo_with_announced_buffers(tmp_path, announce):
         assert (started, used) == (2, 0)
 
 
-@pytest.mark.parametrize("world,per_rank,n,div,announce", [(3, 2, 13, 0.002, 1), (4, 1, 13, 0.06, 0), (3, 1, 10, 0.012, 1)])
+@pytest.mark.parametrize("world,per_rank,n,div,announce", [(3, 2, 13, 0.002, 1), (4, 1, 13, 0.06, 0), (3, 1, 10, 0.012, 1), (2, 3, 13, "mixed", 0),
+                                                          (3, 2, 13, "mixed", 1)])
 def test_more_ranks_gloo(tmp_path, world, per_rank, n, div, announce):
     """3 and 4 ranks (rank-major target order inside a round, the veto-free speculative path with three parties, retries
     that cut a round between two ranks) == one process with rounds of world x per_rank"""
