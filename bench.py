@@ -83,7 +83,7 @@ KERNEL_OF = {"resolve": "k_resolve_blocks4", "stitch": "k_stitch_pre + k_stitch 
              "insert": "k_insert_multi", "emit": "k_emit_* (13 launches)"}
 # HBM-side bytes per launch of each kernel, from the PMC passes over THIS command (profiles/pmc_summary.py writes the
 # file from rocprofv3's FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes); absent = null
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 MIXED_GENOMES = 200                  # configs[4]'s kind of data, as many genomes as a bench line can afford (the full 10 000: profiles/configs4_run.py)
@@ -176,7 +176,7 @@ def config1_line():
         if r.returncode != 0 or not lines:
             return {"config": "configs[1]", "error": "child bench exited with %d: %s" % (r.returncode, r.stderr[-300:])}
         d = json.loads(lines[-1])
-        return {"config": "configs[1]", "workload": "configs[1]: 128 synthetic 5 Mbp genomes @99% identity, SlidingWindowSparseEMMatcher only (matchTexts + loadRef per round, no "
+        return {"config": "configs[1]", "workload": "configs[1]: 128 synthetic 5 Mbp genomes @99%% identity, SlidingWindowSparseEMMatcher only (matchTexts + loadRef per round, no "
                                                     "emission), %.4g-byte circular reference (the buffer `mbgc c` gives 129 files), rounds of 16; timed: targets 17..128" % d["config"]["max_ref_len"],
                 "metric": d["metric"], "value": d["value"], "unit": d["unit"], "extension_bytes_dropped_per_step": d.get("extension_bytes_dropped_per_step"),
                 "ms_per_step": d["ms_per_step"], "targets_per_step": d["config"]["targets_per_step"], "max_ref_len": d["config"]["max_ref_len"],

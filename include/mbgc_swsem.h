@@ -197,7 +197,9 @@ int swsem_emit_batch_end(swsem_t *h);
 /* Two emissions can be in flight: _begin only waits for the one before the previous (whose buffers it takes
  * over). swsem_emit_result / swsem_emit_pack_dev read the latest emission, or — after swsem_emit_select(h, 1) —
  * the one before it, which lets a caller begin round r+1 before it collects the streams of round r.
- * swsem_emit_batch_end waits for both. */
+ * swsem_emit_batch_end waits for both. The pointers swsem_emit_result hands out (page-locked host memory of the library) stay
+ * valid until the emission FOUR _begin calls later is taken: a caller may copy them out on a thread of its own while it
+ * begins, runs and takes the next emissions (every slot keeps two host buffers and uses them in turn). */
 int swsem_emit_select(swsem_t *h, int previous);
 int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out);
 /* Keep the streams in HBM (no host copy inside swsem_emit_batch; swsem_emit_result then copies on demand)

@@ -13,8 +13,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
+#include <sys/mman.h>
 
 #include "../../include/mbgc_fasta.h"
 
@@ -466,18 +469,47 @@ int mbgc_fasta_parse_host(mbgc_fasta_t *p, const uint8_t *file_host, uint64_t n,
     return 0;
 }
 
+// Page-locked staging memory. hipHostMalloc takes 33-37 ms for a round's 160 MB on this host (profiles/pin_bench.hip) — twice,
+// in front of the first round; memory of the process's own in 2 MB pages (madvise, where the system gives them) is registered in
+// about 1 ms once it is there, and touching it takes 10 ms instead of 27. So: mmap, ask for huge pages, register.
+namespace fa {
+static std::mutex g_hostMu;
+static std::map<void *, std::pair<void *, size_t>> g_hostMaps;      // registered pointer -> (mapping, its length)
+}
+
 int mbgc_fasta_host_alloc(mbgc_fasta_t *p, uint64_t bytes, void **out) {
     using namespace fa;
     FCHK(hipSetDevice(p->device));
     *out = nullptr;
-    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return fail(-101, "cannot pin %llu B of host memory", (unsigned long long) bytes);
+    const size_t HUGE = (size_t) 2 << 20, n = ((bytes ? bytes : 1) + HUGE - 1) & ~(HUGE - 1);
+    void *m = mmap(nullptr, n + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return fail(-101, "cannot map %llu B of host memory", (unsigned long long) bytes);
+    void *a = (void *) (((uintptr_t) m + HUGE - 1) & ~(uintptr_t) (HUGE - 1));
+    (void) madvise(a, n, MADV_HUGEPAGE);
+    if (hipHostRegister(a, n, hipHostRegisterDefault) != hipSuccess) {
+        (void) hipGetLastError();
+        munmap(m, n + HUGE);
+        return fail(-101, "cannot pin %llu B of host memory", (unsigned long long) bytes);
+    }
+    { std::lock_guard<std::mutex> g(g_hostMu); g_hostMaps[a] = std::make_pair(m, n + HUGE); }
+    *out = a;
     return 0;
 }
 
 int mbgc_fasta_host_free(mbgc_fasta_t *p, void *ptr) {
     using namespace fa;
     FCHK(hipSetDevice(p->device));
-    if (ptr) FCHK(hipHostFree(ptr));
+    if (!ptr) return 0;
+    std::pair<void *, size_t> m;
+    {
+        std::lock_guard<std::mutex> g(g_hostMu);
+        auto it = g_hostMaps.find(ptr);
+        if (it == g_hostMaps.end()) return fail(-100, "mbgc_fasta_host_free: not a pointer of mbgc_fasta_host_alloc");
+        m = it->second;
+        g_hostMaps.erase(it);
+    }
+    FCHK(hipHostUnregister(ptr));
+    munmap(m.first, m.second);
     return 0;
 }
 

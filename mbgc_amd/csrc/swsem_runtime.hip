@@ -269,8 +269,14 @@ struct swsem {
                 return 0;
             }
             void release() { if (p) (void) hipHostFree(p); p = nullptr; cap = 0; }
-        } hostStreams;
-        std::vector<uint64_t> hostStreamOff; // [k * NSTREAMS + s] offset into hostStreams
+        } hostHalf[2];
+        // Two host buffers per slot, used in turn: the views of an emission (swsem_emit_view) stay valid while the NEXT emission
+        // of the same slot is begun, runs and is taken — a caller that copies the bytes out on a thread of its own has two
+        // emissions' time for it, not the gap between taking one emission and beginning the next (mgmp_driver.cpp: the large
+        // literal and flag streams of divergent collections, 0.4 bytes per base, were waited for there).
+        int hostAt = 0;
+        PinBytes &hostStreams() { return hostHalf[hostAt]; }
+        std::vector<uint64_t> hostStreamOff; // [k * NSTREAMS + s] offset into hostStreams()
         bool hostStreamsValid = false;
         uint64_t packedBytes = 0;
         void release() {
@@ -278,7 +284,7 @@ struct swsem {
             dEPack.release(); dERm.release(); dEArena.release(); dEKeep.release(); dEMeta.release(); dECorr.release();
             dESz.release(); dEOfs.release(); dEChunk.release(); dEStates.release(); dEStat.release(); dEPm.release(); dELit.release(); dEBad.release(); dELong.release(); dELongCount.release();
             if (pinE) { (void) hipHostFree(pinE); pinE = nullptr; pinECap = 0; }
-            hostStreams.release();
+            hostHalf[0].release(); hostHalf[1].release();
             if (evDone) { (void) hipEventDestroy(evDone); evDone = nullptr; }
             if (evMetaDone) { (void) hipEventDestroy(evMetaDone); evMetaDone = nullptr; }
         }
@@ -311,6 +317,7 @@ struct swsem {
     uint32_t overlap = 1024, overlapFixed = 0, batchBlocks = 0;
     uint32_t rb = 8;                       // length of a resolve block in units of RBU positions: chosen per batch (run_batch) unless SWSEM_RB fixes it
     uint32_t rbFixed = 0;
+    uint32_t rbMin = 2048 / RBU;           // shortest resolve block (units of RBU positions); SWSEM_RB_MIN=positions for A/B runs
     uint32_t slotPercent = 95;             // share of the wave slots a launch's blocks are sized for (80 %: +5 % on the 4.35e9-byte sizing, -3 % on configs[2]'s)
     uint32_t waveSlots = 256 * 4 * RESOLVE_WAVES_PER_SIMD;   // resolve waves the device holds at once (CUs x SIMDs x waves)
     std::vector<Contig> contigs;
@@ -877,7 +884,7 @@ int run_batch(swsem *h, const uint8_t *qdev, const uint64_t *offsets, int n, uin
         h->chainsPerWave = (h->simt && !h->seqResolve && h->K <= K_MAX4) ? (uint32_t) GC : 1u;
         const uint64_t waves = h->chainsPerWave > 1 ? (uint64_t) h->waveSlots / RESOLVE_WAVES_PER_SIMD * RESOLVE4_WAVES_PER_SIMD : h->waveSlots;
         const uint64_t slots = std::max<uint64_t>(1, waves * h->chainsPerWave * h->slotPercent / 100);
-        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(65536 / RBU, std::max<uint64_t>(2048 / RBU, (allUnits + slots - 1) / slots));   // (a small batch — one target of the sequential schedule — runs short chains: it is their length that takes the time)
+        h->rb = h->rbFixed ? h->rbFixed : (uint32_t) std::min<uint64_t>(65536 / RBU, std::max<uint64_t>(h->rbMin, (allUnits + slots - 1) / slots));   // (a small batch — one target of the sequential schedule — runs short chains: it is their length that takes the time)
     }
     for (int c = 0; c < n; c++) {
         Contig &cg = h->contigs[c];
@@ -1056,8 +1063,9 @@ int end_slot(swsem *h, int si) {
     E.packedBytes = tot;
     E.hostStreamsValid = false;
     if (h->emitHostCopy) {
-        if (E.hostStreams.reserve(tot + 1)) return fail(SWSEM_ENOMEM, "cannot pin %llu B of host memory", (unsigned long long) tot);
-        if (tot) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, tot, hipMemcpyDeviceToHost, h->s3()));
+        E.hostAt ^= 1;                                                 // (the other half may still be read through the views of this slot's last emission)
+        if (E.hostStreams().reserve(tot + 1)) return fail(SWSEM_ENOMEM, "cannot pin %llu B of host memory", (unsigned long long) tot);
+        if (tot) HIPCHK(hipMemcpyAsync(E.hostStreams().data(), E.dEArena.p, tot, hipMemcpyDeviceToHost, h->s3()));
         HIPCHK(hipStreamSynchronize(h->s3()));
         E.hostStreamsValid = true;
     }
@@ -1145,6 +1153,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_META_WARM")) h->metaWarm = std::min(swk::MWARM, std::max(0, atoi(e)));
     if (const char *e = getenv("SWSEM_OVERLAP")) { int x = atoi(e); if (x >= 0 && x <= OVERLAP_MAX) h->overlap = h->overlapFixed = (uint32_t) std::max(1, x); }
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x * (1024 / RBU); }   // (in units of 1024 positions)
+    if (const char *e = getenv("SWSEM_RB_MIN")) { int x = atoi(e); if (x >= RBU && x <= 65536) h->rbMin = (uint32_t) x / RBU; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
     if (const char *e = getenv("SWSEM_LAP_TAGS")) h->useTags = h->useTags && atoi(e) != 0;
@@ -1869,14 +1878,15 @@ int swsem_emit_result(swsem_t *h, int k, swsem_streams_t *out) {
     { int e = end_slot(h, (int) (&E - h->slot)); if (e) return e; }
     if (k < 0 || k >= (int) E.eout.size()) return fail(SWSEM_EINVAL, "swsem_emit_result: no result %d", k);
     if (!E.hostStreamsValid) {
-        if (E.hostStreams.reserve(E.packedBytes + 1)) return fail(SWSEM_ENOMEM, "cannot pin %llu B of host memory", (unsigned long long) E.packedBytes);
-        if (E.packedBytes) HIPCHK(hipMemcpyAsync(E.hostStreams.data(), E.dEArena.p, E.packedBytes, hipMemcpyDeviceToHost, h->s3()));
+        E.hostAt ^= 1;
+        if (E.hostStreams().reserve(E.packedBytes + 1)) return fail(SWSEM_ENOMEM, "cannot pin %llu B of host memory", (unsigned long long) E.packedBytes);
+        if (E.packedBytes) HIPCHK(hipMemcpyAsync(E.hostStreams().data(), E.dEArena.p, E.packedBytes, hipMemcpyDeviceToHost, h->s3()));
         HIPCHK(hipStreamSynchronize(h->s3()));
         E.hostStreamsValid = true;
     }
     const EmitOut &o = E.eout[k];
     for (int st = 0; st < SWSEM_NSTREAMS; st++) {
-        out->data[st] = E.hostStreams.data() + E.hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st];
+        out->data[st] = E.hostStreams().data() + E.hostStreamOff[(size_t) k * SWSEM_NSTREAMS + st];
         out->size[st] = o.size[st];
     }
     out->unmatchedChars = o.unmatchedChars;

@@ -604,10 +604,12 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
     auto collect = [&](const Deferred &D, bool newerBegun) {
         RoundBatch &B = *D.B;
         const double tc0 = nowSeconds();
-        appendsDone();
+        appendsDone();                                                      // (one set of appends outstanding at a time)
+        const double tc1 = nowSeconds();
+        g_tAppendWait += tc1 - tc0;
         if (newerBegun) matcher->emitSelect(true);
         if (!bench && D.c1 > D.c0) { swsem_streams_t st = {}; matcher->emitView(0, st); }   // (waits for the emission and its copy)
-        g_tCollectWait += nowSeconds() - tc0;
+        g_tCollectWait += nowSeconds() - tc1;
         auto views = std::make_shared<std::vector<swsem_streams_t>>();
         auto perTarget = std::make_shared<std::vector<uint32_t>>();
         size_t c = D.c0;                                                    // (the contigs of a round are in target order)
@@ -732,10 +734,10 @@ void MultipleGenomeMatchingProcessor::processTargetsRounds() {
                 spec.factor = params->currentUnmatchedFractionFactor; spec.rcFactor = params->rcInReference ? params->unmatchedFractionRCFactor : 0;
             }
             const size_t before = matcher->getLoadedRefLength();
-            const double ta0 = nowSeconds();
-            appendsDone();                                                  // (this emission's slot is the one those views point into)
+            // (the appends of the emission before the last one may still be running: their views point into the host buffer this
+            // slot used LAST time, and the library gives every slot two of them in turn — include/mbgc_swsem.h; collect() below
+            // waits for them before it queues the next ones, so at most one set of appends is ever outstanding)
             const double te0 = nowSeconds();
-            g_tAppendWait += te0 - ta0;
             const bool applied = matcher->emitRoundBegin(emitParams(), locks, factors, processed, tidx, loadedPositions(),
                                                          useSpec ? &spec : nullptr, un, counts);   // :381
             g_tEmit += nowSeconds() - te0;

@@ -28,7 +28,7 @@ for i in range(n):
 with open(os.path.join(d, "list.txt"), "w") as f:
     f.write("\n".join(paths) + "\n")
 out = {}
-runs = [("m3", ["-m", "3"]), ("m1_rounds", []), ("m1_t1", ["-t1"])]
+runs = [("m3", ["-m", "3"]), ("m1_rounds", []), ("m1_rounds_again", []), ("m1_rounds_third", []), ("m1_t1", ["-t1"])]   # (the rounds three times: the first round's file reads and page-locked buffers make runs differ by tens of milliseconds)
 if os.environ.get("MBGC_MIX_RUNS"):                  # e.g. "R2:-R 2,R4:-R 4": other command lines instead of the three above
     runs = [(x.split(":")[0], x.split(":")[1].split()) for x in os.environ["MBGC_MIX_RUNS"].split(",")]
 for name, args in runs:
@@ -47,5 +47,6 @@ for name, args in runs:
         out[name]["host_threads"] = where[-1]
     if r.returncode:
         sys.stderr.write(r.stderr[-800:])
-print(json.dumps(dict(genomes=n, bases=bases, runs=out)))
+rounds = sorted(v["gbases_per_s"] for k, v in out.items() if k.startswith("m1_rounds") and v.get("gbases_per_s"))
+print(json.dumps(dict(genomes=n, bases=bases, m1_rounds_median_gbases_per_s=rounds[len(rounds) // 2] if rounds else None, runs=out)))
 subprocess.run(["rm", "-rf", d])
