@@ -255,13 +255,17 @@ void MultipleGenomeMatchingProcessor::startReadAhead(uint32_t f0, uint32_t f1, i
     readAhead.f0 = f0; readAhead.f1 = f1; readAhead.slot = slot; readAhead.active = true;
     StagedFiles *S = &staged[slot], *O = &staged[1 - slot];
     readAhead.done = std::async(std::launch::async, [this, S, O, f0, f1, bothBuffers] {
+        const double ta = nowSeconds();
         readFiles(*S, f0, f1);
+        const double tb = nowSeconds();
         // (page-locking a round's worth of memory takes tens of milliseconds and holds up the uploads queued meanwhile: the
         // second staging buffer is made here, beside the matcher's construction, not beside the first round)
         if (bothBuffers && S->error.empty() && O->cap < S->cap) {
             void *p = nullptr;
             if (mbgc_fasta_host_alloc(fasta, S->cap, &p) == 0) { O->pin = (uint8_t *) p; O->cap = S->cap; }
         }
+        if (getenv("MBGC_HIP_TIMES") && f0 <= 1)
+            fprintf(stderr, "  first read-ahead: files %u..%u read in %.0f ms (their page-locked buffer included), the second buffer in %.0f ms\n", f0, f1, (tb - ta) * 1e3, (nowSeconds() - tb) * 1e3);
     });
 }
 
@@ -322,7 +326,7 @@ void MultipleGenomeMatchingProcessor::prepareRound(uint32_t f0, uint32_t f1, Rou
     if (readAhead.active) {
         readAhead.done.wait();
         readAhead.active = false;
-        if (readAhead.f0 == f0 && readAhead.f1 == f1) S = &staged[readAhead.slot];
+        if (readAhead.f0 == f0 && readAhead.f1 >= f1) S = &staged[readAhead.slot];             // (the first read-ahead works from a guessed round size: a file or two too many are read again later)
     }
     g_tReadWait += nowSeconds() - tWait0;
     if (!S) { S = &staged[staged[1].cap > staged[0].cap ? 1 : 0]; readFiles(*S, f0, f1); }   // (the buffer that has been allocated)
@@ -332,8 +336,8 @@ void MultipleGenomeMatchingProcessor::prepareRound(uint32_t f0, uint32_t f1, Rou
     }
     const std::vector<uint64_t> &fileOff = S->fileOff;
     const double tParse0 = nowSeconds();
-    totalFilesLength += fileOff.back();
-    const size_t n = fileOff.back();
+    const size_t n = fileOff[nf];                            // (the staged files may be more than this round's)
+    totalFilesLength += n;
     if (n + 64 > rawCap) {                                   // grow-only: freeing device memory waits for the whole device
         if (rawDev) matcher->devFree(rawDev);
         rawCap = n + n / 4 + 64;
@@ -1059,15 +1063,22 @@ void MBGC_Encoder::encode(const std::vector<std::string> &files) {
             int tmp = 15 - (__builtin_clz((unsigned) filesCount) / 3);
             guessParams.referenceFactor = 1 << (tmp < 5 ? 5 : (tmp > 12 ? 12 : tmp));
         }
-        MBGC_Params *keep = params; params = &guessParams;
+        // (refLengthLimitFor is the base class's and reads ITS parameter pointer: until round 4 only this class's was pointed at the
+        // guess, the limit came out 0 and the first read-ahead fetched 64 files — read again, 28 of them, by the first round)
+        MGMP_Params *keep = MultipleGenomeMatchingProcessor::params;
+        MultipleGenomeMatchingProcessor::params = &guessParams;
         const size_t lim = refLengthLimitFor(std::max<size_t>(g0, MGMP_Params::MIN_BASIC_BLOCK_SIZE), nullptr);
-        params = keep;
+        MultipleGenomeMatchingProcessor::params = keep;
         params->roundSize = (int) windowRoundSize(params->circularReference ? lim / (size_t) params->referenceSlidingWindowFactor : 0, gpus);
     }
     if (!params->sequentialMatching && !params->exchange)
         startReadAhead(1, std::min<uint32_t>(filesCount, 1 + (uint32_t) std::max(1, params->roundSize)), 1, readBesideUpload());
+    const double tG0 = nowSeconds();
     loadG0Ref(fileNames[0]);
+    if (getenv("MBGC_HIP_TIMES")) fprintf(stderr, "  loadG0Ref (the matcher's buffers and table, the first file): %.0f ms\n", (nowSeconds() - tG0) * 1e3);
+    const int guessed = params->roundSize;
     if (autoRound) params->roundSize = (int) windowRoundSize(matcher->getSlidingWindowSize(), gpus);   // (the window as the matcher has it)
+    if (getenv("MBGC_HIP_TIMES") && autoRound) fprintf(stderr, "  round size: %d (guessed %d for the first read-ahead)\n", params->roundSize, guessed);
     params->emit.enable40bitReference = params->enable40bitReference;
     if (params->lazyDecompressionSupport) refExtLoadedPosArr.emplace_back(matcher->getLoadingPosition());   // ENC.cpp:789-791
     performMatching();

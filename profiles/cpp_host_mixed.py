@@ -16,17 +16,11 @@ sys.path.insert(0, ROOT)
 from mbgc_amd import synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-d = tempfile.mkdtemp(prefix="mbgc_mix_", dir=os.environ.get("TMPDIR", "/tmp"))
-coll = synth.MixedSpecies()
-paths, bases = [], 0
-for i in range(n):
-    p = os.path.join(d, "m%05d.fa" % i)
-    with open(p, "wb") as f:
-        f.write(coll.fasta(i))
-    bases += sum(c.size for c in coll.contigs(i))
-    paths.append(p)
-with open(os.path.join(d, "list.txt"), "w") as f:
-    f.write("\n".join(paths) + "\n")
+# the files are written by forked workers (bench.py's helper, as for its configs[4] line): written by this one process they all
+# sat in the page cache of its NUMA node, and the tool's reader threads — bound to the GPU's node — read them at half the rate
+import bench  # noqa: E402
+d = bench.write_mixed_species(n)
+bases = json.load(open(os.path.join(d, "meta.json")))["bases"]
 out = {}
 runs = [("m3", ["-m", "3"]), ("m1_rounds", []), ("m1_rounds_again", []), ("m1_rounds_third", []), ("m1_t1", ["-t1"])]   # (the rounds three times: the first round's file reads and page-locked buffers make runs differ by tens of milliseconds)
 if os.environ.get("MBGC_MIX_RUNS"):                  # e.g. "R2:-R 2,R4:-R 4": other command lines instead of the three above

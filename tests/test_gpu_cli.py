@@ -100,12 +100,16 @@ def crlf(c):
 # one and two targets); "crlf": CRLF line ends; "gz": gzip files
 @pytest.mark.parametrize("args,rs,div", [(["-t1"], 0, 0.015), (["-R", "3"], 3, 0.015), (["-R", "8"], 8, 0.015), (["-R", "2"], 2, 0.001),
                                          (["-R", "3"], 3, 0.06), (["-R", "6"], 6, "mixed"), (["-R", "7"], 7, "mixed"), (["-R", "5"], 5, 0.06),
+                                         (["-m", "0", "-R", "8"], 8, "mixed2"), (["-m", "2", "-R", "5"], 5, "mixed2"),
                                          (["-R", "3"], 3, "crlf"), (["-t1"], 0, "crlf"), (["-R", "3"], 3, "gz"), (["-t1"], 0, "gz")])
 def test_synthetic_files_equal_oracle_driver(tmp_path, args, rs, div):
     base = synth.base_codes(70_000, 55)
     cr, gz = div == "crlf", div == "gz"
+    mode = int(args[args.index("-m") + 1]) if "-m" in args else 1
     if div == "mixed":
         gs = [synth.genome(base, i, 0.07 if i % 3 == 2 else 0.004) for i in range(16)]
+    elif div == "mixed2":       # two genomes of three far from the rest: -m0 goes on in units of up to five stopped targets, -m2 in units of one
+        gs = [synth.genome(base, i, 0.004 if i % 3 == 1 else 0.07) for i in range(18)]
     else:
         gs = [synth.genome(base, i, 0.015 if cr or gz else div) for i in range(8)]
     files = [split(g, 2) for g in gs]
@@ -135,9 +139,9 @@ def test_synthetic_files_equal_oracle_driver(tmp_path, args, rs, div):
         streams = oe.streams()
         g0lit = files[0][0].tobytes() + b"\xa2"
     else:
-        lim, _ = _driver.ref_length_limit(len(files), sum(c.size for c in files[0]))
-        o = _orc.OracleMatcher(lim)
-        res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o), files[0], files[1:], rs)
+        lim, _ = _driver.ref_length_limit(len(files), sum(c.size for c in files[0]), mode=mode)
+        o = _orc.OracleMatcher(lim, skip_margin=24 if mode >= 2 else 16)
+        res = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o, _orc.emit_params(mode)), files[0], files[1:], rs, _driver.Policy(mode))
         streams = res["streams"]
         g0lit = b"".join(c.tobytes() + b"\xa2" for c in files[0])
     got = {k: (tmp_path / ("out." + k)).read_bytes() for k in ("literals", "mapOff", "mapOff5th", "mapLen", "gapDelta", "flags", "locksPos", "refExtSize")}

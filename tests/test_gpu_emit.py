@@ -87,6 +87,35 @@ def test_emission_rounds_with_locks_and_wrap(binding, round_size):
     assert o.loaded_ref_length() > lim
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_rounds_that_go_on_in_units_of_other_sizes(binding, mode):
+    """a round whose first pass gives contigs up goes on in units of allowedTargetsOutrunForDissimilarContigs + 1 stopped targets
+    (tests/_driver.py): -m0 allows an outrun of 4 (units of up to five, and only the last three targets of a round of 8 can stop),
+    -m2 none (units of one, every target but the first can). Two genomes of three are 7 % from the rest."""
+    base = synth.base_codes(60_000, 77)
+    gs = [synth.genome(base, i, 0.004 if i % 3 == 1 else 0.07) for i in range(18)]
+    targets = [[g[:25_000], g[25_000:]] for g in gs[1:]]
+    lim = 3_000_000
+    margin = 24 if mode >= 2 else 16
+    h = binding.SlidingWindowSparseEMMatcher(lim, skip_margin=margin)
+    o = _orc.OracleMatcher(lim, skip_margin=margin)
+    pol = _driver.Policy(mode)
+    stops = []
+
+    class Watch(_orc.OracleEmitter):
+        def process(s, m, contig, lock, factor, processed, t, loaded):
+            r = super().process(m, contig, lock, factor, processed, t, loaded)
+            if r == _driver.SKIPPED:
+                stops.append(t)
+            return r
+    a = _driver.encode_rounds(h, lambda: HipEmitter(binding, h, binding.emit_params(mode)), [gs[0]], targets, 8, pol)
+    b = _driver.encode_rounds(o, lambda: Watch(o, _orc.emit_params(mode)), [gs[0]], targets, 8, pol)
+    assert a["locks"] == b["locks"] and a["refExtSize"] == b["refExtSize"] and a["unmatched"] == b["unmatched"]
+    compare(a["streams"], b["streams"])
+    assert len(set(stops)) >= 3, stops
+    assert all(t % 8 > pol.outrun for t in stops), stops                # (ENC.cpp:203: never with processed >= targetIdx - outrun)
+
+
 def test_emission_mixed_alphabet_and_edges(binding):
     """lower case, N runs, IUPAC codes, a contig without matches, a tiny contig, an identical contig"""
     rng = np.random.default_rng(8)

@@ -231,6 +231,42 @@ def test_emission_rounds_with_locks_and_wrap(refh, round_size):
     assert o.loaded_ref_length() > lim
 
 
+@pytest.mark.parametrize("mode,round_size", [(0, 8), (1, 6), (2, 5)])
+def test_rounds_that_go_on_in_units(refh, mode, round_size):
+    """the round drive of tests/_driver.py on collections whose rounds hold stopped targets in front of, between and behind kept
+    ones (two genomes of three 7 % from the rest), with the reference's own processMatches behind it — units of five (-m0), two
+    (-m1) and one (-m2) stopped targets; what the oracle restates must be what the reference does under that drive"""
+    base = synth.base_codes(60_000, 77)
+    gs = [synth.genome(base, i, 0.004 if i % 3 == 1 else 0.07) for i in range(18)]
+    targets = [[g[:25_000], g[25_000:]] for g in gs[1:]]
+    lim = 3_000_000
+    margin = 24 if mode >= 2 else 16
+    r, o = both(refh, lim, skip_margin=margin)
+    pol = _driver.Policy(mode)
+    ad = RefEmitAdapter(refh, r, n_targets=len(targets), mode=mode)
+    cnt = {"t": 0}
+    resets = []
+
+    def make_ref():
+        class E:
+            def __init__(s): s.t = cnt["t"]; cnt["t"] += 1; s.v = ad.view(s.t)
+            def process(s, *a): return s.v.process(*a)
+            def put(s, which, data): ad.e.after_sequence(s.t) if which == 0 else ad.e.after_target(s.t)
+            def streams(s): return ad.e.streams(s.t)
+            def reset(s): resets.append(s.t); ad.e.reset_target(s.t); return s
+        return E()
+
+    a = _driver.encode_rounds(r, make_ref, [gs[0]], targets, round_size, pol)
+    b = _driver.encode_rounds(o, lambda: _orc.OracleEmitter(o, _orc.emit_params(mode)), [gs[0]], targets, round_size, pol)
+    assert a["locks"] == b["locks"] and a["refExtSize"] == b["refExtSize"] and a["unmatched"] == b["unmatched"]
+    for x, y in zip(a["matches"], b["matches"]):
+        assert np.array_equal(x, y)
+    for k in a["streams"]:
+        assert a["streams"][k] == b["streams"][k], k
+    assert_same_state(r, o)
+    assert len(resets) >= 3 and len(resets) < len(targets), resets      # (some targets were matched again, some kept the first pass)
+
+
 @pytest.mark.parametrize("round_size,laps", [(1, 5), (4, 2)])
 def test_five_laps_of_the_buffer(refh, round_size, laps):
     """the collection of tests/test_gpu_laps.py (five laps of a 2.4 MB buffer with rounds of 1; with rounds of 4 the lock
