@@ -1158,8 +1158,20 @@ __device__ uint32_t gap_right(const EmitView &v, const EmitContig &cg, const Rig
     return pos;
 }
 
+// The task of a thread in a block that serves one chunk of 256 gap tasks with 256 * S threads: a wave holds 64 / S tasks in
+// its first lanes. A wave walks the long stretches of its tasks one after the other (all lanes on each), so on sequence that
+// diverges by a few percent — every gap a stretch of hundreds of bytes — a wave's time is its number of tasks: a batch that
+// cannot fill the chip with waves of 64 tasks (one contig of the sequential schedule, a unit of two targets) is launched with
+// S = 4, four times the waves and a quarter of the stretches each; -1: a lane without a task.
+template <int S>
+__device__ __forceinline__ int64_t chunk_task(uint32_t gx) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    return lane < (uint32_t) (WAVE / S) ? (int64_t) gx * 256 + wave * (WAVE / S) + lane : -1;
+}
+
 // sizes of every gap task, one block per chunk of 256 tasks
-__global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig *__restrict__ cgs) {
+template <int S>
+__global__ void __launch_bounds__(256 * S) k_emit_sizes(EmitView v, const EmitContig *__restrict__ cgs) {
     const uint32_t gk = v.chunkOwner[blockIdx.x];
     const EmitContig cg = cgs[gk];
     const uint32_t gx = blockIdx.x - cg.chunk0;
@@ -1167,7 +1179,8 @@ __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
     if ((int64_t) gx * 256 > n) return;
-    const int64_t t = (int64_t) gx * 256 + threadIdx.x;
+    const int64_t tt = chunk_task<S>(gx);
+    const int64_t t = tt < 0 ? n + 1 : tt;                          // (a lane without a task: beyond the last one)
     uint32_t cloc[2] = {0, 0};
     const EMatch *E = v.em + cg.scratchBase;
     const uint8_t *q = v.qbuf + cg.qoff;
@@ -1231,12 +1244,12 @@ __global__ void __launch_bounds__(256) k_emit_sizes(EmitView v, const EmitContig
         cloc[1] += (uint32_t) __shfl_down((int) cloc[1], d);
     }
     // one pair of atomics per block: every block of a contig adds to the same two words
-    __shared__ uint32_t part[2 * (256 / WAVE)];
+    __shared__ uint32_t part[2 * (256 * S / WAVE)];
     if ((threadIdx.x & (WAVE - 1)) == 0) { part[2 * (threadIdx.x / WAVE)] = cloc[0]; part[2 * (threadIdx.x / WAVE) + 1] = cloc[1]; }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long a = 0, b = 0;
-        for (int w = 0; w < 256 / WAVE; w++) { a += part[2 * w]; b += part[2 * w + 1]; }
+        for (int w = 0; w < 256 * S / WAVE; w++) { a += part[2 * w]; b += part[2 * w + 1]; }
         if (a | b) {
             atomicAdd((unsigned long long *) &v.out[gk].extMatched, a);
             atomicAdd((unsigned long long *) &v.out[gk].extMismatches, b);
@@ -1374,14 +1387,16 @@ __global__ void __launch_bounds__(CH) k_emit_place_final(EmitView v, const EmitC
 // literals — the unmatched stretch of a divergent contig can be megabytes — is not one thread's work: the wave
 // copies it together, 16 bytes per lane and round.
 constexpr uint32_t PLAIN_INLINE = 48;                                  // plain literals a thread copies itself
-__global__ void __launch_bounds__(256) k_emit_write(EmitView v, const EmitContig *__restrict__ cgs) {
+template <int S>
+__global__ void __launch_bounds__(256 * S) k_emit_write(EmitView v, const EmitContig *__restrict__ cgs) {
     const uint32_t gk = v.chunkOwner[blockIdx.x];
     const EmitContig cg = cgs[gk];
     const uint32_t gx = blockIdx.x - cg.chunk0;
     const EmitOut o = v.out[gk];
     if (o.unmatchedChars == UINT64_MAX) return;
     const int64_t n = (int64_t) o.nmatches;
-    const int64_t t = (int64_t) gx * 256 + threadIdx.x;
+    const int64_t tt = chunk_task<S>(gx);
+    const int64_t t = tt < 0 ? n + 1 : tt;                          // (a lane without a task: beyond the last one)
     const uint8_t *q = v.qbuf + cg.qoff;
     uint32_t longLen = 0;
     const uint8_t *longSrc = nullptr;

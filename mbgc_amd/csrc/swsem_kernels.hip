@@ -863,7 +863,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     constexpr int TW = 3 * SNAP;       // u64 words of the newest-rows window
     __shared__ uint64_t ptop[TW];      // newest true rows, newest first, {posSrc, len, posDest} each
     int known = 0;                     // rows of ptop that are valid
-    uint32_t replayed = 0;
+    uint32_t replayed = 0, nFast = 0, nSlow = 0, nSkip = 0;   // (diagnostics: blocks accepted in runs / tested one by one / jumped over)
     const BlockRec *rc = recs + cg.rb0;
     const int32_t span = (int32_t) (rb * RBU);
     const int32_t npos = cg.n >= (uint64_t) v.K ? (int32_t) (cg.n - v.K + 1) : 0;
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     for (uint32_t b = 0; b < cg.nrb; b++) {
         if ((b & (WAVE - 1)) == 0) fr = b + lane < cg.nrb ? ((const uint4 *) (fast + cg.rb0))[b + lane] : make_uint4(0, 0, 0, 0xFFFFFFFFu);
         const int32_t w0 = (int32_t) b * span;
-        if (scanT >= w0 + span) { prevPlain = false; continue; }  // the sequential loop jumped over this block
+        if (scanT >= w0 + span) { prevPlain = false; nSkip++; continue; }  // the sequential loop jumped over this block
         const int fl = (int) (b & (WAVE - 1));
         const int32_t fPop = (int32_t) rl32(fr.w, fl);
         if (prevPlain && fPop >= 0) {
@@ -915,8 +915,10 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
             scanT = (int32_t) rl32(fr.x, fl + L - 1);
             known = 0;                                          // the newest-rows window is rebuilt from the list if ever needed
             b += (uint32_t) (L - 1);
+            nFast += (uint32_t) L;
             continue;
         }
+        nSlow++;
         {                                                       // the complete test needs the whole record
             const uint4 *src = (const uint4 *) (rc + b);
             for (uint32_t i = lane; i < sizeof(BlockRec) / 16; i += WAVE) srec[i] = src[i];
@@ -1038,6 +1040,9 @@ __global__ void __launch_bounds__(WAVE) k_stitch(RefView v, const uint8_t *__res
     if (lane == 0) {
         matchCount[blockIdx.x] = run;
         atomicAdd(&stats[3], (unsigned long long) replayed);
+        atomicAdd(&stats[5], (unsigned long long) nFast);
+        atomicAdd(&stats[6], (unsigned long long) nSlow);
+        atomicAdd(&stats[7], (unsigned long long) nSkip);
     }
 }
 

@@ -317,6 +317,8 @@ struct swsem {
     uint32_t overlap = 1024, overlapFixed = 0, batchBlocks = 0;
     uint32_t rb = 8;                       // length of a resolve block in units of RBU positions: chosen per batch (run_batch) unless SWSEM_RB fixes it
     uint32_t rbFixed = 0;
+    uint64_t stitchDiag[4] = {0, 0, 0, 0};  // over the handle's life: resolve blocks replayed / accepted in runs / tested one by one / jumped over (SWSEM_DEBUG_STATS)
+    uint32_t emitThinMax = 512;            // emissions of at most this many chunks of 256 gap tasks run their byte automata with 16 tasks per wave (SWSEM_EMIT_THIN_MAX)
     uint32_t rbMin = 2048 / RBU;           // shortest resolve block (units of RBU positions); SWSEM_RB_MIN=positions for A/B runs
     uint32_t slotPercent = 95;             // share of the wave slots a launch's blocks are sized for (80 %: +5 % on the 4.35e9-byte sizing, -3 % on configs[2]'s)
     uint32_t waveSlots = 256 * 4 * RESOLVE_WAVES_PER_SIMD;   // resolve waves the device holds at once (CUs x SIMDs x waves)
@@ -469,12 +471,16 @@ int run_phase2b(swsem *h, swsem::EmitSlot &E, bool gated) {
     const dim3 grid2(E.grid2b);
     const int n = E.n2b;
     h->mark(SWSEM_K_EMIT2, true, h->stream2);
-    k_emit_sizes<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
+    // (few chunks: a quarter of the tasks per wave, four times the waves — swsem_emit.hip, chunk_task)
+    const bool thin = E.grid2b <= h->emitThinMax;
+    if (thin) k_emit_sizes<4><<<grid2, dim3(1024), 0, h->stream2>>>(v, E.dECg.p);
+    else k_emit_sizes<1><<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
     k_emit_place_sums<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
     k_emit_place_scan<<<dim3(n), dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
     k_emit_packoffs<<<1, dim3(CH), 0, h->stream2>>>(v);
     k_emit_place_final<<<grid2, dim3(CH), 0, h->stream2>>>(v, E.dECg.p);
-    k_emit_write<<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
+    if (thin) k_emit_write<4><<<grid2, dim3(1024), 0, h->stream2>>>(v, E.dECg.p);
+    else k_emit_write<1><<<grid2, dim3(256), 0, h->stream2>>>(v, E.dECg.p);
     k_emit_copy_long<<<dim3(512), dim3(256), 0, h->stream2>>>(v);
     h->mark(SWSEM_K_EMIT2, false, h->stream2);
     HIPCHK(hipGetLastError());
@@ -1022,6 +1028,7 @@ void take_counts(swsem *h) {
     const unsigned long long *st = (const unsigned long long *) h->pin;
     h->matchCount.assign((const uint32_t *) (h->pin + 64), (const uint32_t *) (h->pin + 64) + n);
     h->stats[1] = h->hostProbes; h->stats[2] = st[2]; h->stats[5] = st[3];
+    h->stitchDiag[0] += st[3]; h->stitchDiag[1] += st[5]; h->stitchDiag[2] += st[6]; h->stitchDiag[3] += st[7];
     if (!h->overlapFixed && h->batchBlocks >= 2048) {              // (a batch large enough for the share to mean something)
         const uint64_t replayed = st[3];
         if (replayed * 400 > h->batchBlocks) h->overlap = std::min<uint32_t>((uint32_t) OVERLAP_MAX, h->overlap + 128);         // > 0.25 %: longer
@@ -1153,6 +1160,7 @@ int swsem_create(swsem_t **out, uint64_t maxRefLength, int L, int k1, int k2, in
     if (const char *e = getenv("SWSEM_META_WARM")) h->metaWarm = std::min(swk::MWARM, std::max(0, atoi(e)));
     if (const char *e = getenv("SWSEM_OVERLAP")) { int x = atoi(e); if (x >= 0 && x <= OVERLAP_MAX) h->overlap = h->overlapFixed = (uint32_t) std::max(1, x); }
     if (const char *e = getenv("SWSEM_RB")) { int x = atoi(e); if (x >= 1 && x <= 256) h->rbFixed = (uint32_t) x * (1024 / RBU); }   // (in units of 1024 positions)
+    if (const char *e = getenv("SWSEM_EMIT_THIN_MAX")) h->emitThinMax = (uint32_t) std::max(0, atoi(e));
     if (const char *e = getenv("SWSEM_RB_MIN")) { int x = atoi(e); if (x >= RBU && x <= 65536) h->rbMin = (uint32_t) x / RBU; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->waveSlots = (uint32_t) pr.multiProcessorCount * 4u * RESOLVE_WAVES_PER_SIMD; }
     const size_t nSlots = (size_t) ((maxRefLength + REF_SLACK) >> h->k1ord) + 2;
@@ -1191,6 +1199,9 @@ void swsem_destroy(swsem_t *h) {
     if (h->streamUp) (void) hipStreamSynchronize(h->streamUp);
     if (h->streamAux) (void) hipStreamSynchronize(h->streamAux);
     h->drain_events();
+    if (getenv("SWSEM_DEBUG_STATS"))
+        fprintf(stderr, "swsem stitch: blocks replayed %llu, accepted in runs %llu, tested one by one %llu, jumped over %llu\n",
+                (unsigned long long) h->stitchDiag[0], (unsigned long long) h->stitchDiag[1], (unsigned long long) h->stitchDiag[2], (unsigned long long) h->stitchDiag[3]);
     if (getenv("SWSEM_DEBUG_STATS")) {                               // diagnostics: the pairing chain's counters of this handle
         uint64_t t[8];
         if (swsem_debug_emit_stats(h, t) == SWSEM_OK && (t[4] | t[5] | t[6] | t[7]))

@@ -464,15 +464,25 @@ void MultipleGenomeMatchingProcessor::verifyEmission(size_t contigs, size_t base
 void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
     RoundBatch three[3];                   // the file being matched, the file arriving, the file whose last contig's emission still reads its bytes
     struct { bool valid = false; int fileSeps = 0; uint32_t buf = 0; } prev;                   // the contig whose streams are still to be taken
+    // the appends run on a thread of their own, one set at a time (a divergent contig's streams are megabytes: 0.2 ms of memcpy
+    // between a contig's first pass and its loadRef otherwise); the views stay valid meanwhile — every emission slot keeps two
+    // host buffers in turn (include/mbgc_swsem.h)
+    std::future<void> appending;
+    auto appendsDone = [&] { if (appending.valid()) appending.get(); };
     auto collectPrev = [&](bool newerBegun) {
+        appendsDone();
+        swsem_streams_t st = {};
+        const bool has = prev.valid;
         if (prev.valid) {
             if (newerBegun) matcher->emitSelect(true);
-            swsem_streams_t st = {};
             matcher->emitView(0, st);
-            appendContigInOrder(st);                                                            // processMatches' appends + processAfterSequence (:276, :288)
             if (newerBegun) matcher->emitSelect(false);
         }
-        for (int k = 0; k < prev.fileSeps; k++) endTargetInOrder();                             // processAfterTarget (:306)
+        const int seps = prev.fileSeps;
+        appending = std::async(std::launch::async, [this, st, has, seps] {
+            if (has) appendContigInOrder(st);                                                   // processMatches' appends + processAfterSequence (:276, :288)
+            for (int k = 0; k < seps; k++) endTargetInOrder();                                  // processAfterTarget (:306)
+        });
         prev.valid = false; prev.fileSeps = 0;
     };
     const std::vector<uint64_t> noLock(1, UINT64_MAX);                                          // :274 (no lock in this mode)
@@ -507,6 +517,7 @@ void MultipleGenomeMatchingProcessor::processTargetsWithParallelIO() {
     }
     if (prev.valid) matcher->emitEnd();
     collectPrev(false);
+    appendsDone();
     if (ahead.active) { ahead.done.wait(); ahead.active = false; }
     for (auto &B : three) if (B.seqDev) matcher->devFree(B.seqDev);
 }
