@@ -533,7 +533,11 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
         uint64_t tmpLength = len;
         const uint64_t tmpMax = tmpEnd < (uint64_t) h->pos1 ? h->maxRefLength : tmpEnd;
         if ((uint64_t) h->pos1 + tmpLength > tmpMax) tmpLength = tmpMax - (uint64_t) h->pos1;
-        {
+        // (a loader that stands at the window's end with that byte already the separator writes nothing — every further target of a
+        // round whose loads have filled the window: no emission has to be waited for then; on collections that load every contig
+        // with its reverse complement that is the second half of most rounds)
+        const bool sepWrite = addSep && (uint64_t) h->pos1 + tmpLength == h->swEnd && !(tmpLength == 0 && h->sep_end_done(sep));
+        if (tmpLength || sepWrite) {
             // bytes this step writes: the copy, and the separator at the window's end when the copy reaches it
             // (a window that wraps has its end BELOW the loading position: only a loader that stands AT the end writes the byte before it)
             const uint64_t first = (uint64_t) h->pos1 == h->swEnd ? h->swEnd - 1 : (uint64_t) h->pos1;
@@ -554,7 +558,7 @@ int load_pieces(swsem *h, const uint8_t *text, uint64_t len, bool rc, bool addSe
                 HIPCHK(hipMemcpyAsync(h->ref + h->pos1, text, tmpLength, hipMemcpyDeviceToDevice, h->stream));
             h->mark(SWSEM_K_LOAD, false);
         }
-        if (addSep && (uint64_t) h->pos1 + tmpLength == h->swEnd && !(tmpLength == 0 && h->sep_end_done(sep))) {
+        if (sepWrite) {
             // (with the window full every target of a round comes by here and through loadSeparator's same case: once is enough)
             if (h->deferInserts) { BytePiece bp; bp.off = h->swEnd - 1; bp.val = (uint64_t) (uint8_t) sep; h->pendingBytes.push_back(bp); }
             else k_set_byte<<<1, 1, 0, h->stream>>>(h->ref + h->swEnd - 1, (uint8_t) sep);
