@@ -23,8 +23,9 @@ them: a rank that dies ends the run within seconds with a line that says `"value
 
 Beside the headline, N = 1 only and never inside its timed region (`--no-extras` skips them): `cpp_host` — the product's C++
 host (`mbgc-hip c --bench`) on the same collection from FASTA files; `configs` — BASELINE configs[1] (128 genomes, matcher
-only) and the configs[4] data class and sizing (mixed-species genomes, `-m 3`, 4.5e9-byte reference with 40-bit offsets)
-through the C++ host, each with its match-finding kernel's roofline; `cpu_baseline` — the reference's own OpenMP path.
+only), the configs[4] data class and sizing (mixed-species genomes, `-m 3`, 4.5e9-byte reference with 40-bit offsets)
+and the same genomes in `-m1` rounds (rounds on a divergent collection go on in units) through the C++ host, each
+with its match-finding kernel's roofline; `cpu_baseline` — the reference's own OpenMP path.
 
 Diagnostics (never the headline): --no-emit (matcher only), --from-host (queries cross PCIe inside the timed region),
 --check (first round against the oracle); environment: MBGC_BENCH_MAX_REF (another buffer size), MBGC_BENCH_BLOCK_STATS
