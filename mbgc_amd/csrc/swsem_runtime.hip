@@ -1788,6 +1788,10 @@ static int emit_begin_impl(swsem_t *h, const swsem_emit_params_t *p, int n, cons
         if (!queued) restore();
     }
     if (specAsked) { if ((r = phase2b(queued))) return r; }
+    // While pass 1 runs: the emission before this one — its second phase ran beside this batch's match-finding — is taken now, its
+    // streams copied to the host (end_slot), instead of when the caller asks for them right after this call returns: on divergent
+    // collections that copy is megabytes per emission and stood between one unit's loads and the next unit's launch.
+    if (h->emitHostCopy) { int e = end_slot(h, si ^ 1); if (e) return e; }
     HIPCHK(hipEventSynchronize(h->evP1));                           // pass 1 and its copies to the host (not what was queued after them)
     if (needCounts) take_counts(h);
     E.eout.assign((const EmitOut *) (h->pin + h->pinExtraAt), (const EmitOut *) (h->pin + h->pinExtraAt) + n);
