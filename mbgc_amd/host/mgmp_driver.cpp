@@ -52,7 +52,7 @@ static void writeUInt64Frugal(std::string &dest, uint64_t value) {
 static double nowSeconds() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 // where the host's wall time goes (MBGC_HIP_TIMES=1 prints it with "matching finished"): reading + inflating files,
 // upload + device parse, taking the streams over
-static uint64_t g_retryPasses = 0, g_retryContigs = 0;          // passes of processRoundWithRetries and the contigs they matched
+static uint64_t g_retryPasses = 0, g_retryContigs = 0;          // rounds whose first pass gave contigs up, and the contigs of the targets matched again in units
 static double g_tRead = 0, g_tParse = 0, g_tCollect = 0, g_tWait = 0, g_tCollectWait = 0, g_tAppend = 0, g_tAppendWait = 0, g_tPrepareSync = 0, g_tReadWait = 0, g_tMatch = 0, g_tEmit = 0, g_tFinalize = 0;
 
 // ---------------------------------------------------------------- input stage
@@ -896,7 +896,7 @@ void MultipleGenomeMatchingProcessor::performMatching() {
     }
     if (getenv("MBGC_HIP_TIMES"))
         fprintf(stderr, "  reader threads: reading files %.0f ms; input thread: waiting for them %.0f ms, upload + parse %.0f ms; main thread: waiting for it %.0f ms, taking the streams over %.0f ms"
-                        " (%.0f of them waiting for the bytes; appends on their thread %.0f ms, waited for %.0f ms); rounds prepared by the main thread itself %.0f ms; match-finding calls %.0f ms, processMatches calls %.0f ms, loadRef calls %.0f ms; rounds cut at a dissimilar contig: %llu passes over %llu contigs\n",
+                        " (%.0f of them waiting for the bytes; appends on their thread %.0f ms, waited for %.0f ms); rounds prepared by the main thread itself %.0f ms; match-finding calls %.0f ms, processMatches calls %.0f ms, loadRef calls %.0f ms; rounds whose first pass gave contigs up as dissimilar: %llu, contigs matched again in units: %llu\n",
                 g_tRead * 1e3, g_tReadWait * 1e3, g_tParse * 1e3, g_tWait * 1e3, g_tCollect * 1e3, g_tCollectWait * 1e3, g_tAppend * 1e3, g_tAppendWait * 1e3, g_tPrepareSync * 1e3, g_tMatch * 1e3, g_tEmit * 1e3, g_tFinalize * 1e3,
                 (unsigned long long) g_retryPasses, (unsigned long long) g_retryContigs);
 }
