@@ -86,3 +86,40 @@ def test_spawner_bounds_the_whole_run():
     assert r.returncode != 0 and dt < 30
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines[0]["value"] is None and "limit" in lines[0]["error"]
+
+
+# ---- the lines bench.py adds beside the headline are put together from other programs' output: their format strings and regular
+# expressions are exercised here with stand-ins for those programs (a percent sign in one of them cost a round-4 run its configs[1] line)
+def _fake_tool(tmp_path, stdout, stderr):
+    p = tmp_path / "fake-tool"
+    p.write_text("#!/bin/sh\ncat <<'EOF_OUT'\n%s\nEOF_OUT\ncat >&2 <<'EOF_ERR'\n%s\nEOF_ERR\n" % (stdout, stderr))
+    p.chmod(0o755)
+    return str(p)
+
+
+def test_the_lines_beside_the_headline_are_put_together(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = ('kernel profile: {"load": {"ms": 7.0, "launches": 500}, "insert": {"ms": 12.0, "launches": 500}, "probe": {"ms": 0.0, "launches": 0}, '
+            '"emit2": {"ms": 230.0, "launches": 500}, "resolve": {"ms": 140.0, "launches": 500}, "stitch": {"ms": 90.0, "launches": 500}, "emit": {"ms": 13.0, "launches": 500}}')
+    out = "rounds of 28 targets; reference extension bytes dropped at the sliding window's end: 0\nfinal reference length: 1809744201\nexact matches total: 6954058\nswsMEM unmatched chars: 381336073\nfinal unmatched chars: 1"
+    monkeypatch.setattr(bench, "TOOL", _fake_tool(tmp_path, out, "matching finished - 432 [ms]\n" + prof))
+    (tmp_path / "meta.json").write_text(json.dumps({"genomes": 200, "bases": 909_000_000, "g0_bases": 5_000_000}))
+    (tmp_path / "list.txt").write_text("")
+    for rounds in (False, True):
+        line = bench.config4_line(str(tmp_path), rounds=rounds)
+        assert "error" not in line, line
+        assert line["value"] == round(904_000_000 / 0.432 / 1e9, 4) and line["roofline"]["kernel"] == "k_resolve_blocks4"
+        assert ("rounds of 28" in line["workload"]) == rounds and ("0.2-10 % divergence" in line["workload"]) != rounds
+    # configs[1]: a child bench.py whose last line is the diagnostic line of `--no-emit`
+    child = {"metric": "m", "value": 56.4, "unit": "Gbases/s", "ms_per_step": 1.4, "extension_bytes_dropped_per_step": 0.0,
+             "config": {"max_ref_len": 1_280_000_000, "targets_per_step": 16}, "roofline": {"frac": 0.036}, "kernel_ms_per_launch": {"resolve": 0.92}}
+
+    class R:
+        returncode = 0
+        stdout = json.dumps(child) + "\n"
+        stderr = ""
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: R())
+    line = bench.config1_line()
+    assert "error" not in line, line
+    assert line["value"] == 56.4 and "99% identity" in line["workload"] and "1.28e+09-byte" in line["workload"]
